@@ -1,0 +1,645 @@
+"""
+CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+A numpy/scipy restatement of the euispice_coreg `hdrshift.Alignment` correlation-sweep
+hot path.  Nothing in the product package (`euispice_coreg_amd/`) imports this module: it
+is used only by `tests/`, by `__graft_entry__.smoke()` and by `bench.py`'s `cpu_baseline`
+leg, as the checker / reported baseline -- never as the thing shipped or measured as GPU.
+
+Parity status ("pinning"):
+  * Carrington per-lag resample (rows a-13, a-14 of SURVEY.md section 8): PINNED against outputs
+    of the reference's own `utils/rectify.py` (CarringtonTransform + Rectifier + interpol2d)
+    run in the build container; vectors + generating script in `tests/golden/`.
+  * TAN pixel<->world (third-party astropy.wcs / wcslib, pinned astropy 7.2.0 in
+    poetry.lock, not vendored): restated from FITS WCS Paper II; PINNED by vectors generated
+    with astropy 4.3.1 / wcslib 7.6 (`tests/golden/make_golden_wcs.py`).
+  * `scipy.ndimage.map_coordinates` (third-party, pinned scipy 1.17.1): the oracle calls
+    scipy itself (1.15.3 here); a scalar model of its order-1/2 semantics is also restated
+    (`spline_sample_model`) and checked against scipy in tests.
+  * Pearson (`hdrshift/c_correlate.py:39-72`): restated; numba absent, arithmetic trivial.
+  * `AlignmentResults._compute_shift`: pinned by the reference's embedded fixture
+    (`hdrshift/test/test_AlignmentResults.py:33-126,172-173`).
+
+Each function cites the reference file:line it follows (paths relative to the reference
+repository root, `euispice_coreg/...`).
+
+Headers are plain `dict`s holding the FITS keywords the path reads.
+"""
+from __future__ import annotations
+
+import copy
+import math
+import multiprocessing as mp
+from multiprocessing import shared_memory
+
+import numpy as np
+from scipy.ndimage import map_coordinates
+
+R_SUN_M = 695700000.0  # astropy.constants.R_sun.value (IAU 2015 nominal), rectify.py:405
+
+_UNIT_TO_DEG = {"deg": 1.0, "arcsec": 1.0 / 3600.0, "arcmin": 1.0 / 60.0, "rad": 180.0 / math.pi,
+                "mas": 1.0 / 3600.0e3}
+
+
+def unit_to_deg(unit: str) -> float:
+    return _UNIT_TO_DEG[str(unit).strip()]
+
+
+# --------------------------------------------------------------------------------------
+# utils/Util.py:76-80
+def ang2pipi(ang_deg):
+    """Put an angle (degrees) in ]-180, +180].  Util.py:76-80."""
+    ang_deg = np.asarray(ang_deg, dtype=np.float64)
+    return -((-ang_deg + 180.0) % 360.0 - 180.0)
+
+
+def ang2pipi_unit(val, unit):
+    """ang2pipi on a value expressed in `unit` (what Quantity arithmetic does): the wrap is at
+    180 deg expressed in that unit.  Util.py:76-80 with astropy Quantity semantics."""
+    pi = 180.0 / unit_to_deg(unit)
+    val = np.asarray(val, dtype=np.float64)
+    return -((-val + pi) % (2 * pi) - pi)
+
+
+# --------------------------------------------------------------------------------------
+# utils/Util.py:82-104 == utils/rectify.py:22-56
+def interpol2d(image, x, y, fill, order, dst=None):
+    """scipy map_coordinates(order, mode='constant', cval=fill, prefilter=False).
+    Util.py:82-104 / rectify.py:22-56.  (`x == np.nan` guard there is always False.)"""
+    coords = np.stack((np.asarray(y).ravel(), np.asarray(x).ravel()), axis=0)
+    if dst is None:
+        dst = np.empty(np.shape(x), dtype=image.dtype)
+    out = dst.reshape(-1)  # view (dst is contiguous)
+    map_coordinates(image, coords, order=order, mode="constant", cval=fill, output=out, prefilter=False)
+    return dst
+
+
+def spline_sample_model(image, x, y, fill, order):
+    """Scalar-semantics model (vectorised numpy) of what scipy's NI_GeometricTransform does for
+    order 1/2, mode='constant', prefilter=False (scipy/ndimage/src/ni_interpolation.c; SURVEY a-14):
+      * coordinate c on an axis of length n: c<0 or c>n-1 or NaN -> whole sample = fill;
+      * order 2: start=floor(c+0.5)-1, t=c-floor(c+0.5), w0=.5(.5-t)^2, w1=.75-t^2, w2=1-w0-w1;
+        order 1: start=floor(c), t=c-start, w0=1-t, w1=t;
+      * taps outside [0,n-1] mirrored about the edge sample;
+      * value = sum over taps (row-major) of (v*wy)*wx in float64.
+    Used to pin the semantics the HIP kernel implements."""
+    image = np.asarray(image, dtype=np.float64)
+    ny_, nx_ = image.shape
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    shp = x.shape
+    x = x.ravel()
+    y = y.ravel()
+    with np.errstate(invalid="ignore"):
+        inb = (x >= 0) & (x <= nx_ - 1) & (y >= 0) & (y <= ny_ - 1)
+    xs = np.where(inb, x, 0.0)
+    ys = np.where(inb, y, 0.0)
+
+    def axis_weights(c, n):
+        if order == 2:
+            f = np.floor(c + 0.5)
+            t = c - f
+            w1 = 0.75 - t * t
+            h = 0.5 - t
+            w0 = 0.5 * h * h
+            w2 = 1.0 - w0 - w1
+            start = f.astype(np.int64) - 1
+            ws = [w0, w1, w2]
+        elif order == 1:
+            f = np.floor(c)
+            t = c - f
+            start = f.astype(np.int64)
+            ws = [1.0 - t, t]
+        else:
+            raise NotImplementedError(order)
+        idx = []
+        for k in range(order + 1):
+            i = start + k
+            if n > 1:
+                s2 = 2 * n - 2
+                i = np.where(i < 0, -i, i)
+                i = np.where(i >= n, s2 - i, i)
+            else:
+                i = np.zeros_like(i)
+            idx.append(i)
+        return ws, idx
+
+    wx, ix = axis_weights(xs, nx_)
+    wy, iy = axis_weights(ys, ny_)
+    acc = np.zeros_like(xs)
+    for a in range(order + 1):
+        for b in range(order + 1):
+            acc = acc + (image[iy[a], ix[b]] * wy[a]) * wx[b]
+    out = np.where(inb, acc, fill)
+    return out.reshape(shp)
+
+
+# --------------------------------------------------------------------------------------
+# hdrshift/c_correlate.py:39-72
+def c_correlate(s_1, s_2, lags=(0,)):
+    """Zero-lag Pearson coefficient as the reference's numba routine computes it
+    (mean, centred copies, sum of products / sqrt(sum sq * sum sq)).  c_correlate.py:39-72.
+    Empty input -> NaN (the reference divides by zero inside numba)."""
+    s_1 = np.asarray(s_1, dtype=np.float64)
+    s_2 = np.asarray(s_2, dtype=np.float64)
+    if s_1.size == 0:
+        return np.array([np.nan])
+    c1 = s_1 - float(np.mean(s_1))
+    c2 = s_2 - float(np.mean(s_2))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        r = np.sum(c1 * c2) / np.sqrt((c1 ** 2).sum() * (c2 ** 2).sum())
+    return np.array([r])
+
+
+# --------------------------------------------------------------------------------------
+# astropy.wcs.WCS restricted to 2-D TAN (FITS WCS papers I/II; wcslib prj.c tanx2s/tans2x,
+# sph.c sphx2s/sphs2x).  Call sites: alignment.py:1041-1065, Util.py:284-290.
+class TanWCS:
+    """2-D gnomonic WCS built from a header dict the way `astropy.wcs.WCS(hdr)` sees it on this
+    path: PCi_j + CDELT (PC present after alignment.py:580-611), CUNIT converted to degrees
+    (wcslib unitfix), LONPOLE default 180 deg."""
+
+    def __init__(self, hdr):
+        u1 = unit_to_deg(hdr.get("CUNIT1", "deg"))
+        u2 = unit_to_deg(hdr.get("CUNIT2", "deg"))
+        self.crpix = (float(hdr["CRPIX1"]), float(hdr["CRPIX2"]))
+        self.cdelt = (float(hdr["CDELT1"]) * u1, float(hdr["CDELT2"]) * u2)
+        self.crval = (float(hdr["CRVAL1"]) * u1, float(hdr["CRVAL2"]) * u2)
+        self.pc = np.array([[float(hdr.get("PC1_1", 1.0)), float(hdr.get("PC1_2", 0.0))],
+                            [float(hdr.get("PC2_1", 0.0)), float(hdr.get("PC2_2", 1.0))]])
+        self.lonpole = float(hdr.get("LONPOLE", 180.0))
+        self.naxis = (int(hdr["NAXIS1"]) if "NAXIS1" in hdr else None,
+                      int(hdr["NAXIS2"]) if "NAXIS2" in hdr else None)
+        if "ZNAXIS1" in hdr:
+            self.naxis = (int(hdr["ZNAXIS1"]), int(hdr["ZNAXIS2"]))
+
+    def pixel_to_world(self, px, py):
+        """0-based pixel -> (lon, lat) degrees (longitude normalised as wcslib does)."""
+        px = np.asarray(px, dtype=np.float64)
+        py = np.asarray(py, dtype=np.float64)
+        q1 = px + 1.0 - self.crpix[0]
+        q2 = py + 1.0 - self.crpix[1]
+        x = self.cdelt[0] * (self.pc[0, 0] * q1 + self.pc[0, 1] * q2)
+        y = self.cdelt[1] * (self.pc[1, 0] * q1 + self.pc[1, 1] * q2)
+        # tanx2s
+        r = np.hypot(x, y)
+        phi = np.where(r == 0.0, 0.0, np.degrees(np.arctan2(x, -y)))
+        theta = np.degrees(np.arctan2(180.0 / math.pi, r))
+        # sphx2s (wcslib sph.c): direction cosines; latitude via asin, or acos(hypot) when |z| > 0.99
+        a0, d0 = self.crval
+        dphi = np.radians(phi - self.lonpole)
+        th = np.radians(theta)
+        sd0, cd0 = math.sin(math.radians(d0)), math.cos(math.radians(d0))
+        sth, cth = np.sin(th), np.cos(th)
+        xx = sth * cd0 - cth * sd0 * np.cos(dphi)
+        yy = -cth * np.sin(dphi)
+        zz = sth * sd0 + cth * cd0 * np.cos(dphi)
+        dlng = np.degrees(np.arctan2(yy, xx))
+        lng = a0 + dlng
+        lat_a = np.degrees(np.arcsin(np.clip(zz, -1.0, 1.0)))
+        lat_b = np.copysign(np.degrees(np.arccos(np.clip(np.hypot(xx, yy), 0.0, 1.0))), zz)
+        lat = np.where(np.abs(zz) > 0.99, lat_b, lat_a)
+        # wcslib celx2s normalisation: sign of CRVAL1 decides [0,360) or (-360,0]
+        if a0 >= 0.0:
+            lng = np.where(lng < 0.0, lng + 360.0, lng)
+        else:
+            lng = np.where(lng > 0.0, lng - 360.0, lng)
+        lng = np.where(lng > 360.0, lng - 360.0, lng)
+        lng = np.where(lng < -360.0, lng + 360.0, lng)
+        return lng, lat
+
+    def world_to_pixel(self, lon, lat):
+        """(lon, lat) degrees -> 0-based pixel (x, y)."""
+        lon = np.asarray(lon, dtype=np.float64)
+        lat = np.asarray(lat, dtype=np.float64)
+        a0, d0 = self.crval
+        dl = np.radians(lon - a0)
+        la = np.radians(lat)
+        sd0, cd0 = math.sin(math.radians(d0)), math.cos(math.radians(d0))
+        sla, cla = np.sin(la), np.cos(la)
+        # sphs2x + tans2x in direction-cosine form (wcslib switches from asin(z) to acos(hypot(x, y)) when
+        # |z| > 0.99; r = r0 cos(theta)/sin(theta) is evaluated here from the cosines directly)
+        xx = sla * cd0 - cla * sd0 * np.cos(dl)
+        yy = -cla * np.sin(dl)
+        zz = sla * sd0 + cla * cd0 * np.cos(dl)
+        phi = np.radians(self.lonpole) + np.arctan2(yy, xx)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r = (180.0 / math.pi) * np.hypot(xx, yy) / zz
+        x = r * np.sin(phi)
+        y = -r * np.cos(phi)
+        bad = ~(zz > 0.0)
+        m = np.array([[self.cdelt[0] * self.pc[0, 0], self.cdelt[0] * self.pc[0, 1]],
+                      [self.cdelt[1] * self.pc[1, 0], self.cdelt[1] * self.pc[1, 1]]])
+        mi = np.linalg.inv(m)
+        q1 = mi[0, 0] * x + mi[0, 1] * y
+        q2 = mi[1, 0] * x + mi[1, 1] * y
+        px = q1 + self.crpix[0] - 1.0
+        py = q2 + self.crpix[1] - 1.0
+        px = np.where(bad, np.nan, px)
+        py = np.where(bad, np.nan, py)
+        return px, py
+
+
+def extract_EUI_coordinates(hdr):
+    """Longitude/latitude (degrees, ]-180,180]) of every pixel of `hdr`.  Util.py:282-312
+    (non-sunpy branch: list of Quantities, ang2pipi applied)."""
+    w = TanWCS(hdr)
+    x, y = np.meshgrid(np.arange(w.naxis[0]), np.arange(w.naxis[1]))
+    lon, lat = w.pixel_to_world(x, y)
+    return ang2pipi(lon), ang2pipi(lat)
+
+
+def extract_coordinates_pixels(header_initial_to_project, header_target_projection):
+    """Pixel coordinates, in `header_target_projection`, of every pixel of
+    `header_initial_to_project`.  alignment.py:1038-1069 (non-sunpy branch)."""
+    w_to = TanWCS(header_target_projection)
+    lon, lat = extract_EUI_coordinates(header_initial_to_project)
+    return w_to.world_to_pixel(lon, lat)
+
+
+# --------------------------------------------------------------------------------------
+# header logic
+def check_and_create_pcij_matrix(hdr, force_crota_0=False):
+    """alignment.py:580-611."""
+    if "PC1_1" not in hdr:
+        if "CROTA" in hdr:
+            crot = hdr["CROTA"]
+        elif "CROTA2" in hdr:
+            crot = hdr["CROTA2"]
+        else:
+            if force_crota_0:
+                crot = 0.0
+                hdr["CROTA"] = 0.0
+            else:
+                raise ValueError("No, CROTA, CROTA2 or PCi_j matrix in your FITS file.")
+        rho = np.deg2rad(crot)
+        lam = hdr["CDELT2"] / hdr["CDELT1"]
+        hdr["PC1_1"] = np.cos(rho)
+        hdr["PC2_2"] = np.cos(rho)
+        hdr["PC1_2"] = -lam * np.sin(rho)
+        hdr["PC2_1"] = (1 / lam) * np.sin(rho)
+    if hdr["PC1_1"] >= 1.0:
+        hdr["PC1_1"] = 1.0
+        hdr["PC2_2"] = 1.0
+        hdr["PC1_2"] = 0.0
+        hdr["PC2_1"] = 0.0
+        hdr["CROTA"] = 0.0
+    if "CROTA" not in hdr:
+        s = -np.sign(hdr["PC1_2"]) + (hdr["PC1_2"] == 0)
+        hdr["CROTA"] = s * np.rad2deg(np.arccos(hdr["PC1_1"]))
+
+
+class SweepState:
+    """The attributes of `Alignment` that the sweep reads (alignment.py:78-140, 799-842)."""
+
+    def __init__(self, hdr_small, hdr_large, data_small, data_large, lag_crval1, lag_crval2, lag_cdelt1,
+                 lag_cdelt2, lag_crota, lag_solar_r=None, unit_lag="arcsec", order=2,
+                 cdelt_semantics="intended"):
+        self.hdr_small = dict(hdr_small)
+        self.hdr_large = dict(hdr_large)
+        self.data_small = np.array(data_small, dtype=np.float64)
+        self.data_large = np.array(data_large, dtype=np.float64)
+
+        def arr(v):
+            return np.array([0.0]) if v is None else np.atleast_1d(np.asarray(v, dtype=np.float64))
+
+        self.lag_crval1 = arr(lag_crval1)
+        self.lag_crval2 = arr(lag_crval2)
+        self.lag_cdelt1 = arr(lag_cdelt1)
+        self.lag_cdelt2 = arr(lag_cdelt2)
+        self.lag_crota = arr(lag_crota)
+        self.lag_solar_r = None if lag_solar_r is None else np.atleast_1d(np.asarray(lag_solar_r, dtype=np.float64))
+        self.unit_lag = unit_lag
+        self.order = order
+        # "reference": CDELT1 lag is a no-op, CDELT2 lag raises (alignment.py:420-440, quirk Q2)
+        # "intended": CDELTi += d then PC rebuilt (Util.py:199-215)
+        self.cdelt_semantics = cdelt_semantics
+        self.lonlims = None
+        self.latlims = None
+        self.shape = None
+
+
+def set_initial_header_values(st: SweepState, use_ang2pipi=True):
+    """alignment.py:799-842."""
+    h = st.hdr_small
+    st.crval1_ref = h["CRVAL1"]
+    st.crval2_ref = h["CRVAL2"]
+    if "CROTA" in h:
+        st.crota_ref = h["CROTA"]
+    elif "CROTA2" in h:
+        st.crota_ref = h["CROTA2"]
+    else:
+        s = -np.sign(h["PC1_2"]) + (h["PC1_2"] == 0)
+        st.crota_ref = np.rad2deg(np.arccos(h["PC1_1"])) * s
+        h["CROTA"] = np.rad2deg(np.arccos(h["PC1_1"]))
+    st.cdelt1_ref = h["CDELT1"]
+    st.cdelt2_ref = h["CDELT2"]
+    st.unit1 = h["CUNIT1"]
+    st.unit2 = h["CUNIT2"]
+    if st.unit_lag in st.unit1:
+        pass
+    else:
+        f1 = unit_to_deg(st.unit_lag) / unit_to_deg(st.unit1)
+        f2 = unit_to_deg(st.unit_lag) / unit_to_deg(st.unit2)
+        if use_ang2pipi:
+            st.lag_crval1 = ang2pipi_unit(st.lag_crval1, st.unit_lag) * f1
+            st.lag_crval2 = ang2pipi_unit(st.lag_crval2, st.unit_lag) * f2
+            st.lag_cdelt1 = ang2pipi_unit(st.lag_cdelt1, st.unit_lag) * f1
+            st.lag_cdelt2 = ang2pipi_unit(st.lag_cdelt2, st.unit_lag) * f2
+        else:
+            st.lag_crval1 = st.lag_crval1 * f1
+            st.lag_crval2 = st.lag_crval2 * f2
+            st.lag_cdelt1 = st.lag_cdelt1 * f1
+            st.lag_cdelt2 = st.lag_cdelt2 * f2
+        st.unit_lag = st.unit1
+    if st.unit1 != st.unit2:
+        raise ValueError("CUNIT1 and CUNIT2 must be equal")
+    if st.lag_solar_r is None:
+        st.lag_solar_r = np.array([1.004])
+
+
+def shift_header(st: SweepState, hdr, d_crval1, d_crval2, d_cdelt1, d_cdelt2, d_crota):
+    """alignment.py:401-468, including quirk Q3 (PC rebuilt only when one of d_crota,
+    d_cdelt1, d_cdelt2 is != 0.0).  CDELT lags: `cdelt_semantics`."""
+    if st.unit_lag != hdr["CUNIT1"] or st.unit_lag != hdr["CUNIT2"]:
+        raise ValueError("lag.unit and cUNIT are not the same")
+    hdr["CRVAL1"] = st.crval1_ref + d_crval1
+    hdr["CRVAL2"] = st.crval2_ref + d_crval2
+    change_pcij = False
+    if d_cdelt1 != 0.0:
+        change_pcij = True
+        if st.cdelt_semantics == "intended":
+            hdr["CDELT1"] = st.cdelt1_ref + d_cdelt1
+        # "reference": computed but never written (alignment.py:423-430)
+    if d_cdelt2 != 0.0:
+        change_pcij = True
+        if st.cdelt_semantics == "intended":
+            hdr["CDELT2"] = st.cdelt2_ref + d_cdelt2
+        else:
+            raise AttributeError("'numpy.float64' object has no attribute 'to'")  # alignment.py:440
+    if d_crota != 0.0:
+        change_pcij = True
+        if "CROTA" in hdr:
+            hdr["CROTA"] = st.crota_ref + d_crota
+        elif "CROTA2" in hdr:
+            hdr["CROTA2"] = st.crota_ref + d_crota
+        crot = st.crota_ref + d_crota
+    else:
+        crot = st.crota_ref
+    if change_pcij:
+        rho = np.deg2rad(crot)
+        lam = hdr["CDELT2"] / hdr["CDELT1"]
+        hdr["PC1_1"] = np.cos(rho)
+        hdr["PC2_2"] = np.cos(rho)
+        hdr["PC1_2"] = -lam * np.sin(rho)
+        hdr["PC2_1"] = (1 / lam) * np.sin(rho)
+
+
+def set_threshold_minmax_to_nan(data_small, vmin=None, vmax=None):
+    """alignment.py:876-887 (in place)."""
+    c1 = np.ones(data_small.shape, dtype=bool)
+    c2 = np.ones(data_small.shape, dtype=bool)
+    with np.errstate(invalid="ignore"):
+        if vmin is not None:
+            c1[np.abs(data_small) < vmin] = False
+        if vmax is not None:
+            c2[np.abs(data_small) > vmax] = False
+    data_small[~(c1 & c2)] = np.nan
+
+
+# --------------------------------------------------------------------------------------
+# Carrington: rectify.py:282-423 (transforms), :842-888 (Rectifier), alignment.py:889-901
+def carrington_grid(shape, lonlims, latlims, dtype=np.float32):
+    """rectify.py:875-878: meshgrid(linspace(lon, shape[0], float32), linspace(lat, shape[1], float32));
+    arrays have shape [shape[1], shape[0]]."""
+    return np.meshgrid(np.linspace(lonlims[0], lonlims[1], shape[0], dtype=dtype),
+                       np.linspace(latlims[0], latlims[1], shape[1], dtype=dtype))
+
+
+def carrington_params(hdr, radius_correction):
+    """rectify.py:387-415: header -> SphericalTransform arguments."""
+    roll = hdr["CROTA"] if "CROTA" in hdr else hdr["CROTA2"]
+    cos = np.cos(np.radians(roll))
+    sin = np.sin(np.radians(roll))
+    dx = cos * hdr["CRVAL1"] + sin * hdr["CRVAL2"]
+    dy = -sin * hdr["CRVAL1"] + cos * hdr["CRVAL2"]
+    return dict(x0=(hdr["CRPIX1"] - 1) - dx / hdr["CDELT1"],
+                y0=(hdr["CRPIX2"] - 1) - dy / hdr["CDELT2"],
+                dist=hdr["DSUN_OBS"] / (radius_correction * R_SUN_M),
+                lon0=np.radians(hdr["CRLN_OBS"]), lat0=np.radians(hdr["CRLT_OBS"]),
+                roll=np.radians(roll), cdelt1=hdr["CDELT1"], cdelt2=hdr["CDELT2"])
+
+
+def carrington_coords(hdr, radius_correction, shape, lonlims, latlims):
+    """(nx, ny) pixel coordinates in the image of `hdr` of every Carrington grid point.
+    rectify.py:304-311 (differential rotation, dead: rate_wave=None => dx == 0 but promotes the
+    longitude array to float64, quirk Q5) then rectify.py:340-363.  dtype flow is that of NumPy 2
+    (NEP 50): grid fp32, radians/sin/cos of latitude in fp32, everything else fp64."""
+    x, y = carrington_grid(shape, lonlims, latlims)
+    # DifferentialRotationTransform.forward with coeffs (14.18, 0, 0)
+    siny2 = np.sin(np.radians(y)) ** 2
+    dx = np.float64(0.0) * (14.18 + siny2 * (0 + 0 * siny2) - 14.18)
+    x = x - dx
+    p = carrington_params(hdr, radius_correction)
+    # SphericalTransform.forward
+    lon = np.radians(x) - p["lon0"]
+    lat = np.radians(y)
+    xs = np.cos(lat) * np.sin(lon)
+    ys = np.sin(lat)
+    zs = np.cos(lat) * np.cos(lon)
+    zz = zs * np.cos(p["lat0"]) + ys * np.sin(p["lat0"])
+    yy = ys * np.cos(p["lat0"]) - zs * np.sin(p["lat0"])
+    gd = zz >= 0
+    yr = yy[gd] * np.cos(p["roll"]) - xs[gd] * np.sin(p["roll"])
+    xr = xs[gd] * np.cos(p["roll"]) + yy[gd] * np.sin(p["roll"])
+    z = p["dist"] - zz[gd]
+    nx = np.full_like(lon, np.nan)
+    ny = np.full_like(lon, np.nan)
+    nx[gd] = p["x0"] + np.degrees(np.arctan(xr / z)) * 3600 / p["cdelt1"]
+    ny[gd] = p["y0"] + np.degrees(np.arctan(yr / z)) * 3600 / p["cdelt2"]
+    return nx, ny
+
+
+def carrington_transform_fa(data, hdr, d_solar_r, shape, lonlims, latlims, order=2):
+    """alignment.py:889-901: Rectifier(CarringtonTransform(hdr))(data, ..., fill=-32762), -32762 -> NaN."""
+    nx, ny = carrington_coords(hdr, d_solar_r, shape, lonlims, latlims)
+    image = interpol2d(data, nx, ny, fill=-32762, order=order)
+    return np.where(image == -32762, np.nan, image)
+
+
+# --------------------------------------------------------------------------------------
+# helioprojective: alignment.py:987-1029
+def create_submap_of_large_data(st: SweepState):
+    """alignment.py:987-1016: large image resampled on the small header's own pixel grid, fp32;
+    hdr_large := copy of hdr_small."""
+    hdr_cut = dict(st.hdr_small)
+    x_cut, y_cut = extract_coordinates_pixels(hdr_cut, st.hdr_large)
+    image_large_cut = np.zeros_like(x_cut, dtype="float32")
+    interpol2d(st.data_large.copy(), x=x_cut, y=y_cut, dst=image_large_cut, order=st.order, fill=np.nan)
+    st.hdr_large = dict(hdr_cut)
+    return np.array(image_large_cut)
+
+
+def interpolate_on_large_data_grid(st: SweepState, data, hdr):
+    """alignment.py:1018-1029: small image resampled on hdr_large's pixel grid, fp32."""
+    x_large, y_large = extract_coordinates_pixels(st.hdr_large, hdr)
+    image_small_shft = np.zeros_like(x_large, dtype="float32")
+    interpol2d(data.copy(), x=x_large, y=y_large, order=st.order, fill=np.nan, dst=image_small_shft)
+    return image_small_shft
+
+
+# --------------------------------------------------------------------------------------
+# one lag-point: alignment.py:509-578
+def masked_pearson(data_large, data_small_interp):
+    """alignment.py:525-531."""
+    a = data_large.ravel()
+    b = data_small_interp.ravel()
+    is_nan = np.logical_or(~np.isfinite(a), ~np.isfinite(b))
+    A = np.array(a[~is_nan], dtype="float")
+    B = np.array(b[~is_nan], dtype="float")
+    return c_correlate(A, B, lags=[0])[0]
+
+
+def residus(data_large, data_small_interp):
+    """alignment.py:544-547 (no NaN mask: quirk Q8)."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        norm = np.sqrt(data_large.ravel())
+        diff = (data_large.ravel() - data_small_interp.ravel()) / norm
+        return np.std(diff)
+
+
+def step(st: SweepState, frame, data_small, data_large, d_crval1, d_crval2, d_cdelt1, d_cdelt2, d_crota,
+         d_solar_r, method="correlation"):
+    """alignment.py:509-549 / 551-578."""
+    hdr = dict(st.hdr_small)
+    shift_header(st, hdr, d_crval1, d_crval2, d_cdelt1, d_cdelt2, d_crota)
+    if frame == "carrington":
+        interp = carrington_transform_fa(data_small, hdr, d_solar_r, st.shape, st.lonlims, st.latlims, st.order)
+    else:
+        interp = interpolate_on_large_data_grid(st, data_small, hdr)
+    if method == "correlation":
+        return masked_pearson(data_large, interp)
+    elif method == "residus":
+        return residus(data_large, interp)
+    raise NotImplementedError
+
+
+def prepare_reference(st: SweepState, frame, d_solar_r, parallelism=True):
+    """alignment.py:646-651 (parallel) / 762-767 (serial; quirk Q1: helioprojective keeps the
+    FULL large grid because the condition tests 'initial_helioprojective')."""
+    if frame == "carrington":
+        return carrington_transform_fa(st.data_large, st.hdr_large, d_solar_r, st.shape, st.lonlims,
+                                       st.latlims, st.order)
+    if parallelism:
+        return create_submap_of_large_data(st)
+    return st.data_large
+
+
+def lag_table(st: SweepState):
+    """C-order ravel of meshgrid(crval1, crval2, cdelt1, cdelt2, crota, indexing='ij').
+    alignment.py:667-674."""
+    g = np.meshgrid(st.lag_crval1, st.lag_crval2, st.lag_cdelt1, st.lag_cdelt2, st.lag_crota, indexing="ij")
+    return np.stack([a.ravel() for a in g], axis=1), g[0].shape
+
+
+def _worker(args):
+    (shm_small, shp_small, shm_large, shp_large, dt_large, st, frame, lags, d_solar_r, method) = args
+    s1 = shared_memory.SharedMemory(name=shm_small)
+    s2 = shared_memory.SharedMemory(name=shm_large)
+    try:
+        data_small = np.ndarray(shp_small, dtype=np.float64, buffer=s1.buf)
+        data_large = np.ndarray(shp_large, dtype=dt_large, buffer=s2.buf)
+        out = np.zeros(len(lags))
+        for i, lg in enumerate(lags):
+            out[i] = step(st, frame, data_small, data_large, lg[0], lg[1], lg[2], lg[3], lg[4], d_solar_r, method)
+        return out
+    finally:
+        s1.close()
+        s2.close()
+
+
+def find_best_header_parameters(st: SweepState, frame, method="correlation", parallelism=True, counts=None,
+                                lag_subset=None):
+    """alignment.py:613-797.  Returns the 6-D corr array [crval1, crval2, cdelt1, cdelt2, crota, solar_r].
+    `counts` > 1 fans the raveled lag list out over processes in `np.array_split` chunks with the images in
+    POSIX shared memory (alignment.py:667-744); `counts` in (None, 1) runs in-process.
+    `lag_subset` (indices into the raveled lag list) restricts the computation (bench sampling);
+    other entries are NaN."""
+    set_initial_header_values(st)
+    table, shp = lag_table(st)
+    nsr = len(st.lag_solar_r)
+    corr = np.full((table.shape[0], nsr), np.nan)
+    for kk, d_solar_r in enumerate(st.lag_solar_r):
+        data_large = prepare_reference(st, frame, d_solar_r, parallelism)
+        if np.isnan(st.data_small).all():
+            raise ValueError("minimum or maximum value have set all small FOV to nan")
+        idx = np.arange(table.shape[0]) if lag_subset is None else np.asarray(lag_subset)
+        if counts is None or counts <= 1:
+            for i in idx:
+                lg = table[i]
+                corr[i, kk] = step(st, frame, st.data_small, data_large, lg[0], lg[1], lg[2], lg[3], lg[4],
+                                   d_solar_r, method)
+        else:
+            data_large = np.ascontiguousarray(data_large)
+            s1 = shared_memory.SharedMemory(create=True, size=st.data_small.nbytes)
+            s2 = shared_memory.SharedMemory(create=True, size=data_large.nbytes)
+            try:
+                np.ndarray(st.data_small.shape, dtype=np.float64, buffer=s1.buf)[...] = st.data_small
+                np.ndarray(data_large.shape, dtype=data_large.dtype, buffer=s2.buf)[...] = data_large
+                chunks = [c for c in np.array_split(idx, counts) if len(c)]
+                st_light = copy.copy(st)
+                st_light.data_small = None
+                st_light.data_large = None
+                jobs = [(s1.name, st.data_small.shape, s2.name, data_large.shape, data_large.dtype, st_light, frame,
+                         table[c], d_solar_r, method) for c in chunks]
+                with mp.get_context("fork").Pool(len(chunks)) as pool:
+                    outs = pool.map(_worker, jobs)
+                for c, o in zip(chunks, outs):
+                    corr[c, kk] = o
+            finally:
+                s1.close()
+                s1.unlink()
+                s2.close()
+                s2.unlink()
+    return corr.reshape(shp + (nsr,))
+
+
+# --------------------------------------------------------------------------------------
+# hdrshift/AlignmentResults.py:12-21, 218-341
+def twoD_Gaussian(xy, amplitude, xo, yo, sigma_x, sigma_y, offset):
+    x, y = xy
+    g = offset + amplitude * np.exp(-((((x - float(xo)) ** 2) / (2 * sigma_x ** 2))
+                                      + (((y - float(yo)) ** 2) / (2 * sigma_y ** 2))))
+    return g.ravel()
+
+
+def compute_shift(corr, lag_crval1_arcsec, lag_crval2_arcsec):
+    """AlignmentResults.py:218-341 restated: returns (max_index, shift_pixels(x,y), shift_arcsec(x,y))."""
+    from scipy.optimize import curve_fit
+    max_index = np.unravel_index(np.nanargmax(corr), corr.shape)
+    corr2d = corr[:, :, max_index[2], max_index[3], max_index[4]]
+    px = [max_index[0]]
+    py = [max_index[1]]
+    lenx, leny = corr2d.shape[0], corr2d.shape[1]
+    for ii in (-2, -1, 0, 1, 2):
+        for jj in (-2, -1, 0, 1, 2):
+            x = max_index[0] + ii
+            y = max_index[1] + jj
+            if (x != -1) and (x < lenx) and (y != -1) and (y < leny):
+                px.append(x)
+                py.append(y)
+    if len(px) < 4:
+        return max_index, (max_index[0], max_index[1]), (lag_crval1_arcsec[max_index[0]], lag_crval2_arcsec[max_index[1]])
+    A = (np.float64(px), np.float64(py))
+    B = np.float64(corr2d[px, py].ravel())
+    p0 = (np.float64(corr2d[max_index[0], max_index[1]][0]), np.float64(max_index[0]), np.float64(max_index[1]),
+          1.0, 1.0, 0.9)
+    bounds = ([0.0, max_index[0] - 5.0, max_index[1] - 5.0, 0.0, 0.0, -10.0],
+              [10.0, max_index[0] + 5.0, max_index[1] + 5.0, 1000.0, 1000.0, 10.0])
+    try:
+        popt, _ = curve_fit(f=twoD_Gaussian, xdata=A, ydata=B, p0=p0, bounds=bounds)
+    except ValueError:
+        return max_index, (max_index[0], max_index[1]), (lag_crval1_arcsec[max_index[0]], lag_crval2_arcsec[max_index[1]])
+    sx = np.interp(popt[1], np.arange(len(lag_crval1_arcsec)), lag_crval1_arcsec)
+    sy = np.interp(popt[2], np.arange(len(lag_crval2_arcsec)), lag_crval2_arcsec)
+    return max_index, (popt[1], popt[2]), (sx, sy)
