@@ -1,0 +1,341 @@
+"""
+ctypes binding of libcoreg_hip.so (C ABI: include/coreg_hip.h).
+
+The library is the product path: there is NO CPU fallback.  If the shared object has not been
+built (`python -c "import __graft_entry__ as g; g.build()"` or `make -C euispice_coreg_amd/csrc`)
+importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcoreg_hip.so")
+
+COREG_OK = 0
+COREG_EINVAL, COREG_EHIP, COREG_ESTATE, COREG_ENOTIMPL, COREG_ENOMEM = -1, -2, -3, -4, -5
+COREG_F32, COREG_F64 = 0, 1
+METHOD_CORRELATION, METHOD_RESIDUS = 0, 1
+CDELT_INTENDED, CDELT_REFERENCE = 0, 1
+
+
+class CoregError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libcoreg_hip error {code}: {msg}")
+        self.code = code
+
+
+class Wcs2d(C.Structure):
+    _fields_ = [("naxis1", C.c_int32), ("naxis2", C.c_int32),
+                ("crpix1", C.c_double), ("crpix2", C.c_double),
+                ("crval1", C.c_double), ("crval2", C.c_double),
+                ("cdelt1", C.c_double), ("cdelt2", C.c_double),
+                ("pc1_1", C.c_double), ("pc1_2", C.c_double), ("pc2_1", C.c_double), ("pc2_2", C.c_double),
+                ("crota", C.c_double), ("unit_to_deg", C.c_double), ("lonpole", C.c_double),
+                ("dsun_obs", C.c_double), ("crln_obs", C.c_double), ("crlt_obs", C.c_double)]
+
+
+class Lags(C.Structure):
+    _fields_ = [("crval1", C.POINTER(C.c_double)), ("n_crval1", C.c_int32),
+                ("crval2", C.POINTER(C.c_double)), ("n_crval2", C.c_int32),
+                ("cdelt1", C.POINTER(C.c_double)), ("n_cdelt1", C.c_int32),
+                ("cdelt2", C.POINTER(C.c_double)), ("n_cdelt2", C.c_int32),
+                ("crota", C.POINTER(C.c_double)), ("n_crota", C.c_int32)]
+
+
+class CarrGrid(C.Structure):
+    _fields_ = [("lon0", C.c_double), ("lon1", C.c_double), ("n_lon", C.c_int32),
+                ("lat0", C.c_double), ("lat1", C.c_double), ("n_lat", C.c_int32),
+                ("lat_cos", C.POINTER(C.c_float)), ("lat_sin", C.POINTER(C.c_float))]
+
+
+class Stats(C.Structure):
+    _fields_ = [("sweep_kernel_ms", C.c_double), ("precompute_ms", C.c_double), ("total_gpu_ms", C.c_double),
+                ("n_lags", C.c_int64), ("n_grid_points", C.c_int64), ("n_active_points", C.c_int64),
+                ("n_sweep_launches", C.c_int64), ("small_is_f32", C.c_int32), ("used_lds", C.c_int32)]
+
+
+# every symbol include/coreg_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_WP = C.POINTER(Wcs2d)
+SYMBOLS = [
+    ("coreg_version", C.c_char_p, []),
+    ("coreg_create", C.c_int, [C.POINTER(_P), C.c_int]),
+    ("coreg_destroy", None, [_P]),
+    ("coreg_last_error", C.c_char_p, [_P]),
+    ("coreg_set_stream", C.c_int, [_P, _P]),
+    ("coreg_synchronize", C.c_int, [_P]),
+    ("coreg_set_small", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    ("coreg_set_reference_on_grid", C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32]),
+    ("coreg_prepare_reference_carrington", C.c_int,
+     [_P, _P, C.c_int32, C.c_int32, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
+    ("coreg_prepare_reference_helioprojective", C.c_int, [_P, _P, C.c_int32, C.c_int32, _WP, _WP, C.c_int]),
+    ("coreg_get_reference_on_grid", C.c_int, [_P, _P, C.c_int]),
+    ("coreg_resample_carrington", C.c_int, [_P, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int, _P]),
+    ("coreg_resample_helioprojective", C.c_int, [_P, _WP, _WP, C.c_int, _P]),
+    ("coreg_sweep_carrington", C.c_int,
+     [_P, _WP, C.POINTER(CarrGrid), C.c_double, C.POINTER(Lags), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P,
+      C.c_int]),
+    ("coreg_sweep_helioprojective", C.c_int,
+     [_P, _WP, _WP, C.POINTER(Lags), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P, C.c_int]),
+    ("coreg_last_stats", C.c_int, [_P, C.POINTER(Stats)]),
+    ("coreg_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
+    ("coreg_shift_header", C.c_int,
+     [_WP, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _WP]),
+    ("coreg_homography", C.c_int, [_WP, _WP, C.POINTER(C.c_double)]),
+    ("coreg_carrington_origin", C.c_int, [_WP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libcoreg_hip.so and declare every prototype.  Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+_UNIT_TO_DEG = {"deg": 1.0, "arcsec": 1.0 / 3600.0, "arcmin": 1.0 / 60.0, "rad": 180.0 / np.pi, "mas": 1.0 / 3.6e6}
+
+
+def unit_to_deg(unit) -> float:
+    u = str(unit).strip()
+    if u not in _UNIT_TO_DEG:
+        raise ValueError(f"unsupported CUNIT {unit!r}")
+    return _UNIT_TO_DEG[u]
+
+
+def wcs_from_header(hdr, carrington=False) -> Wcs2d:
+    """Fill the C struct from a header mapping (after alignment.py:580-611: PCi_j and CROTA present)."""
+    w = Wcs2d()
+    if "ZNAXIS1" in hdr:
+        w.naxis1, w.naxis2 = int(hdr["ZNAXIS1"]), int(hdr["ZNAXIS2"])
+    else:
+        w.naxis1, w.naxis2 = int(hdr.get("NAXIS1", 0)), int(hdr.get("NAXIS2", 0))
+    w.crpix1, w.crpix2 = float(hdr["CRPIX1"]), float(hdr["CRPIX2"])
+    w.crval1, w.crval2 = float(hdr["CRVAL1"]), float(hdr["CRVAL2"])
+    w.cdelt1, w.cdelt2 = float(hdr["CDELT1"]), float(hdr["CDELT2"])
+    w.pc1_1, w.pc1_2 = float(hdr.get("PC1_1", 1.0)), float(hdr.get("PC1_2", 0.0))
+    w.pc2_1, w.pc2_2 = float(hdr.get("PC2_1", 0.0)), float(hdr.get("PC2_2", 1.0))
+    w.crota = float(hdr["CROTA"] if "CROTA" in hdr else hdr.get("CROTA2", 0.0))
+    u1 = hdr.get("CUNIT1", "deg")
+    if str(u1).strip() != str(hdr.get("CUNIT2", u1)).strip():
+        raise ValueError("CUNIT1 and CUNIT2 must be equal")  # alignment.py:839-840
+    w.unit_to_deg = unit_to_deg(u1)
+    w.lonpole = float(hdr.get("LONPOLE", 180.0))
+    if carrington:
+        w.dsun_obs = float(hdr["DSUN_OBS"])
+        w.crln_obs = float(hdr["CRLN_OBS"])
+        w.crlt_obs = float(hdr["CRLT_OBS"])
+    return w
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class LagSet:
+    """Owns contiguous float64 copies of the five lag axes and the C struct pointing at them."""
+
+    def __init__(self, crval1, crval2, cdelt1, cdelt2, crota):
+        def arr(v):
+            return np.ascontiguousarray(np.atleast_1d(np.asarray([0.0] if v is None else v, dtype=np.float64)))
+
+        self.arrays = [arr(crval1), arr(crval2), arr(cdelt1), arr(cdelt2), arr(crota)]
+        a = self.arrays
+        self.c = Lags(_dptr(a[0]), len(a[0]), _dptr(a[1]), len(a[1]), _dptr(a[2]), len(a[2]), _dptr(a[3]), len(a[3]),
+                      _dptr(a[4]), len(a[4]))
+        self.shape = tuple(len(x) for x in a)
+        self.size = int(np.prod(self.shape))
+
+
+class Grid:
+    """Carrington grid (utils/rectify.py:875-878) as the C struct; `numpy_lat_trig=True` passes NumPy's own
+    float32 cos/sin(radians(lat)) tables so that the latitude trig equals the reference's bit for bit."""
+
+    def __init__(self, lonlims, latlims, shape, numpy_lat_trig=True):
+        self.n_lon, self.n_lat = int(shape[0]), int(shape[1])
+        self._cos = self._sin = None
+        cp = sp = None
+        if numpy_lat_trig:
+            lat = np.radians(np.linspace(latlims[0], latlims[1], self.n_lat, dtype=np.float32))
+            self._cos = np.ascontiguousarray(np.cos(lat), dtype=np.float32)
+            self._sin = np.ascontiguousarray(np.sin(lat), dtype=np.float32)
+            cp = self._cos.ctypes.data_as(C.POINTER(C.c_float))
+            sp = self._sin.ctypes.data_as(C.POINTER(C.c_float))
+        self.c = CarrGrid(float(lonlims[0]), float(lonlims[1]), self.n_lon, float(latlims[0]), float(latlims[1]),
+                          self.n_lat, cp, sp)
+
+
+class CoregHandle:
+    """One GPU context of libcoreg_hip (RAII over coreg_create / coreg_destroy)."""
+
+    def __init__(self, device=-1):
+        self._lib = load_library()
+        self._h = _P()
+        rc = self._lib.coreg_create(C.byref(self._h), int(device))
+        if rc != COREG_OK:
+            self._h = None
+            raise CoregError(rc, "coreg_create failed (no HIP device visible?)")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.coreg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != COREG_OK:
+            raise CoregError(rc, self._lib.coreg_last_error(self._h).decode("utf-8", "replace"))
+
+    # -- configuration
+    def set_option(self, name, value):
+        self._chk(self._lib.coreg_set_option(self._h, name.encode(), int(value)))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self._lib.coreg_set_stream(self._h, _P(stream_ptr)))
+
+    def synchronize(self):
+        self._chk(self._lib.coreg_synchronize(self._h))
+
+    # -- images
+    def set_small(self, img):
+        img = np.ascontiguousarray(img, dtype=np.float64)
+        if img.ndim != 2:
+            raise ValueError("small image must be 2-D")
+        self._chk(self._lib.coreg_set_small(self._h, img.ctypes.data, img.shape[0], img.shape[1]))
+
+    def set_reference_on_grid(self, ref):
+        ref = np.ascontiguousarray(ref)
+        if ref.ndim != 2 or ref.dtype not in (np.float32, np.float64):
+            raise ValueError("reference on grid must be a 2-D float32/float64 array")
+        dt = COREG_F32 if ref.dtype == np.float32 else COREG_F64
+        self._chk(self._lib.coreg_set_reference_on_grid(self._h, ref.ctypes.data, dt, ref.shape[0], ref.shape[1]))
+
+    def prepare_reference_carrington(self, large, hdr_large, grid: Grid, solar_r, order=2):
+        large = np.ascontiguousarray(large, dtype=np.float64)
+        w = wcs_from_header(hdr_large, carrington=True)
+        self._chk(self._lib.coreg_prepare_reference_carrington(self._h, large.ctypes.data, large.shape[0],
+                                                               large.shape[1], C.byref(w), C.byref(grid.c),
+                                                               float(solar_r), int(order)))
+
+    def prepare_reference_helioprojective(self, large, hdr_large, hdr_small, order=2):
+        large = np.ascontiguousarray(large, dtype=np.float64)
+        wl, ws = wcs_from_header(hdr_large), wcs_from_header(hdr_small)
+        self._chk(self._lib.coreg_prepare_reference_helioprojective(self._h, large.ctypes.data, large.shape[0],
+                                                                    large.shape[1], C.byref(wl), C.byref(ws),
+                                                                    int(order)))
+
+    def get_reference_on_grid(self, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        dt = COREG_F32 if out.dtype == np.float32 else COREG_F64
+        self._chk(self._lib.coreg_get_reference_on_grid(self._h, out.ctypes.data, dt))
+        return out
+
+    # -- single resamples
+    def resample_carrington(self, hdr, grid: Grid, solar_r, order=2):
+        w = wcs_from_header(hdr, carrington=True)
+        out = np.empty((grid.n_lat, grid.n_lon), dtype=np.float64)
+        self._chk(self._lib.coreg_resample_carrington(self._h, C.byref(w), C.byref(grid.c), float(solar_r), int(order),
+                                                      out.ctypes.data))
+        return out
+
+    def resample_helioprojective(self, hdr_target, hdr, order=2):
+        wt, w = wcs_from_header(hdr_target), wcs_from_header(hdr)
+        out = np.empty((wt.naxis2, wt.naxis1), dtype=np.float32)
+        self._chk(self._lib.coreg_resample_helioprojective(self._h, C.byref(wt), C.byref(w), int(order),
+                                                           out.ctypes.data))
+        return out
+
+    # -- sweeps
+    def sweep_carrington(self, hdr_small, grid: Grid, solar_r, lags: LagSet, order=2, method=METHOD_CORRELATION,
+                         cdelt_semantics=CDELT_INTENDED, lag_begin=0, lag_end=None, out_dev_ptr=None):
+        lag_end = lags.size if lag_end is None else int(lag_end)
+        w = wcs_from_header(hdr_small, carrington=True)
+        if out_dev_ptr is None:
+            out = np.empty(lag_end - lag_begin, dtype=np.float64)
+            ptr, on_dev = out.ctypes.data, 0
+        else:
+            out, ptr, on_dev = None, int(out_dev_ptr), 1
+        self._chk(self._lib.coreg_sweep_carrington(self._h, C.byref(w), C.byref(grid.c), float(solar_r),
+                                                   C.byref(lags.c), int(order), int(method), int(cdelt_semantics),
+                                                   int(lag_begin), lag_end, _P(ptr), on_dev))
+        return out
+
+    def sweep_helioprojective(self, hdr_target, hdr_small, lags: LagSet, order=2, method=METHOD_CORRELATION,
+                              cdelt_semantics=CDELT_INTENDED, lag_begin=0, lag_end=None, out_dev_ptr=None):
+        lag_end = lags.size if lag_end is None else int(lag_end)
+        wt, w = wcs_from_header(hdr_target), wcs_from_header(hdr_small)
+        if out_dev_ptr is None:
+            out = np.empty(lag_end - lag_begin, dtype=np.float64)
+            ptr, on_dev = out.ctypes.data, 0
+        else:
+            out, ptr, on_dev = None, int(out_dev_ptr), 1
+        self._chk(self._lib.coreg_sweep_helioprojective(self._h, C.byref(wt), C.byref(w), C.byref(lags.c), int(order),
+                                                        int(method), int(cdelt_semantics), int(lag_begin), lag_end,
+                                                        _P(ptr), on_dev))
+        return out
+
+    def last_stats(self) -> dict:
+        s = Stats()
+        self._chk(self._lib.coreg_last_stats(self._h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in Stats._fields_}
+
+
+# host-only helpers (no GPU): used by CPU tests of the header logic
+def shift_header(hdr, d_crval1, d_crval2, d_cdelt1, d_cdelt2, d_crota, cdelt_semantics=CDELT_INTENDED):
+    lib = load_library()
+    w = wcs_from_header(hdr)
+    out = Wcs2d()
+    rc = lib.coreg_shift_header(C.byref(w), d_crval1, d_crval2, d_cdelt1, d_cdelt2, d_crota, cdelt_semantics,
+                                C.byref(out))
+    if rc < 0:
+        raise CoregError(rc, "coreg_shift_header")
+    return rc, out
+
+
+def homography(hdr_from, hdr_to):
+    lib = load_library()
+    a, b = wcs_from_header(hdr_from), wcs_from_header(hdr_to)
+    h = (C.c_double * 9)()
+    rc = lib.coreg_homography(C.byref(a), C.byref(b), h)
+    if rc != COREG_OK:
+        raise CoregError(rc, "coreg_homography")
+    return np.array(h[:]).reshape(3, 3)
+
+
+def carrington_origin(hdr):
+    lib = load_library()
+    w = wcs_from_header(hdr, carrington=True)
+    x0, y0 = C.c_double(), C.c_double()
+    rc = lib.coreg_carrington_origin(C.byref(w), C.byref(x0), C.byref(y0))
+    if rc != COREG_OK:
+        raise CoregError(rc, "coreg_carrington_origin")
+    return x0.value, y0.value

@@ -1,0 +1,1015 @@
+// libcoreg_hip.so -- C ABI (include/coreg_hip.h) of the MI355X alignment sweep.
+// Host side: lag table / header shifting / batching (the part of Alignment._find_best_header_parameters,
+// hdrshift/alignment.py:613-797, that is not per-pixel work) and the kernel launches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "geometry.hpp"
+#include "kernels.hpp"
+
+using namespace coreg;
+
+#define COREG_VERSION "0.1.0"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            if (e != hipSuccess) return e;
+            p = nullptr;
+            cap = 0;
+        }
+        const size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return e;
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() const {
+        return (T*)p;
+    }
+};
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+}  // namespace
+
+struct coreg_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // small image
+    DevBuf small;
+    int sW = 0, sH = 0;
+    bool small_f32 = false;
+    // reference on grid
+    DevBuf ref;
+    int gW = 0, gH = 0;
+    int ref_dtype = -1;
+    // pivots[0] = mean(reference), pivots[1] = mean(small)
+    DevBuf pivots, red_sum, red_cnt;
+    // geometry tables
+    DevBuf t_sin_lon, t_cos_lon, t_cos_lat, t_sin_lat;
+    // precompute outputs
+    DevBuf base0, base1, aval, tile_count, tile_list, tile_info, tile_bbox;
+    // sweep
+    DevBuf lane_params, out_index, partials, out_dev, tmp_img;
+
+    // options
+    int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = 64 * 1024;
+
+    coreg_stats stats;
+    std::vector<EventPair> ev_sweep, ev_pre;
+    size_t ev_sweep_used = 0, ev_pre_used = 0;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+};
+
+namespace {
+
+int fail(coreg_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return fail(h, COREG_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+    } while (0)
+
+#define RETCHK(expr)             \
+    do {                         \
+        int _r = (expr);         \
+        if (_r != COREG_OK) return _r; \
+    } while (0)
+
+int bind_device(coreg_handle* h) {
+    HIPCHK(hipSetDevice(h->device));
+    return COREG_OK;
+}
+
+EventPair* next_event(coreg_handle* h, std::vector<EventPair>& v, size_t& used) {
+    if (used == v.size()) {
+        EventPair e;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return nullptr;
+        v.push_back(e);
+    }
+    return &v[used++];
+}
+
+template <typename T>
+int device_mean(coreg_handle* h, const T* v, long long n, double* mean_dev) {
+    const int nb = 256;
+    HIPCHK(h->red_sum.reserve(nb * sizeof(double)));
+    HIPCHK(h->red_cnt.reserve(nb * sizeof(long long)));
+    hipLaunchKernelGGL((k_sum_finite<T>), dim3(nb), dim3(256), 0, h->stream, v, n, h->red_sum.as<double>(),
+                       h->red_cnt.as<long long>());
+    hipLaunchKernelGGL(k_mean_final, dim3(1), dim3(64), 0, h->stream, h->red_sum.as<double>(),
+                       h->red_cnt.as<long long>(), nb, mean_dev);
+    HIPCHK(hipGetLastError());
+    return COREG_OK;
+}
+
+bool all_f32_exact(const double* v, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        const double x = v[i];
+        if (x != x) continue;
+        if ((double)(float)x != x) return false;
+    }
+    return true;
+}
+
+// upload a float64 host image as float32 when exact, else float64
+int upload_image(coreg_handle* h, const double* img, size_t n, DevBuf& buf, bool* is_f32) {
+    const bool f32 = all_f32_exact(img, n);
+    *is_f32 = f32;
+    if (f32) {
+        std::vector<float> tmp(n);
+        for (size_t i = 0; i < n; ++i) tmp[i] = (float)img[i];
+        HIPCHK(buf.reserve(n * sizeof(float)));
+        HIPCHK(hipMemcpyAsync(buf.p, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));  // tmp goes out of scope
+    } else {
+        HIPCHK(buf.reserve(n * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(buf.p, img, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return COREG_OK;
+}
+
+int upload_carr_tables(coreg_handle* h, const coreg_carr_grid& g, const coreg_wcs2d& hdr, CarrDev* dev) {
+    if (g.n_lon < 1 || g.n_lat < 1) return fail(h, COREG_EINVAL, "carrington grid: n_lon/n_lat must be >= 1");
+    CarrTables t;
+    carr_tables(g, hdr.crln_obs, t);
+    HIPCHK(h->t_sin_lon.reserve(g.n_lon * sizeof(double)));
+    HIPCHK(h->t_cos_lon.reserve(g.n_lon * sizeof(double)));
+    HIPCHK(h->t_cos_lat.reserve(g.n_lat * sizeof(float)));
+    HIPCHK(h->t_sin_lat.reserve(g.n_lat * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(h->t_sin_lon.p, t.sin_lon.data(), g.n_lon * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->t_cos_lon.p, t.cos_lon.data(), g.n_lon * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->t_cos_lat.p, t.cos_lat.data(), g.n_lat * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->t_sin_lat.p, t.sin_lat.data(), g.n_lat * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // host vectors die here
+    dev->sin_lon = h->t_sin_lon.as<double>();
+    dev->cos_lon = h->t_cos_lon.as<double>();
+    dev->cos_lat = h->t_cos_lat.as<float>();
+    dev->sin_lat = h->t_sin_lat.as<float>();
+    dev->n_lon = g.n_lon;
+    dev->n_lat = g.n_lat;
+    return COREG_OK;
+}
+
+void set_carr_common(CarrDev* dev, const CarrCommon& c) {
+    dev->dist = c.dist;
+    dev->cb = c.cb;
+    dev->sb = c.sb;
+    dev->cr = c.cr;
+    dev->sr = c.sr;
+    dev->cdelt1 = c.cdelt1;
+    dev->cdelt2 = c.cdelt2;
+}
+
+// host mirror of kernels.hpp carr_term (tile-shape heuristics only)
+bool carr_term_host(const CarrTables& t, const CarrCommon& c, int i, int j, double* t0, double* t1) {
+    const double cl = (double)t.cos_lat[j], y = (double)t.sin_lat[j];
+    const double x = cl * t.sin_lon[i], z = cl * t.cos_lon[i];
+    const double zz = z * c.cb + y * c.sb, yy = y * c.cb - z * c.sb;
+    const double yr = yy * c.cr - x * c.sr, xr = x * c.cr + yy * c.sr;
+    const double zd = c.dist - zz;
+    *t0 = std::atan(xr / zd) * kRad2Deg * 3600.0 / c.cdelt1;
+    *t1 = std::atan(yr / zd) * kRad2Deg * 3600.0 / c.cdelt2;
+    return zz >= 0.0;
+}
+
+template <typename F>
+int dispatch_resample(coreg_handle* h, int mode, int order, bool ts_f32, bool out_f32, const ResampleArgs& a, F) {
+    const long long n = (long long)a.gw * a.gh;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+#define RS(M, O, TS, TO) hipLaunchKernelGGL((k_resample<M, O, TS, TO>), grid, block, 0, h->stream, a)
+#define RS_T(M, O)                                  \
+    do {                                            \
+        if (ts_f32) {                               \
+            if (out_f32) RS(M, O, float, float);    \
+            else RS(M, O, float, double);           \
+        } else {                                    \
+            if (out_f32) RS(M, O, double, float);   \
+            else RS(M, O, double, double);          \
+        }                                           \
+    } while (0)
+    if (mode == MODE_TRANSLATE) {
+        if (order == 2) RS_T(MODE_TRANSLATE, 2);
+        else RS_T(MODE_TRANSLATE, 1);
+    } else {
+        if (order == 2) RS_T(MODE_HOMOGRAPHY, 2);
+        else RS_T(MODE_HOMOGRAPHY, 1);
+    }
+#undef RS_T
+#undef RS
+    HIPCHK(hipGetLastError());
+    return COREG_OK;
+}
+
+int check_order(coreg_handle* h, int order) {
+    if (order != 1 && order != 2)
+        return fail(h, COREG_ENOTIMPL, "reprojection_order must be 1 or 2 (got " + std::to_string(order) + ")");
+    return COREG_OK;
+}
+
+// ---- lag batching ---------------------------------------------------------------------------------------------
+struct LagDims {
+    int n1, n2, n3, n4, n5;
+    long long nc;  // n3*n4*n5
+    long long total() const { return (long long)n1 * n2 * nc; }
+};
+
+int check_lags(coreg_handle* h, const coreg_lags* l, LagDims* d, int64_t begin, int64_t end) {
+    if (!l || !l->crval1 || !l->crval2 || !l->cdelt1 || !l->cdelt2 || !l->crota)
+        return fail(h, COREG_EINVAL, "lags: null array");
+    if (l->n_crval1 < 1 || l->n_crval2 < 1 || l->n_cdelt1 < 1 || l->n_cdelt2 < 1 || l->n_crota < 1)
+        return fail(h, COREG_EINVAL, "lags: every axis needs at least one value");
+    d->n1 = l->n_crval1;
+    d->n2 = l->n_crval2;
+    d->n3 = l->n_cdelt1;
+    d->n4 = l->n_cdelt2;
+    d->n5 = l->n_crota;
+    d->nc = (long long)d->n3 * d->n4 * d->n5;
+    if (begin < 0 || end > d->total() || begin > end)
+        return fail(h, COREG_EINVAL, "lag_begin/lag_end outside [0, n_lags]");
+    return COREG_OK;
+}
+
+// super-patch (sw x sh <= 256 CRVAL1 x CRVAL2 lags per workgroup) minimising padded lane slots
+void choose_patch(int n1, int n2, int* sw_out, int* sh_out) {
+    long long best = std::numeric_limits<long long>::max();
+    int bw = 1, bh = 1;
+    for (int sw = 1; sw <= std::min(n1, kBlock); ++sw) {
+        int sh = std::min(n2, kBlock / sw);
+        if (sh < 1) break;
+        const long long batches = (long long)((n1 + sw - 1) / sw) * ((n2 + sh - 1) / sh);
+        // shrink sh to the smallest value giving the same batch count (squarer, smaller windows)
+        const int rows = (n2 + sh - 1) / sh;
+        sh = (n2 + rows - 1) / rows;
+        const int big = std::max(sw, sh), small = std::min(sw, sh);
+        const long long cost = batches * 1024 + (long long)(big - small) + (big > 4 * small ? 512 : 0);
+        if (cost < best) {
+            best = cost;
+            bw = sw;
+            bh = sh;
+        }
+    }
+    *sw_out = bw;
+    *sh_out = bh;
+}
+
+struct SlotList {
+    std::vector<int> i1, i2;        // lag indices supplying the lane parameters (clamped for padding)
+    std::vector<long long> outidx;  // raveled C-order lag index or -1
+    int n_batches = 0;
+};
+
+// slots for combo c (= (i3*n4 + i4)*n5 + i5) restricted to the raveled slice [begin, end)
+void build_slots(const LagDims& d, long long c, long long begin, long long end, SlotList* s) {
+    s->i1.clear();
+    s->i2.clear();
+    s->outidx.clear();
+    s->n_batches = 0;
+    const long long row = (long long)d.n2 * d.nc;
+    const int i1_lo = (int)(begin / row);
+    const int i1_hi = (int)((end - 1) / row);
+    const int m1 = i1_hi - i1_lo + 1;
+    int sw, sh;
+    choose_patch(m1, d.n2, &sw, &sh);
+    for (int p1 = 0; p1 * sw < m1; ++p1)
+        for (int p2 = 0; p2 * sh < d.n2; ++p2) {
+            bool any = false;
+            const size_t at = s->i1.size();
+            for (int t = 0; t < kBlock; ++t) {
+                int lx = t % sw, ly = t / sw;
+                bool valid = ly < sh;
+                if (!valid) lx = ly = 0;
+                int i1 = i1_lo + p1 * sw + lx, i2 = p2 * sh + ly;
+                if (i1 > i1_hi) {
+                    i1 = i1_hi;
+                    valid = false;
+                }
+                if (i2 > d.n2 - 1) {
+                    i2 = d.n2 - 1;
+                    valid = false;
+                }
+                const long long idx = ((long long)i1 * d.n2 + i2) * d.nc + c;
+                if (idx < begin || idx >= end) valid = false;
+                s->i1.push_back(i1);
+                s->i2.push_back(i2);
+                s->outidx.push_back(valid ? idx : -1);
+                any |= valid;
+            }
+            if (!any) {
+                s->i1.resize(at);
+                s->i2.resize(at);
+                s->outidx.resize(at);
+            } else {
+                s->n_batches++;
+            }
+        }
+}
+
+int pick_groups(coreg_handle* h, int n_batches, int n_tiles) {
+    long long g = h->opt_n_groups > 0 ? h->opt_n_groups : (4096 + n_batches - 1) / n_batches;
+    g = std::min<long long>(g, n_tiles);
+    g = std::max<long long>(8, std::min<long long>(512, ((g + 7) / 8) * 8));
+    return (int)g;
+}
+
+template <int MODE>
+int launch_precompute(coreg_handle* h, const PrecomputeArgs& a, int n_tiles) {
+    EventPair* ev = next_event(h, h->ev_pre, h->ev_pre_used);
+    if (!ev) return fail(h, COREG_EHIP, "hipEventCreate failed");
+    HIPCHK(hipEventRecord(ev->a, h->stream));
+    if (h->ref_dtype == COREG_F32)
+        hipLaunchKernelGGL((k_precompute<MODE, float>), dim3(n_tiles), dim3(256), 0, h->stream, a);
+    else
+        hipLaunchKernelGGL((k_precompute<MODE, double>), dim3(n_tiles), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, h->stream, (const int*)a.tile_count, n_tiles,
+                       h->tile_list.as<int>(), h->tile_info.as<long long>());
+    HIPCHK(hipEventRecord(ev->b, h->stream));
+    HIPCHK(hipGetLastError());
+    return COREG_OK;
+}
+
+int reserve_tiles(coreg_handle* h, int n_tiles) {
+    const size_t pts = (size_t)n_tiles * kTilePts;
+    HIPCHK(h->base0.reserve(pts * sizeof(double)));
+    HIPCHK(h->base1.reserve(pts * sizeof(double)));
+    HIPCHK(h->aval.reserve(pts * sizeof(double)));
+    HIPCHK(h->tile_count.reserve(n_tiles * sizeof(int)));
+    HIPCHK(h->tile_list.reserve(n_tiles * sizeof(int)));
+    HIPCHK(h->tile_info.reserve(2 * sizeof(long long)));
+    HIPCHK(h->tile_bbox.reserve((size_t)n_tiles * 4 * sizeof(double)));
+    return COREG_OK;
+}
+
+void fill_precompute_common(coreg_handle* h, PrecomputeArgs* a, int tile_w) {
+    a->ref = h->ref.p;
+    a->gw = h->gW;
+    a->gh = h->gH;
+    a->tile_w = tile_w;
+    a->tile_h = kTilePts / tile_w;
+    a->tiles_x = (h->gW + a->tile_w - 1) / a->tile_w;
+    a->tiles_y = (h->gH + a->tile_h - 1) / a->tile_h;
+    a->pivot_a = h->pivots.as<double>();
+    a->base0 = h->base0.as<double>();
+    a->base1 = h->base1.as<double>();
+    a->aval = h->aval.as<double>();
+    a->tile_count = h->tile_count.as<int>();
+    a->tile_bbox = h->tile_bbox.as<double>();
+}
+
+// one sweep-kernel launch + finalize over the slots in `params` (SoA [np][n_slots])
+int launch_sweep(coreg_handle* h, int mode, int order, int np, const std::vector<double>& params,
+                 const std::vector<long long>& outidx, int n_batches, int n_tiles, int round_f32,
+                 long long lag_begin, double* out_dev) {
+    const long long n_slots = (long long)n_batches * kBlock;
+    const int n_groups = pick_groups(h, n_batches, n_tiles);
+    HIPCHK(h->lane_params.reserve(params.size() * sizeof(double)));
+    HIPCHK(h->out_index.reserve(outidx.size() * sizeof(long long)));
+    HIPCHK(h->partials.reserve((size_t)n_groups * kNumSums * n_slots * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->lane_params.p, params.data(), params.size() * sizeof(double), hipMemcpyHostToDevice,
+                          h->stream));
+    HIPCHK(hipMemcpyAsync(h->out_index.p, outidx.data(), outidx.size() * sizeof(long long), hipMemcpyHostToDevice,
+                          h->stream));
+    // the host vectors are reused by the caller's next combo: make the copies complete first
+    HIPCHK(hipStreamSynchronize(h->stream));
+
+    SweepArgs a;
+    a.img = h->small.p;
+    a.W = h->sW;
+    a.H = h->sH;
+    a.base0 = h->base0.as<double>();
+    a.base1 = h->base1.as<double>();
+    a.aval = h->aval.as<double>();
+    a.tile_count = h->tile_count.as<int>();
+    a.tile_list = h->tile_list.as<int>();
+    a.tile_info = h->tile_info.as<long long>();
+    a.tile_bbox = h->tile_bbox.as<double>();
+    a.lane_params = h->lane_params.as<double>();
+    a.n_slots = n_slots;
+    a.n_batches = n_batches;
+    a.n_groups = n_groups;
+    a.partials = h->partials.as<double>();
+    a.pivots = h->pivots.as<double>();
+    a.round_f32 = round_f32;
+    a.use_lds = h->opt_use_lds ? 1 : 0;
+    const size_t esz = h->small_f32 ? sizeof(float) : sizeof(double);
+    const size_t lds_bytes = a.use_lds ? (size_t)h->opt_lds_bytes : 0;
+    a.lds_elems = (int)(lds_bytes / esz);
+    (void)np;
+
+    const dim3 grid((unsigned)((long long)n_groups * n_batches)), block(kBlock);
+    EventPair* ev = next_event(h, h->ev_sweep, h->ev_sweep_used);
+    if (!ev) return fail(h, COREG_EHIP, "hipEventCreate failed");
+#define SW(M, O, TS)                                                                                              \
+    do {                                                                                                          \
+        if (lds_bytes > 48 * 1024)                                                                                \
+            HIPCHK(hipFuncSetAttribute((const void*)(k_sweep<M, O, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds_bytes));                                                          \
+        HIPCHK(hipEventRecord(ev->a, h->stream));                                                                 \
+        hipLaunchKernelGGL((k_sweep<M, O, TS>), grid, block, lds_bytes, h->stream, a);                            \
+        HIPCHK(hipEventRecord(ev->b, h->stream));                                                                 \
+    } while (0)
+#define SW_T(M, O)                         \
+    do {                                   \
+        if (h->small_f32) SW(M, O, float); \
+        else SW(M, O, double);             \
+    } while (0)
+    if (mode == MODE_TRANSLATE) {
+        if (order == 2) SW_T(MODE_TRANSLATE, 2);
+        else SW_T(MODE_TRANSLATE, 1);
+    } else {
+        if (order == 2) SW_T(MODE_HOMOGRAPHY, 2);
+        else SW_T(MODE_HOMOGRAPHY, 1);
+    }
+#undef SW_T
+#undef SW
+    HIPCHK(hipGetLastError());
+    h->stats.n_sweep_launches++;
+    h->stats.used_lds = a.use_lds;
+
+    FinalizeArgs f;
+    f.partials = h->partials.as<double>();
+    f.n_groups = n_groups;
+    f.n_slots = n_slots;
+    f.out_index = h->out_index.as<long long>();
+    f.lag_begin = lag_begin;
+    f.out = out_dev;
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, h->stream, f);
+    HIPCHK(hipGetLastError());
+    return COREG_OK;
+}
+
+int begin_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_device, double** out_dev) {
+    if (!h->small.p) return fail(h, COREG_ESTATE, "coreg_set_small has not been called");
+    if (!h->ref.p) return fail(h, COREG_ESTATE, "no reference image on the target grid");
+    if (!corr_out && n_out > 0) return fail(h, COREG_EINVAL, "corr_out is null");
+    h->ev_sweep_used = 0;
+    h->ev_pre_used = 0;
+    std::memset(&h->stats, 0, sizeof(h->stats));
+    h->stats.small_is_f32 = h->small_f32 ? 1 : 0;
+    h->stats.n_grid_points = (long long)h->gW * h->gH;
+    h->stats.n_lags = n_out;
+    if (out_on_device) {
+        *out_dev = corr_out;
+    } else {
+        HIPCHK(h->out_dev.reserve((size_t)std::max<long long>(n_out, 1) * sizeof(double)));
+        *out_dev = h->out_dev.as<double>();
+    }
+    HIPCHK(hipEventRecord(h->ev_t0, h->stream));
+    if (n_out > 0) {
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, h->stream, *out_dev,
+                           (long long)n_out, std::numeric_limits<double>::quiet_NaN());
+        HIPCHK(hipGetLastError());
+    }
+    return COREG_OK;
+}
+
+int end_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_device, double* out_dev) {
+    HIPCHK(hipEventRecord(h->ev_t1, h->stream));
+    if (!out_on_device && n_out > 0)
+        HIPCHK(hipMemcpyAsync(corr_out, out_dev, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    long long info[2] = {0, 0};
+    if (h->tile_info.p)
+        HIPCHK(hipMemcpyAsync(info, h->tile_info.p, sizeof(info), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stats.n_active_points = info[1];
+    float ms = 0.f;
+    for (size_t i = 0; i < h->ev_sweep_used; ++i) {
+        HIPCHK(hipEventElapsedTime(&ms, h->ev_sweep[i].a, h->ev_sweep[i].b));
+        h->stats.sweep_kernel_ms += ms;
+    }
+    for (size_t i = 0; i < h->ev_pre_used; ++i) {
+        HIPCHK(hipEventElapsedTime(&ms, h->ev_pre[i].a, h->ev_pre[i].b));
+        h->stats.precompute_ms += ms;
+    }
+    HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+    h->stats.total_gpu_ms = ms;
+    return COREG_OK;
+}
+
+int pick_tile_w(coreg_handle* h, double dx_di, double dx_dj, double dy_di, double dy_dj, double span_x,
+                double span_y) {
+    if (h->opt_tile_w > 0) return (int)h->opt_tile_w;
+    int best_w = 32;
+    double best = std::numeric_limits<double>::max();
+    for (int tw = 4; tw <= 256; tw *= 2) {
+        const int th = kTilePts / tw;
+        const double ex = tw * std::fabs(dx_di) + th * std::fabs(dx_dj) + span_x + 4;
+        const double ey = tw * std::fabs(dy_di) + th * std::fabs(dy_dj) + span_y + 4;
+        const double cost = ex * ey;
+        if (cost < best) {
+            best = cost;
+            best_w = tw;
+        }
+    }
+    return best_w;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+extern "C" {
+
+const char* coreg_version(void) { return "coreg_hip " COREG_VERSION " (gfx950)"; }
+
+int coreg_create(coreg_handle** out, int device) {
+    if (!out) return COREG_EINVAL;
+    *out = nullptr;
+    coreg_handle* h = new (std::nothrow) coreg_handle();
+    if (!h) return COREG_ENOMEM;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) {
+        delete h;
+        return COREG_EHIP;
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= ndev) {
+        delete h;
+        return COREG_EINVAL;
+    }
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_t1) != hipSuccess ||
+        h->pivots.reserve(2 * sizeof(double)) != hipSuccess ||
+        hipMemsetAsync(h->pivots.p, 0, 2 * sizeof(double), h->stream) != hipSuccess) {
+        delete h;
+        return COREG_EHIP;
+    }
+    h->own_stream = true;
+    std::memset(&h->stats, 0, sizeof(h->stats));
+    *out = h;
+    return COREG_OK;
+}
+
+void coreg_destroy(coreg_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    DevBuf* bufs[] = {&h->small, &h->ref, &h->pivots, &h->red_sum, &h->red_cnt, &h->t_sin_lon, &h->t_cos_lon,
+                      &h->t_cos_lat, &h->t_sin_lat, &h->base0, &h->base1, &h->aval, &h->tile_count, &h->tile_list,
+                      &h->tile_info, &h->tile_bbox, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
+                      &h->tmp_img};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& e : h->ev_sweep) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    for (auto& e : h->ev_pre) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
+    if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* coreg_last_error(const coreg_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int coreg_set_stream(coreg_handle* h, void* hip_stream) {
+    if (!h) return COREG_EINVAL;
+    RETCHK(bind_device(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) HIPCHK(hipStreamDestroy(h->stream));
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return COREG_OK;
+}
+
+int coreg_synchronize(coreg_handle* h) {
+    if (!h) return COREG_EINVAL;
+    RETCHK(bind_device(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return COREG_OK;
+}
+
+int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
+    if (!h || !name) return COREG_EINVAL;
+    const std::string n(name);
+    if (n == "use_lds") {
+        h->opt_use_lds = value ? 1 : 0;
+    } else if (n == "tile_w") {
+        if (value != 0 && (value < 1 || value > kTilePts || (value & (value - 1)) != 0))
+            return fail(h, COREG_EINVAL, "tile_w must be 0 or a power of two <= 1024");
+        h->opt_tile_w = value;
+    } else if (n == "n_groups") {
+        if (value < 0) return fail(h, COREG_EINVAL, "n_groups must be >= 0");
+        h->opt_n_groups = value;
+    } else if (n == "lds_bytes") {
+        // 160 KiB per CU minus the kernel's static LDS
+        if (value < 1024 || value > 159 * 1024) return fail(h, COREG_EINVAL, "lds_bytes must be in [1 KiB, 159 KiB]");
+        h->opt_lds_bytes = value;
+    } else {
+        return fail(h, COREG_EINVAL, "unknown option: " + n);
+    }
+    return COREG_OK;
+}
+
+int coreg_set_small(coreg_handle* h, const double* img, int32_t ny, int32_t nx) {
+    if (!h) return COREG_EINVAL;
+    if (!img || ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "set_small: bad image");
+    RETCHK(bind_device(h));
+    const size_t n = (size_t)ny * nx;
+    RETCHK(upload_image(h, img, n, h->small, &h->small_f32));
+    h->sW = nx;
+    h->sH = ny;
+    if (h->small_f32)
+        RETCHK(device_mean<float>(h, h->small.as<float>(), (long long)n, h->pivots.as<double>() + 1));
+    else
+        RETCHK(device_mean<double>(h, h->small.as<double>(), (long long)n, h->pivots.as<double>() + 1));
+    return COREG_OK;
+}
+
+static int ref_pivot(coreg_handle* h) {
+    const long long n = (long long)h->gW * h->gH;
+    if (h->ref_dtype == COREG_F32) return device_mean<float>(h, h->ref.as<float>(), n, h->pivots.as<double>());
+    return device_mean<double>(h, h->ref.as<double>(), n, h->pivots.as<double>());
+}
+
+int coreg_set_reference_on_grid(coreg_handle* h, const void* ref, int dtype, int32_t gy, int32_t gx) {
+    if (!h) return COREG_EINVAL;
+    if (!ref || gy < 1 || gx < 1 || (dtype != COREG_F32 && dtype != COREG_F64))
+        return fail(h, COREG_EINVAL, "set_reference_on_grid: bad argument");
+    RETCHK(bind_device(h));
+    const size_t bytes = (size_t)gy * gx * (dtype == COREG_F32 ? 4 : 8);
+    HIPCHK(h->ref.reserve(bytes));
+    HIPCHK(hipMemcpyAsync(h->ref.p, ref, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->gW = gx;
+    h->gH = gy;
+    h->ref_dtype = dtype;
+    return ref_pivot(h);
+}
+
+int coreg_prepare_reference_carrington(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
+                                       const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r, int order) {
+    if (!h) return COREG_EINVAL;
+    if (!large || !hdr || !grid || ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
+    RETCHK(check_order(h, order));
+    RETCHK(bind_device(h));
+    bool f32;
+    RETCHK(upload_image(h, large, (size_t)ny * nx, h->tmp_img, &f32));
+    ResampleArgs a;
+    std::memset(&a, 0, sizeof(a));
+    RETCHK(upload_carr_tables(h, *grid, *hdr, &a.carr));
+    set_carr_common(&a.carr, carr_common(*hdr, solar_r));
+    carr_origin(*hdr, &a.x0, &a.y0);
+    a.img = h->tmp_img.p;
+    a.W = nx;
+    a.H = ny;
+    a.gw = grid->n_lon;
+    a.gh = grid->n_lat;
+    HIPCHK(h->ref.reserve((size_t)a.gw * a.gh * sizeof(double)));
+    a.out = h->ref.p;
+    RETCHK(dispatch_resample(h, MODE_TRANSLATE, order, f32, false, a, 0));
+    h->gW = a.gw;
+    h->gH = a.gh;
+    h->ref_dtype = COREG_F64;
+    RETCHK(ref_pivot(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->tmp_img.release();
+    return COREG_OK;
+}
+
+int coreg_prepare_reference_helioprojective(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
+                                            const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order) {
+    if (!h) return COREG_EINVAL;
+    if (!large || !hdr_large || !hdr_small || ny < 1 || nx < 1)
+        return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
+    if (hdr_small->naxis1 < 1 || hdr_small->naxis2 < 1) return fail(h, COREG_EINVAL, "hdr_small: NAXIS1/2 missing");
+    RETCHK(check_order(h, order));
+    RETCHK(bind_device(h));
+    bool f32;
+    RETCHK(upload_image(h, large, (size_t)ny * nx, h->tmp_img, &f32));
+    ResampleArgs a;
+    std::memset(&a, 0, sizeof(a));
+    homography(*hdr_small, *hdr_large, a.hom.h);  // alignment.py:993: pixels of hdr_cut -> pixels of hdr_large
+    a.img = h->tmp_img.p;
+    a.W = nx;
+    a.H = ny;
+    a.gw = hdr_small->naxis1;
+    a.gh = hdr_small->naxis2;
+    HIPCHK(h->ref.reserve((size_t)a.gw * a.gh * sizeof(float)));
+    a.out = h->ref.p;
+    RETCHK(dispatch_resample(h, MODE_HOMOGRAPHY, order, f32, true, a, 0));
+    h->gW = a.gw;
+    h->gH = a.gh;
+    h->ref_dtype = COREG_F32;
+    RETCHK(ref_pivot(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->tmp_img.release();
+    return COREG_OK;
+}
+
+int coreg_get_reference_on_grid(coreg_handle* h, void* out, int dtype) {
+    if (!h) return COREG_EINVAL;
+    if (!h->ref.p) return fail(h, COREG_ESTATE, "no reference image on the target grid");
+    if (!out || dtype != h->ref_dtype) return fail(h, COREG_EINVAL, "get_reference_on_grid: dtype mismatch");
+    RETCHK(bind_device(h));
+    const size_t bytes = (size_t)h->gW * h->gH * (dtype == COREG_F32 ? 4 : 8);
+    HIPCHK(hipMemcpyAsync(out, h->ref.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return COREG_OK;
+}
+
+int coreg_resample_carrington(coreg_handle* h, const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r,
+                              int order, double* out) {
+    if (!h) return COREG_EINVAL;
+    if (!hdr || !grid || !out) return fail(h, COREG_EINVAL, "resample_carrington: bad argument");
+    if (!h->small.p) return fail(h, COREG_ESTATE, "coreg_set_small has not been called");
+    RETCHK(check_order(h, order));
+    RETCHK(bind_device(h));
+    ResampleArgs a;
+    std::memset(&a, 0, sizeof(a));
+    RETCHK(upload_carr_tables(h, *grid, *hdr, &a.carr));
+    set_carr_common(&a.carr, carr_common(*hdr, solar_r));
+    carr_origin(*hdr, &a.x0, &a.y0);
+    a.img = h->small.p;
+    a.W = h->sW;
+    a.H = h->sH;
+    a.gw = grid->n_lon;
+    a.gh = grid->n_lat;
+    const size_t bytes = (size_t)a.gw * a.gh * sizeof(double);
+    HIPCHK(h->out_dev.reserve(bytes));
+    a.out = h->out_dev.p;
+    RETCHK(dispatch_resample(h, MODE_TRANSLATE, order, h->small_f32, false, a, 0));
+    HIPCHK(hipMemcpyAsync(out, h->out_dev.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return COREG_OK;
+}
+
+int coreg_resample_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr, int order,
+                                   float* out) {
+    if (!h) return COREG_EINVAL;
+    if (!hdr_target || !hdr || !out) return fail(h, COREG_EINVAL, "resample_helioprojective: bad argument");
+    if (!h->small.p) return fail(h, COREG_ESTATE, "coreg_set_small has not been called");
+    if (hdr_target->naxis1 < 1 || hdr_target->naxis2 < 1) return fail(h, COREG_EINVAL, "hdr_target: NAXIS missing");
+    RETCHK(check_order(h, order));
+    RETCHK(bind_device(h));
+    ResampleArgs a;
+    std::memset(&a, 0, sizeof(a));
+    homography(*hdr_target, *hdr, a.hom.h);  // alignment.py:1022
+    a.img = h->small.p;
+    a.W = h->sW;
+    a.H = h->sH;
+    a.gw = hdr_target->naxis1;
+    a.gh = hdr_target->naxis2;
+    const size_t bytes = (size_t)a.gw * a.gh * sizeof(float);
+    HIPCHK(h->out_dev.reserve(bytes));
+    a.out = h->out_dev.p;
+    RETCHK(dispatch_resample(h, MODE_HOMOGRAPHY, order, h->small_f32, true, a, 0));
+    HIPCHK(hipMemcpyAsync(out, h->out_dev.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return COREG_OK;
+}
+
+int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const coreg_carr_grid* grid, double solar_r,
+                           const coreg_lags* lags, int order, int method, int cdelt_semantics, int64_t lag_begin,
+                           int64_t lag_end, double* corr_out, int out_on_device) {
+    if (!h) return COREG_EINVAL;
+    if (!hdr_small || !grid) return fail(h, COREG_EINVAL, "sweep_carrington: null header/grid");
+    if (method != COREG_METHOD_CORRELATION)
+        return fail(h, COREG_ENOTIMPL, "only method='correlation' is implemented on the GPU");
+    RETCHK(check_order(h, order));
+    LagDims d;
+    RETCHK(check_lags(h, lags, &d, lag_begin, lag_end));
+    RETCHK(bind_device(h));
+    if (h->ref.p && (h->gW != grid->n_lon || h->gH != grid->n_lat))
+        return fail(h, COREG_EINVAL, "reference-on-grid shape differs from the Carrington grid");
+    const long long n_out = lag_end - lag_begin;
+    double* out_dev = nullptr;
+    RETCHK(begin_sweep(h, n_out, corr_out, out_on_device, &out_dev));
+    if (n_out == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+
+    CarrDev cd;
+    std::memset(&cd, 0, sizeof(cd));
+    RETCHK(upload_carr_tables(h, *grid, *hdr_small, &cd));
+    CarrTables tabs;
+    carr_tables(*grid, hdr_small->crln_obs, tabs);
+
+    // tile shape: local scale of the grid -> pixel map near the grid centre (heuristic only)
+    int tile_w = 32;
+    {
+        const CarrCommon c0 = carr_common(*hdr_small, solar_r);
+        const int ic = grid->n_lon / 2, jc = grid->n_lat / 2;
+        double a0, a1, b0, b1, c0x, c0y;
+        carr_term_host(tabs, c0, ic, jc, &a0, &a1);
+        carr_term_host(tabs, c0, std::min(ic + 1, grid->n_lon - 1), jc, &b0, &b1);
+        carr_term_host(tabs, c0, ic, std::min(jc + 1, grid->n_lat - 1), &c0x, &c0y);
+        const double step1 = d.n1 > 1 ? std::fabs(lags->crval1[1] - lags->crval1[0]) / std::fabs(hdr_small->cdelt1) : 0;
+        const double step2 = d.n2 > 1 ? std::fabs(lags->crval2[1] - lags->crval2[0]) / std::fabs(hdr_small->cdelt2) : 0;
+        tile_w = pick_tile_w(h, b0 - a0, c0x - a0, b1 - a1, c0y - a1, 16 * step1, 16 * step2);
+    }
+    PrecomputeArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    // reserve before filling pointers
+    {
+        const int th = kTilePts / tile_w;
+        const int n_tiles = ((h->gW + tile_w - 1) / tile_w) * ((h->gH + th - 1) / th);
+        RETCHK(reserve_tiles(h, n_tiles));
+    }
+    fill_precompute_common(h, &pa, tile_w);
+    const int n_tiles = pa.tiles_x * pa.tiles_y;
+
+    SlotList slots;
+    std::vector<double> params;
+    const long long row = (long long)d.n2 * d.nc;
+    for (long long c = 0; c < d.nc; ++c) {
+        // does the slice touch this combo at all?
+        {
+            const long long first = (lag_begin - c + d.nc - 1) / d.nc;  // smallest k with k*nc + c >= begin
+            if (first * d.nc + c >= lag_end) continue;
+        }
+        const int i5 = (int)(c % d.n5), i4 = (int)((c / d.n5) % d.n4), i3 = (int)(c / ((long long)d.n5 * d.n4));
+        coreg_wcs2d hc;
+        if (shift_header(*hdr_small, 0.0, 0.0, lags->cdelt1[i3], lags->cdelt2[i4], lags->crota[i5], cdelt_semantics,
+                         &hc))
+            continue;  // reference semantics: this lag kills the worker -> NaN (already filled)
+        build_slots(d, c, lag_begin, lag_end, &slots);
+        if (slots.n_batches == 0) continue;
+        const size_t ns = slots.i1.size();
+        params.assign(2 * ns, 0.0);
+        double x0min = 1e300, x0max = -1e300, y0min = 1e300, y0max = -1e300;
+        for (size_t s = 0; s < ns; ++s) {
+            coreg_wcs2d hl = hc;
+            hl.crval1 = hdr_small->crval1 + lags->crval1[slots.i1[s]];  // alignment.py:404
+            hl.crval2 = hdr_small->crval2 + lags->crval2[slots.i2[s]];  // alignment.py:412
+            double x0, y0;
+            carr_origin(hl, &x0, &y0);
+            params[s] = x0;
+            params[ns + s] = y0;
+            x0min = std::min(x0min, x0);
+            x0max = std::max(x0max, x0);
+            y0min = std::min(y0min, y0);
+            y0max = std::max(y0max, y0);
+        }
+        set_carr_common(&cd, carr_common(hc, solar_r));
+        pa.carr = cd;
+        // a point can be in bounds for some lag only if X0 + t0 in [0, W-1] for some X0 in [x0min, x0max]
+        pa.f0lo = -x0max;
+        pa.f0hi = (double)(h->sW - 1) - x0min;
+        pa.f1lo = -y0max;
+        pa.f1hi = (double)(h->sH - 1) - y0min;
+        RETCHK(launch_precompute<MODE_TRANSLATE>(h, pa, n_tiles));
+        RETCHK(launch_sweep(h, MODE_TRANSLATE, order, 2, params, slots.outidx, slots.n_batches, n_tiles, 0, lag_begin,
+                            out_dev));
+    }
+    (void)row;
+    return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+}
+
+int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_small,
+                                const coreg_lags* lags, int order, int method, int cdelt_semantics, int64_t lag_begin,
+                                int64_t lag_end, double* corr_out, int out_on_device) {
+    if (!h) return COREG_EINVAL;
+    if (!hdr_target || !hdr_small) return fail(h, COREG_EINVAL, "sweep_helioprojective: null header");
+    if (method != COREG_METHOD_CORRELATION)
+        return fail(h, COREG_ENOTIMPL, "only method='correlation' is implemented on the GPU");
+    RETCHK(check_order(h, order));
+    LagDims d;
+    RETCHK(check_lags(h, lags, &d, lag_begin, lag_end));
+    RETCHK(bind_device(h));
+    if (h->ref.p && (h->gW != hdr_target->naxis1 || h->gH != hdr_target->naxis2))
+        return fail(h, COREG_EINVAL, "reference-on-grid shape differs from hdr_target NAXIS1/NAXIS2");
+    const long long n_out = lag_end - lag_begin;
+    double* out_dev = nullptr;
+    RETCHK(begin_sweep(h, n_out, corr_out, out_on_device, &out_dev));
+    if (n_out == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+
+    // all slots of all combos -> one launch
+    SlotList slots, all;
+    std::vector<double> hs;  // AoS while building
+    std::vector<coreg_wcs2d> combo_hdr((size_t)d.nc);
+    std::vector<char> combo_dead((size_t)d.nc, 0);
+    for (long long c = 0; c < d.nc; ++c) {
+        const int i5 = (int)(c % d.n5), i4 = (int)((c / d.n5) % d.n4), i3 = (int)(c / ((long long)d.n5 * d.n4));
+        combo_dead[c] = (char)shift_header(*hdr_small, 0.0, 0.0, lags->cdelt1[i3], lags->cdelt2[i4], lags->crota[i5],
+                                           cdelt_semantics, &combo_hdr[c]);
+    }
+    double fx0 = 1e300, fx1 = -1e300, fy0 = 1e300, fy1 = -1e300;  // cull box in target pixels
+    for (long long c = 0; c < d.nc; ++c) {
+        const long long first = (lag_begin - c + d.nc - 1) / d.nc;
+        if (first * d.nc + c >= lag_end || combo_dead[c]) continue;
+        build_slots(d, c, lag_begin, lag_end, &slots);
+        for (size_t s = 0; s < slots.i1.size(); ++s) {
+            coreg_wcs2d hl = combo_hdr[c];
+            hl.crval1 = hdr_small->crval1 + lags->crval1[slots.i1[s]];
+            hl.crval2 = hdr_small->crval2 + lags->crval2[slots.i2[s]];
+            double hm[9];
+            homography(*hdr_target, hl, hm);
+            hs.insert(hs.end(), hm, hm + 9);
+            // inverse map of the small image's corners -> which target pixels can ever be in bounds
+            double hi[9];
+            homography(hl, *hdr_target, hi);
+            for (int k = 0; k < 4; ++k) {
+                double px, py;
+                apply_h(hi, (k & 1) ? (double)(h->sW - 1) : 0.0, (k & 2) ? (double)(h->sH - 1) : 0.0, &px, &py);
+                fx0 = std::min(fx0, px);
+                fx1 = std::max(fx1, px);
+                fy0 = std::min(fy0, py);
+                fy1 = std::max(fy1, py);
+            }
+        }
+        all.i1.insert(all.i1.end(), slots.i1.begin(), slots.i1.end());
+        all.outidx.insert(all.outidx.end(), slots.outidx.begin(), slots.outidx.end());
+        all.n_batches += slots.n_batches;
+    }
+    if (all.n_batches == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+    const size_t ns = all.outidx.size();
+    std::vector<double> params(9 * ns);
+    for (size_t s = 0; s < ns; ++s)
+        for (int k = 0; k < 9; ++k) params[(size_t)k * ns + s] = hs[s * 9 + k];
+
+    // tile shape from the local scale of the first lag's map
+    int tile_w = 32;
+    {
+        const double* m = &hs[0];
+        double ax, ay, bx, by, cx, cy;
+        const double u = hdr_target->naxis1 * 0.5, v = hdr_target->naxis2 * 0.5;
+        apply_h(m, u, v, &ax, &ay);
+        apply_h(m, u + 1, v, &bx, &by);
+        apply_h(m, u, v + 1, &cx, &cy);
+        const double step1 = d.n1 > 1 ? std::fabs(lags->crval1[1] - lags->crval1[0]) / std::fabs(hdr_small->cdelt1) : 0;
+        const double step2 = d.n2 > 1 ? std::fabs(lags->crval2[1] - lags->crval2[0]) / std::fabs(hdr_small->cdelt2) : 0;
+        tile_w = pick_tile_w(h, bx - ax, cx - ax, by - ay, cy - ay, 16 * step1, 16 * step2);
+    }
+    PrecomputeArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    {
+        const int th = kTilePts / tile_w;
+        const int n_tiles = ((h->gW + tile_w - 1) / tile_w) * ((h->gH + th - 1) / th);
+        RETCHK(reserve_tiles(h, n_tiles));
+    }
+    fill_precompute_common(h, &pa, tile_w);
+    const int n_tiles = pa.tiles_x * pa.tiles_y;
+    // the maps are projective and the image corners bound its interior: +-2 px guards rounding of the inverse
+    pa.f0lo = std::floor(fx0) - 2.0;
+    pa.f0hi = std::ceil(fx1) + 2.0;
+    pa.f1lo = std::floor(fy0) - 2.0;
+    pa.f1hi = std::ceil(fy1) + 2.0;
+    RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles));
+    RETCHK(launch_sweep(h, MODE_HOMOGRAPHY, order, 9, params, all.outidx, all.n_batches, n_tiles,
+                        /*round_f32=*/1, lag_begin, out_dev));
+    return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+}
+
+int coreg_last_stats(const coreg_handle* h, coreg_stats* out) {
+    if (!h || !out) return COREG_EINVAL;
+    *out = h->stats;
+    return COREG_OK;
+}
+
+// ---- host-only helpers (no GPU needed): exported so that the header logic can be tested on CPU --------------------
+int coreg_shift_header(const coreg_wcs2d* ref, double d_crval1, double d_crval2, double d_cdelt1, double d_cdelt2,
+                       double d_crota, int cdelt_semantics, coreg_wcs2d* out) {
+    if (!ref || !out) return COREG_EINVAL;
+    return shift_header(*ref, d_crval1, d_crval2, d_cdelt1, d_cdelt2, d_crota, cdelt_semantics, out);
+}
+
+int coreg_homography(const coreg_wcs2d* from, const coreg_wcs2d* to, double* h9) {
+    if (!from || !to || !h9) return COREG_EINVAL;
+    homography(*from, *to, h9);
+    return COREG_OK;
+}
+
+int coreg_carrington_origin(const coreg_wcs2d* hdr, double* x0, double* y0) {
+    if (!hdr || !x0 || !y0) return COREG_EINVAL;
+    carr_origin(*hdr, x0, y0);
+    return COREG_OK;
+}
+
+}  // extern "C"

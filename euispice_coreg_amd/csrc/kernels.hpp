@@ -1,0 +1,570 @@
+// HIP kernels (gfx950 / CDNA4, wave64) of the alignment sweep.
+//
+// Work decomposition ("lag-per-lane"):
+//   * the target grid is cut in tiles of 1024 points; a precompute pass (k_precompute) evaluates the
+//     lag-independent part of the pixel-coordinate transform once per tile, drops points that can never
+//     contribute (reference NaN, behind the limb, outside the small image for every lag) and stores the
+//     survivors compacted, tile-major, together with their bounding box in small-image pixel space;
+//   * the sweep kernel (k_sweep) gives every LANE one lag-point (a workgroup = 256 lags of a compact CRVAL patch)
+//     and walks the compacted points of its tiles: point data are wave-uniform (scalar loads), every lane adds
+//     its own lag displacement, gathers the 3x3 (order 2) / 2x2 (order 1) taps from an LDS-staged window of the
+//     small image and accumulates its own six Pearson sums in registers.  No cross-lane reduction exists
+//     anywhere on the hot path; partial sums leave the kernel once per (tile-group, lag);
+//   * k_finalize adds the tile-group slabs in a fixed order (deterministic) and evaluates the coefficient.
+//
+// Reference arithmetic restated (paths relative to euispice_coreg/):
+//   utils/Util.py:82-104 + scipy.ndimage.map_coordinates(order, mode='constant', prefilter=False)  -> spline_*()
+//   utils/rectify.py:340-363 SphericalTransform.forward                                             -> carr_term()
+//   hdrshift/alignment.py:525-531 mask + hdrshift/c_correlate.py:39-72 Pearson                      -> k_sweep/k_finalize
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace coreg {
+
+constexpr int kTilePts = 1024;  // grid points per tile
+constexpr int kBlock = 256;     // threads per workgroup (4 waves) = lag slots per batch
+constexpr int kNumSums = 6;     // n, sum a, sum b, sum aa, sum bb, sum ab
+
+enum { MODE_TRANSLATE = 0, MODE_HOMOGRAPHY = 1 };
+
+struct CarrDev {
+    const double* sin_lon;  // [n_lon] sin(lon')
+    const double* cos_lon;  // [n_lon] cos(lon')
+    const float* cos_lat;   // [n_lat] float32 cos(lat)
+    const float* sin_lat;   // [n_lat] float32 sin(lat)
+    int n_lon, n_lat;
+    double dist, cb, sb, cr, sr, cdelt1, cdelt2;
+};
+
+struct H9 {
+    double h[9];
+};
+
+// ---- utils/rectify.py:340-363: the lag-independent part of SphericalTransform.forward for grid point (i, j):
+// t0 = degrees(atan(x''/z)) * 3600 / cdelt1, t1 likewise; pixel = (X0 + t0, Y0 + t1).  Operation order follows the
+// reference (no fused multiply-add) so that float64 results track NumPy's.
+__device__ __forceinline__ bool carr_term(const CarrDev& c, int i, int j, double& t0, double& t1) {
+#pragma clang fp contract(off)
+    const double cl = (double)c.cos_lat[j];
+    const double y = (double)c.sin_lat[j];
+    const double x = cl * c.sin_lon[i];
+    const double z = cl * c.cos_lon[i];
+    const double zz = z * c.cb + y * c.sb;
+    const double yy = y * c.cb - z * c.sb;
+    const bool vis = zz >= 0.0;  // zclip = 0
+    const double yr = yy * c.cr - x * c.sr;
+    const double xr = x * c.cr + yy * c.sr;
+    const double zd = c.dist - zz;
+    t0 = atan(xr / zd) * (180.0 / 3.14159265358979323846) * 3600.0 / c.cdelt1;
+    t1 = atan(yr / zd) * (180.0 / 3.14159265358979323846) * 3600.0 / c.cdelt2;
+    return vis;
+}
+
+__device__ __forceinline__ void apply_h(const H9& m, double x, double y, double& ox, double& oy) {
+    const double w = fma(m.h[6], x, fma(m.h[7], y, m.h[8]));
+    const double r = 1.0 / w;
+    ox = fma(m.h[0], x, fma(m.h[1], y, m.h[2])) * r;
+    oy = fma(m.h[3], x, fma(m.h[4], y, m.h[5])) * r;
+}
+
+// ---- spline weights of scipy's get_spline_interpolation_weights (ni_splines.c), orders 1 and 2 -----------------
+template <int ORDER>
+struct Spline;
+template <>
+struct Spline<2> {
+    static constexpr int N = 3;
+    // first tap index and weights for coordinate c
+    static __device__ __forceinline__ void eval(double c, int& start, double w[3]) {
+        const double f = floor(c + 0.5);
+        const double t = c - f;
+        w[1] = 0.75 - t * t;
+        const double y = 0.5 - t;
+        w[0] = 0.5 * y * y;
+        w[2] = 1.0 - w[0] - w[1];
+        start = (int)f - 1;
+    }
+};
+template <>
+struct Spline<1> {
+    static constexpr int N = 2;
+    static __device__ __forceinline__ void eval(double c, int& start, double w[2]) {
+        const double f = floor(c);
+        const double t = c - f;
+        w[0] = 1.0 - t;
+        w[1] = t;
+        start = (int)f;
+    }
+};
+
+__device__ __forceinline__ int mirror_idx(int i, int n) {  // scipy: reflect about the edge sample
+    i = i < 0 ? -i : i;
+    i = i > n - 1 ? 2 * (n - 1) - i : i;
+    return min(max(i, 0), n - 1);
+}
+
+// One sample of map_coordinates(order, mode='constant', prefilter=False) from global memory.
+// inb = the whole-sample bounds rule (c < 0 or c > n-1 or NaN -> cval).
+template <int ORDER, typename TS>
+__device__ __forceinline__ double spline_global(const TS* __restrict__ img, int W, int H, double nx, double ny,
+                                                bool& inb) {
+    constexpr int N = Spline<ORDER>::N;
+    inb = (nx >= 0.0) & (nx <= (double)(W - 1)) & (ny >= 0.0) & (ny <= (double)(H - 1));
+    const double cx = inb ? nx : 0.0, cy = inb ? ny : 0.0;
+    int sx, sy;
+    double wx[N], wy[N];
+    Spline<ORDER>::eval(cx, sx, wx);
+    Spline<ORDER>::eval(cy, sy, wy);
+    int ix[N], iy[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        ix[k] = mirror_idx(sx + k, W);
+        iy[k] = mirror_idx(sy + k, H) * W;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+        double row = 0.0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) row = fma((double)img[iy[a] + ix[b]], wx[b], row);
+        acc = fma(row, wy[a], acc);
+    }
+    return acc;
+}
+
+// Same sample from an LDS window that already holds the mirrored one-pixel apron:
+// lds[(gy - oy) * pitch + (gx - ox)] = image(mirror(gy), mirror(gx)).
+template <int ORDER, typename TS>
+__device__ __forceinline__ double spline_lds(const TS* lds, int pitch, int ox, int oy, int W, int H, double nx,
+                                             double ny, bool& inb) {
+    constexpr int N = Spline<ORDER>::N;
+    inb = (nx >= 0.0) & (nx <= (double)(W - 1)) & (ny >= 0.0) & (ny <= (double)(H - 1));
+    const double cx = inb ? nx : (double)(ox + 1), cy = inb ? ny : (double)(oy + 1);
+    int sx, sy;
+    double wx[N], wy[N];
+    Spline<ORDER>::eval(cx, sx, wx);
+    Spline<ORDER>::eval(cy, sy, wy);
+    const TS* p = lds + (sy - oy) * pitch + (sx - ox);
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+        double row = 0.0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) row = fma((double)p[a * pitch + b], wx[b], row);
+        acc = fma(row, wy[a], acc);
+    }
+    return acc;
+}
+
+// ---- finite-mean (pivot) ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_sum_finite(const T* __restrict__ v, long long n, double* part_sum,
+                                                    long long* part_cnt) {
+    __shared__ double ss[256];
+    __shared__ long long sc[256];
+    double s = 0.0;
+    long long c = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double x = (double)v[i];
+        if (isfinite(x)) {
+            s += x;
+            ++c;
+        }
+    }
+    ss[threadIdx.x] = s;
+    sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            ss[threadIdx.x] += ss[threadIdx.x + o];
+            sc[threadIdx.x] += sc[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part_sum[blockIdx.x] = ss[0];
+        part_cnt[blockIdx.x] = sc[0];
+    }
+}
+__global__ void k_mean_final(const double* part_sum, const long long* part_cnt, int n, double* mean_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        long long c = 0;
+        for (int i = 0; i < n; ++i) {
+            s += part_sum[i];
+            c += part_cnt[i];
+        }
+        mean_out[0] = c > 0 ? s / (double)c : 0.0;
+    }
+}
+
+__global__ void k_fill(double* p, long long n, double v) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---- once-only resample (reference preparation, alignment.py:646-651; single-header resample) ----------------------
+struct ResampleArgs {
+    const void* img;  // small / large image, TS
+    int W, H;
+    int gw, gh;  // output grid [gh][gw]
+    CarrDev carr;
+    double x0, y0;  // Carrington origin (utils/rectify.py:402-404)
+    H9 hom;
+    void* out;
+};
+template <int MODE, int ORDER, typename TS, typename TO>
+__global__ void __launch_bounds__(256) k_resample(const ResampleArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.gw * a.gh) return;
+    const int i = (int)(idx % a.gw), j = (int)(idx / a.gw);
+    double nx, ny;
+    bool ok = true;
+    if (MODE == MODE_TRANSLATE) {
+        double t0, t1;
+        ok = carr_term(a.carr, i, j, t0, t1);
+        nx = a.x0 + t0;
+        ny = a.y0 + t1;
+    } else {
+        apply_h(a.hom, (double)i, (double)j, nx, ny);
+    }
+    bool inb;
+    if (!ok) nx = __builtin_nan("");
+    double v = spline_global<ORDER, TS>((const TS*)a.img, a.W, a.H, nx, ny, inb);
+    if (!inb) v = __builtin_nan("");
+    ((TO*)a.out)[idx] = (TO)v;
+}
+
+// ---- precompute: base coordinates, culling, tile-major compaction -----------------------------------------------
+struct PrecomputeArgs {
+    const void* ref;  // reference on grid, TA, [gh][gw]
+    int gw, gh;
+    int tile_w, tile_h;  // tile_w * tile_h == kTilePts
+    int tiles_x, tiles_y;
+    CarrDev carr;             // MODE_TRANSLATE
+    double f0lo, f0hi, f1lo, f1hi;  // cull box on the base coordinates (inclusive)
+    const double* pivot_a;    // device scalar: mean of the finite reference values
+    double* base0;            // [n_tiles][kTilePts]
+    double* base1;
+    double* aval;             // reference value - pivot
+    int* tile_count;          // [n_tiles]
+    double* tile_bbox;        // [n_tiles][4] min0, max0, min1, max1 over the kept points
+};
+template <int MODE, typename TA>
+__global__ void __launch_bounds__(256) k_precompute(const PrecomputeArgs a) {
+    __shared__ int wave_cnt[4];
+    __shared__ double red[4][4];
+    const int tile = blockIdx.x;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double pivot = a.pivot_a[0];
+    const double inf = __builtin_inf();
+    double mn0 = inf, mx0 = -inf, mn1 = inf, mx1 = -inf;
+    int base_pos = 0;
+    const size_t tbase = (size_t)tile * kTilePts;
+    for (int r = 0; r < kTilePts / 256; ++r) {
+        const int k = r * 256 + threadIdx.x;
+        const int gi = tx * a.tile_w + (k % a.tile_w);
+        const int gj = ty * a.tile_h + (k / a.tile_w);
+        bool valid = (gi < a.gw) & (gj < a.gh);
+        double b0 = 0.0, b1 = 0.0, av = 0.0;
+        if (valid) {
+            av = (double)((const TA*)a.ref)[(size_t)gj * a.gw + gi];
+            if (MODE == MODE_TRANSLATE) {
+                valid = carr_term(a.carr, gi, gj, b0, b1);
+            } else {
+                b0 = (double)gi;
+                b1 = (double)gj;
+            }
+            valid = valid & isfinite(av) & (b0 >= a.f0lo) & (b0 <= a.f0hi) & (b1 >= a.f1lo) & (b1 <= a.f1hi);
+        }
+        const unsigned long long bal = __ballot(valid);
+        const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base_pos;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        if (valid) {
+            const size_t o = tbase + off + rank;
+            a.base0[o] = b0;
+            a.base1[o] = b1;
+            a.aval[o] = av - pivot;
+            mn0 = fmin(mn0, b0);
+            mx0 = fmax(mx0, b0);
+            mn1 = fmin(mn1, b1);
+            mx1 = fmax(mx1, b1);
+        }
+        base_pos += tot;
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mn0 = fmin(mn0, __shfl_xor(mn0, o));
+        mx0 = fmax(mx0, __shfl_xor(mx0, o));
+        mn1 = fmin(mn1, __shfl_xor(mn1, o));
+        mx1 = fmax(mx1, __shfl_xor(mx1, o));
+    }
+    if (lane == 0) {
+        red[wave][0] = mn0;
+        red[wave][1] = mx0;
+        red[wave][2] = mn1;
+        red[wave][3] = mx1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.tile_count[tile] = base_pos;
+        double* bb = a.tile_bbox + (size_t)tile * 4;
+        bb[0] = fmin(fmin(red[0][0], red[1][0]), fmin(red[2][0], red[3][0]));
+        bb[1] = fmax(fmax(red[0][1], red[1][1]), fmax(red[2][1], red[3][1]));
+        bb[2] = fmin(fmin(red[0][2], red[1][2]), fmin(red[2][2], red[3][2]));
+        bb[3] = fmax(fmax(red[0][3], red[1][3]), fmax(red[2][3], red[3][3]));
+    }
+}
+
+// list of non-empty tiles in tile order (single workgroup, deterministic); info[0] = count, info[1] = total points
+__global__ void __launch_bounds__(1024) k_tile_list(const int* __restrict__ tile_count, int n_tiles, int* tile_list,
+                                                    long long* info) {
+    __shared__ int wcnt[16];
+    __shared__ long long wpts[16];
+    __shared__ int s_base;
+    __shared__ long long s_pts;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        s_base = 0;
+        s_pts = 0;
+    }
+    __syncthreads();
+    for (int t0 = 0; t0 < n_tiles; t0 += 1024) {
+        const int t = t0 + threadIdx.x;
+        const int c = t < n_tiles ? tile_count[t] : 0;
+        const bool nz = c > 0;
+        const unsigned long long bal = __ballot(nz);
+        const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+        long long pts = c;
+        for (int o = 32; o > 0; o >>= 1) pts += __shfl_xor(pts, o);
+        if (lane == 0) {
+            wcnt[wave] = __popcll(bal);
+            wpts[wave] = pts;
+        }
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += wcnt[w];
+        if (nz) tile_list[off + rank] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            long long tp = 0;
+            for (int w = 0; w < 16; ++w) {
+                tot += wcnt[w];
+                tp += wpts[w];
+            }
+            s_base += tot;
+            s_pts += tp;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        info[0] = s_base;
+        info[1] = s_pts;
+    }
+}
+
+// ---- the sweep -------------------------------------------------------------------------------------------------------
+struct SweepArgs {
+    const void* img;  // small image, TS [H][W]
+    int W, H;
+    const double* base0;  // tile-major compacted base coordinates
+    const double* base1;
+    const double* aval;
+    const int* tile_count;
+    const int* tile_list;
+    const long long* tile_info;  // [0] = number of non-empty tiles
+    const double* tile_bbox;
+    const double* lane_params;  // SoA [NP][n_slots]; TRANSLATE: X0, Y0; HOMOGRAPHY: h0..h8
+    long long n_slots;          // n_batches * 256
+    int n_batches;
+    int n_groups;  // multiple of 8
+    double* partials;  // [n_groups][kNumSums][n_slots]
+    const double* pivots;  // device: [0] mean(reference) (already subtracted in aval), [1] mean(small image)
+    int round_f32;     // helioprojective: sample rounded to float32 before the mask (alignment.py:1024)
+    int use_lds;
+    int lds_elems;     // capacity of the dynamic LDS window in TS elements
+};
+
+template <int MODE, int ORDER, typename TS>
+__global__ void __launch_bounds__(kBlock) k_sweep(const SweepArgs a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    TS* lds = (TS*)lds_raw;
+    __shared__ double wred[4][4];
+
+    // XCD-aware block -> (group, batch): blocks with equal blockIdx % 8 share an XCD (round-robin dispatch), so all
+    // lag batches of one tile group land on one XCD and re-use its tiles / image window from that XCD's L2.
+    const int b = blockIdx.x;
+    const int slot8 = b & 7;
+    const int q = b >> 3;
+    const int batch = q % a.n_batches;
+    const int group = (q / a.n_batches) * 8 + slot8;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long slot = (long long)batch * kBlock + threadIdx.x;
+
+    // this lane's lag
+    double px0 = 0.0, py0 = 0.0;
+    H9 hm;
+    if (MODE == MODE_TRANSLATE) {
+        px0 = a.lane_params[slot];
+        py0 = a.lane_params[a.n_slots + slot];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) hm.h[k] = a.lane_params[(long long)k * a.n_slots + slot];
+    }
+
+    int cnt_n = 0;
+    double s_a = 0.0, s_b = 0.0, s_aa = 0.0, s_bb = 0.0, s_ab = 0.0;
+
+    const TS* __restrict__ img = (const TS*)a.img;
+    const int W = a.W, H = a.H;
+    const int n_tiles = (int)a.tile_info[0];
+    const double inf = __builtin_inf();
+    const double pivot_b = a.pivots[1];
+
+    for (int tl = group; tl < n_tiles; tl += a.n_groups) {
+        const int tile = a.tile_list[tl];
+        const int cnt = a.tile_count[tile];
+        const double* bb = a.tile_bbox + (size_t)tile * 4;
+        const double bx0 = bb[0], bx1 = bb[1], by0 = bb[2], by1 = bb[3];
+
+        // bounding box, in small-image pixels, of (tile points) x (this workgroup's lags)
+        double mnx, mxx, mny, mxy;
+        if (MODE == MODE_TRANSLATE) {
+            mnx = bx0 + px0;
+            mxx = bx1 + px0;
+            mny = by0 + py0;
+            mxy = by1 + py0;
+        } else {
+            mnx = inf; mxx = -inf; mny = inf; mxy = -inf;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double cx, cy;
+                apply_h(hm, (c & 1) ? bx1 : bx0, (c & 2) ? by1 : by0, cx, cy);
+                mnx = fmin(mnx, cx);
+                mxx = fmax(mxx, cx);
+                mny = fmin(mny, cy);
+                mxy = fmax(mxy, cy);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            mnx = fmin(mnx, __shfl_xor(mnx, o));
+            mxx = fmax(mxx, __shfl_xor(mxx, o));
+            mny = fmin(mny, __shfl_xor(mny, o));
+            mxy = fmax(mxy, __shfl_xor(mxy, o));
+        }
+        __syncthreads();  // previous tile's LDS window and wred are no longer in use
+        if (lane == 0) {
+            wred[wave][0] = mnx;
+            wred[wave][1] = mxx;
+            wred[wave][2] = mny;
+            wred[wave][3] = mxy;
+        }
+        __syncthreads();
+        mnx = fmin(fmin(wred[0][0], wred[1][0]), fmin(wred[2][0], wred[3][0]));
+        mxx = fmax(fmax(wred[0][1], wred[1][1]), fmax(wred[2][1], wred[3][1]));
+        mny = fmin(fmin(wred[0][2], wred[1][2]), fmin(wred[2][2], wred[3][2]));
+        mxy = fmax(fmax(wred[0][3], wred[1][3]), fmax(wred[2][3], wred[3][3]));
+        // no in-bounds sample possible for this (tile, batch)?  (uniform)
+        if (!(mxx >= 0.0) || !(mnx <= (double)(W - 1)) || !(mxy >= 0.0) || !(mny <= (double)(H - 1))) continue;
+        // integer window with the mirrored apron: taps of in-bounds samples lie in [floor(c)-1, floor(c)+2]
+        const int ox = max((int)floor(fmax(mnx, 0.0)) - 1, -1);
+        const int oy = max((int)floor(fmax(mny, 0.0)) - 1, -1);
+        const int ex = min((int)floor(fmin(mxx, (double)(W - 1))) + 2, W);
+        const int ey = min((int)floor(fmin(mxy, (double)(H - 1))) + 2, H);
+        const int ww = ex - ox + 1, wh = ey - oy + 1;
+        const int pitch = ww | 1;  // odd pitch spreads rows over banks
+        const bool in_lds = a.use_lds && ((long long)pitch * wh <= (long long)a.lds_elems);
+
+        if (in_lds) {
+            for (int r = wave; r < wh; r += 4) {
+                const int gy = mirror_idx(oy + r, H);
+                const TS* __restrict__ src = img + (size_t)gy * W;
+                TS* dst = lds + r * pitch;
+                for (int c = lane; c < ww; c += 64) dst[c] = src[mirror_idx(ox + c, W)];
+            }
+            __syncthreads();
+        }
+
+        const double* __restrict__ pb0 = a.base0 + (size_t)tile * kTilePts;
+        const double* __restrict__ pb1 = a.base1 + (size_t)tile * kTilePts;
+        const double* __restrict__ pav = a.aval + (size_t)tile * kTilePts;
+
+        for (int p = 0; p < cnt; ++p) {
+            const double b0 = pb0[p], b1 = pb1[p], av = pav[p];  // wave-uniform
+            double nx, ny;
+            if (MODE == MODE_TRANSLATE) {
+                nx = px0 + b0;  // self.x + term, utils/rectify.py:362
+                ny = py0 + b1;
+            } else {
+                apply_h(hm, b0, b1, nx, ny);
+            }
+            bool inb;
+            double v;
+            if (in_lds)
+                v = spline_lds<ORDER, TS>(lds, pitch, ox, oy, W, H, nx, ny, inb);
+            else
+                v = spline_global<ORDER, TS>(img, W, H, nx, ny, inb);
+            if (a.round_f32) v = (double)(float)v;
+            const bool ok = inb & isfinite(v);
+            const double bm = ok ? v - pivot_b : 0.0;
+            const double am = ok ? av : 0.0;
+            cnt_n += ok ? 1 : 0;
+            s_a += am;
+            s_b += bm;
+            s_aa = fma(am, am, s_aa);
+            s_bb = fma(bm, bm, s_bb);
+            s_ab = fma(am, bm, s_ab);
+        }
+    }
+
+    double* out = a.partials + (size_t)group * kNumSums * a.n_slots + slot;
+    out[0] = (double)cnt_n;
+    out[a.n_slots] = s_a;
+    out[2 * a.n_slots] = s_b;
+    out[3 * a.n_slots] = s_aa;
+    out[4 * a.n_slots] = s_bb;
+    out[5 * a.n_slots] = s_ab;
+}
+
+// ---- finalize: add the tile-group slabs in a fixed order, Pearson coefficient (c_correlate.py:39-72) -------------
+struct FinalizeArgs {
+    const double* partials;
+    int n_groups;
+    long long n_slots;
+    const long long* out_index;  // C-order raveled lag index of each slot, or -1 (padding)
+    long long lag_begin;
+    double* out;  // [lag_end - lag_begin]
+};
+__global__ void __launch_bounds__(256) k_finalize(const FinalizeArgs a) {
+    const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= a.n_slots) return;
+    const long long idx = a.out_index[slot];
+    if (idx < 0) return;
+    double s[kNumSums];
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) s[k] = 0.0;
+    for (int g = 0; g < a.n_groups; ++g) {
+        const double* p = a.partials + (size_t)g * kNumSums * a.n_slots + slot;
+#pragma unroll
+        for (int k = 0; k < kNumSums; ++k) s[k] += p[(size_t)k * a.n_slots];
+    }
+    const double n = s[0];
+    double r = __builtin_nan("");
+    if (n > 0.0) {
+        const double cov = s[5] - s[1] * s[2] / n;
+        const double va = s[3] - s[1] * s[1] / n;
+        const double vb = s[4] - s[2] * s[2] / n;
+        r = cov / sqrt(va * vb);
+    }
+    a.out[idx - a.lag_begin] = r;
+}
+
+}  // namespace coreg

@@ -1,0 +1,114 @@
+"""
+Seeded synthetic Solar-Orbiter-like scenes: one analytic "truth" field in the
+helioprojective plane (sum of Gaussian blobs + floor) rendered through an HRIEUV-like header (the image to
+align, with a known injected pointing error) and through an FSI-like header (the reference image).
+No FITS files, no network.  numpy only.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+AU = 1.495978707e11
+
+
+def _header(naxis1, naxis2, crpix1, crpix2, crval1, crval2, cdelt1, cdelt2, crota, unit="arcsec", dsun_au=0.38,
+            crln=250.0, crlt=-3.0, wavelnth=174, date="2022-03-17T09:50:45.277"):
+    rho = np.deg2rad(crota)
+    lam = cdelt2 / cdelt1
+    return {
+        "NAXIS": 2, "NAXIS1": int(naxis1), "NAXIS2": int(naxis2),
+        "CTYPE1": "HPLN-TAN", "CTYPE2": "HPLT-TAN", "CUNIT1": unit, "CUNIT2": unit,
+        "CRPIX1": float(crpix1), "CRPIX2": float(crpix2), "CRVAL1": float(crval1), "CRVAL2": float(crval2),
+        "CDELT1": float(cdelt1), "CDELT2": float(cdelt2),
+        "PC1_1": float(np.cos(rho)), "PC1_2": float(-lam * np.sin(rho)),
+        "PC2_1": float(np.sin(rho) / lam), "PC2_2": float(np.cos(rho)),
+        "CROTA": float(crota), "LONPOLE": 180.0,
+        "DSUN_OBS": float(dsun_au * AU), "CRLN_OBS": float(crln), "CRLT_OBS": float(crlt),
+        "WAVELNTH": int(wavelnth), "DATE-AVG": date, "DATE-OBS": date,
+    }
+
+
+def _pixel_to_plane(hdr):
+    """Pixel -> helioprojective plane coordinates (arcsec), small-angle linear form of the header."""
+    u = {"arcsec": 1.0, "deg": 3600.0}[hdr["CUNIT1"]]
+    y, x = np.mgrid[0:hdr["NAXIS2"], 0:hdr["NAXIS1"]].astype(np.float64)
+    q1 = x + 1.0 - hdr["CRPIX1"]
+    q2 = y + 1.0 - hdr["CRPIX2"]
+    tx = hdr["CRVAL1"] * u + hdr["CDELT1"] * u * (hdr["PC1_1"] * q1 + hdr["PC1_2"] * q2)
+    ty = hdr["CRVAL2"] * u + hdr["CDELT2"] * u * (hdr["PC2_1"] * q1 + hdr["PC2_2"] * q2)
+    return tx, ty
+
+
+def _plane_to_pixel(hdr, tx, ty):
+    u = {"arcsec": 1.0, "deg": 3600.0}[hdr["CUNIT1"]]
+    m = np.array([[hdr["CDELT1"] * u * hdr["PC1_1"], hdr["CDELT1"] * u * hdr["PC1_2"]],
+                  [hdr["CDELT2"] * u * hdr["PC2_1"], hdr["CDELT2"] * u * hdr["PC2_2"]]])
+    mi = np.linalg.inv(m)
+    dx, dy = tx - hdr["CRVAL1"] * u, ty - hdr["CRVAL2"] * u
+    return mi[0, 0] * dx + mi[0, 1] * dy + hdr["CRPIX1"] - 1.0, mi[1, 0] * dx + mi[1, 1] * dy + hdr["CRPIX2"] - 1.0
+
+
+def _render(hdr, blobs, floor, rng, noise=True):
+    """Sum of Gaussian blobs (centre tx, ty [arcsec], sigma [arcsec], amplitude) on the pixel grid of hdr."""
+    ny, nx = hdr["NAXIS2"], hdr["NAXIS1"]
+    img = np.full((ny, nx), float(floor))
+    u = {"arcsec": 1.0, "deg": 3600.0}[hdr["CUNIT1"]]
+    scale = min(abs(hdr["CDELT1"]), abs(hdr["CDELT2"])) * u  # arcsec / px
+    tx, ty = _pixel_to_plane(hdr)
+    cx, cy = _plane_to_pixel(hdr, blobs[:, 0], blobs[:, 1])
+    for k in range(blobs.shape[0]):
+        r = int(np.ceil(4.5 * blobs[k, 2] / scale)) + 1
+        x0, x1 = int(np.floor(cx[k])) - r, int(np.floor(cx[k])) + r + 1
+        y0, y1 = int(np.floor(cy[k])) - r, int(np.floor(cy[k])) + r + 1
+        x0, x1, y0, y1 = max(x0, 0), min(x1, nx), max(y0, 0), min(y1, ny)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        d2 = (tx[y0:y1, x0:x1] - blobs[k, 0]) ** 2 + (ty[y0:y1, x0:x1] - blobs[k, 1]) ** 2
+        img[y0:y1, x0:x1] += blobs[k, 3] * np.exp(-d2 / (2.0 * blobs[k, 2] ** 2))
+    if noise:
+        img = img + np.sqrt(img) * rng.standard_normal(img.shape)
+    return img
+
+
+def make_scene(small_n=2048, large_n=3072, seed=20220317, n_blobs=400, pointing_error=(17.0, -9.0, 0.3),
+               nan_frac=0.005, float32_exact=True, small_shape=None, small_cdelt=None, small_unit="arcsec"):
+    """Returns (data_small, hdr_small, data_large, hdr_large, truth).
+
+    The small image is rendered through the TRUE header (CRVAL = (-310, 420) arcsec, CROTA 3.3 deg for the
+    default error) and handed out with a WRONG header (CRVAL - (17, -9) arcsec, CROTA 3.0): the sweep should
+    recover lag ~ (+17, -9) arcsec, +0.3 deg.  `float32_exact` rounds pixel values to float32 first, as L2 FITS
+    data (BITPIX=-32) cast to float64 by the reference (alignment.py:301,314) are."""
+    rng = np.random.default_rng(seed)
+    fov = 2048 * 0.492  # arcsec
+    if small_shape is None:
+        small_shape = (small_n, small_n)
+    sny, snx = small_shape
+    if small_cdelt is None:
+        small_cdelt = (fov / snx, fov / sny)
+    lcd = 3072 * 4.44 / large_n
+    true_crval = (-310.0, 420.0)
+    true_crota = 3.0 + pointing_error[2]
+    u = {"arcsec": 1.0, "deg": 1.0 / 3600.0}[small_unit]
+    hdr_true = _header(snx, sny, (snx + 1) / 2.0, (sny + 1) / 2.0, true_crval[0] * u, true_crval[1] * u,
+                       small_cdelt[0] * u, small_cdelt[1] * u, true_crota, unit=small_unit)
+    hdr_small = _header(snx, sny, (snx + 1) / 2.0, (sny + 1) / 2.0, (true_crval[0] - pointing_error[0]) * u,
+                        (true_crval[1] - pointing_error[1]) * u, small_cdelt[0] * u, small_cdelt[1] * u, 3.0,
+                        unit=small_unit)
+    hdr_large = _header(large_n, large_n, (large_n + 1) / 2.0, (large_n + 1) / 2.0, 12.5, -7.25, lcd, lcd, 0.0,
+                        wavelnth=174, date="2022-03-17T09:50:45.281")
+    half = 0.5 * max(small_cdelt[0] * snx, small_cdelt[1] * sny) + 150.0
+    blobs = np.empty((n_blobs, 4))
+    blobs[:, 0] = true_crval[0] + rng.uniform(-half, half, n_blobs)
+    blobs[:, 1] = true_crval[1] + rng.uniform(-half, half, n_blobs)
+    blobs[:, 2] = rng.uniform(3.0, 40.0, n_blobs) * 0.492  # sigma 3..40 HRI pixels, in arcsec
+    blobs[:, 3] = np.exp(rng.uniform(np.log(50.0), np.log(3000.0), n_blobs))
+    small = _render(hdr_true, blobs, 100.0, rng)
+    large = _render(hdr_large, blobs, 100.0, rng)
+    if float32_exact:
+        small = small.astype(np.float32).astype(np.float64)
+        large = large.astype(np.float32).astype(np.float64)
+    if nan_frac > 0:
+        small[rng.random(small.shape) < nan_frac] = np.nan
+    truth = {"lag_crval1": pointing_error[0], "lag_crval2": pointing_error[1], "lag_crota": pointing_error[2],
+             "blobs": blobs}
+    return small, hdr_small, large, hdr_large, truth

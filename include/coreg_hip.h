@@ -1,0 +1,175 @@
+/*
+ * coreg_hip.h -- C ABI of libcoreg_hip.so: the MI355X (gfx950) implementation of the euispice_coreg
+ * `hdrshift.Alignment` correlation sweep (one lag-point = resample the small-FOV image through a shifted
+ * header onto the target grid + masked Pearson coefficient against the reference image on that grid).
+ *
+ * The reference (adolliou/euispice_coreg, pure Python) has no FFI; the seam this library replaces is
+ *     Alignment._find_best_header_parameters()            euispice_coreg/hdrshift/alignment.py:613-797
+ * i.e. everything below the public `align_using_helioprojective()` / `align_using_carrington()` calls.
+ * Each entry point cites the reference code it stands in for.  All pointers are plain host pointers owned by
+ * the caller unless a parameter says "device"; the library copies what it needs and never frees caller memory.
+ * Every function returns COREG_OK (0) or a negative COREG_E* code; coreg_last_error() gives the text.
+ * A handle is bound to one GPU and is not thread-safe; use one handle per thread / per process (one process
+ * per GPU is the intended multi-GPU model: shard the raveled lag range with lag_begin/lag_end).
+ */
+#ifndef COREG_HIP_H
+#define COREG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COREG_OK 0
+#define COREG_EINVAL (-1)   /* bad argument */
+#define COREG_EHIP (-2)     /* HIP runtime error */
+#define COREG_ESTATE (-3)   /* call order: image / reference not set */
+#define COREG_ENOTIMPL (-4) /* valid request the library does not implement */
+#define COREG_ENOMEM (-5)
+
+#define COREG_F32 0
+#define COREG_F64 1
+
+#define COREG_METHOD_CORRELATION 0 /* alignment.py:522-542 */
+#define COREG_METHOD_RESIDUS 1     /* alignment.py:544-547 (no NaN mask, quirk Q8) */
+
+/* CDELT lag semantics */
+#define COREG_CDELT_INTENDED 0  /* CDELTi += d, PC rebuilt with the new lambda (utils/Util.py:199-215) */
+#define COREG_CDELT_REFERENCE 1 /* alignment.py:420-440 as written: d_cdelt1 only forces the PC rebuild; a
+                                   non-zero d_cdelt2 kills the worker -> that lag-point is reported as NaN */
+
+typedef struct coreg_handle coreg_handle;
+
+/* The FITS keywords of one 2-D image header that the path reads (after alignment.py:580-611 has made sure
+ * PCi_j and CROTA exist).  Angles are in the header's own unit; unit_to_deg converts them to degrees
+ * (1/3600 for CUNIT='arcsec', 1 for 'deg') exactly as wcslib's unit fix does inside astropy.wcs.WCS. */
+typedef struct coreg_wcs2d {
+    int32_t naxis1, naxis2;
+    double crpix1, crpix2;
+    double crval1, crval2;
+    double cdelt1, cdelt2;
+    double pc1_1, pc1_2, pc2_1, pc2_2;
+    double crota;       /* degrees: hdr['CROTA'] (else 'CROTA2'); roll for the Carrington transform          */
+    double unit_to_deg; /* CUNIT1 == CUNIT2 scale                                                            */
+    double lonpole;     /* degrees; FITS default for TAN is 180                                              */
+    double dsun_obs;    /* metres          (Carrington only, utils/rectify.py:405)                           */
+    double crln_obs;    /* degrees         (Carrington only, utils/rectify.py:406)                           */
+    double crlt_obs;    /* degrees         (Carrington only, utils/rectify.py:407)                           */
+} coreg_wcs2d;
+
+/* The five lag axes of Alignment.__init__ (alignment.py:47-55), already in header units
+ * (alignment.py:819-837).  The sweep covers meshgrid(crval1, crval2, cdelt1, cdelt2, crota, indexing='ij')
+ * and results are indexed in that C order (alignment.py:667-674). */
+typedef struct coreg_lags {
+    const double* crval1; int32_t n_crval1;
+    const double* crval2; int32_t n_crval2;
+    const double* cdelt1; int32_t n_cdelt1;
+    const double* cdelt2; int32_t n_cdelt2;
+    const double* crota;  int32_t n_crota; /* degrees */
+} coreg_lags;
+
+/* Carrington target grid of utils/rectify.py:875-878: lon = linspace(lon0, lon1, n_lon, float32),
+ * lat = linspace(lat0, lat1, n_lat, float32); images on the grid are [n_lat][n_lon] row-major.
+ * lat_cos/lat_sin (optional, may be NULL): caller-supplied float32 cos/sin of radians(lat) -- NumPy evaluates
+ * these in float32 with a not-correctly-rounded SIMD routine (quirk Q6); a NumPy caller that passes its own
+ * tables reproduces the reference's latitude trig bit for bit.  NULL = correctly rounded float32. */
+typedef struct coreg_carr_grid {
+    double lon0, lon1; int32_t n_lon;
+    double lat0, lat1; int32_t n_lat;
+    const float* lat_cos; /* [n_lat] or NULL */
+    const float* lat_sin; /* [n_lat] or NULL */
+} coreg_carr_grid;
+
+typedef struct coreg_stats {
+    double sweep_kernel_ms;    /* sum of HIP-event durations of the sweep kernel launches of the last sweep   */
+    double precompute_ms;      /* grid-coordinate / compaction kernels of the last sweep                      */
+    double total_gpu_ms;       /* first launch -> last launch of the last sweep, on the handle's stream       */
+    int64_t n_lags;            /* lag-points computed by the last sweep (this handle's slice)                 */
+    int64_t n_grid_points;     /* G                                                                           */
+    int64_t n_active_points;   /* grid points that can overlap the small image for some lag (after culling)   */
+    int64_t n_sweep_launches;
+    int32_t small_is_f32;      /* 1 when the small image was stored as float32 (every value float32-exact)    */
+    int32_t used_lds;          /* 1 when the LDS-staged gather path ran                                       */
+} coreg_stats;
+
+const char* coreg_version(void);
+
+/* device < 0: current HIP device */
+int coreg_create(coreg_handle** h, int device);
+void coreg_destroy(coreg_handle* h);
+const char* coreg_last_error(const coreg_handle* h);
+
+/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) instead of the handle's own. */
+int coreg_set_stream(coreg_handle* h, void* hip_stream);
+int coreg_synchronize(coreg_handle* h);
+
+/* Image to align, float64 [ny][nx], NaN = masked (alignment.py:314, after :844-887 thresholds).
+ * Stored on the device as float32 when every finite value is exactly representable in float32 (true for
+ * BITPIX=-32 / integer FITS data cast to float64), else as float64: arithmetic is float64 either way. */
+int coreg_set_small(coreg_handle* h, const double* img, int32_t ny, int32_t nx);
+
+/* Reference image already resampled on the target grid (what alignment.py:646-651 leaves in data_large),
+ * [gy][gx], dtype COREG_F32 (helioprojective sub-map, alignment.py:995) or COREG_F64 (Carrington). */
+int coreg_set_reference_on_grid(coreg_handle* h, const void* ref, int dtype, int32_t gy, int32_t gx);
+
+/* Once-per-sweep reference preparation on the GPU.
+ * carrington:      alignment.py:646-648 -> :889-901  (large image -> Carrington grid, float64)
+ * helioprojective: alignment.py:649-651 -> :987-1000 (large image -> small header's pixel grid, float32) */
+int coreg_prepare_reference_carrington(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
+                                       const coreg_wcs2d* hdr_large, const coreg_carr_grid* grid, double solar_r,
+                                       int order);
+int coreg_prepare_reference_helioprojective(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
+                                            const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order);
+/* Copy the resident reference-on-grid back (tests / figures). out: [gy][gx] of `dtype` (must match). */
+int coreg_get_reference_on_grid(coreg_handle* h, void* out, int dtype);
+
+/* One resample of the small image through ONE header (= function_to_apply of one lag-point):
+ * carrington:      alignment.py:889-901   out float64 [n_lat][n_lon], NaN outside
+ * helioprojective: alignment.py:1018-1029 out float32 [hdr_target.naxis2][hdr_target.naxis1] */
+int coreg_resample_carrington(coreg_handle* h, const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r,
+                              int order, double* out);
+int coreg_resample_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr,
+                                   int order, float* out);
+
+/* The sweep: replaces the per-lag loop alignment.py:470-578 + :613-797 for one lag_solar_r value.
+ * hdr_small is the UNSHIFTED header of the image to align; its CRVAL/CDELT/CROTA are the *_ref values of
+ * alignment.py:799-814 and each lag-point applies _shift_header (alignment.py:401-468) to it.
+ * [lag_begin, lag_end) selects a contiguous slice of the C-order raveled lag index (np.array_split-style
+ * sharding, alignment.py:677-687); corr_out receives lag_end - lag_begin float64 values
+ * (host memory, or device memory when out_on_device != 0). */
+int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const coreg_carr_grid* grid,
+                           double solar_r, const coreg_lags* lags, int order, int method, int cdelt_semantics,
+                           int64_t lag_begin, int64_t lag_end, double* corr_out, int out_on_device);
+/* hdr_target: header whose pixel grid the reference image lives on (the unshifted small header in the
+ * parallelism=True path, alignment.py:1000; the large header in the serial path, quirk Q1). */
+int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_small,
+                                const coreg_lags* lags, int order, int method, int cdelt_semantics,
+                                int64_t lag_begin, int64_t lag_end, double* corr_out, int out_on_device);
+
+int coreg_last_stats(const coreg_handle* h, coreg_stats* out);
+
+/* Tuning / test knobs (name -> integer value). Known names:
+ *   "use_lds"      1 (default) stage the gather window in LDS, 0 gather from global memory
+ *   "tile_w"       0 (default, auto) or a power of two <= 1024: grid-tile width in points (tile = 1024 pts)
+ *   "n_groups"     0 (default, auto): tile groups (partial-sum slabs) per lag batch
+ *   "lds_bytes"    dynamic LDS per workgroup for the gather window (default 65536, max 159 KiB)
+ * Returns COREG_EINVAL for unknown names. */
+int coreg_set_option(coreg_handle* h, const char* name, int64_t value);
+
+/* Host-only helpers (no GPU work; usable where no device exists): the header arithmetic the sweep applies per
+ * lag-point, exported so that it can be checked against the reference's on CPU.
+ *   coreg_shift_header      alignment.py:401-468 (_shift_header); returns 1 when COREG_CDELT_REFERENCE would kill
+ *                           the worker (d_cdelt2 != 0), else 0
+ *   coreg_homography        0-based pixels of `from` -> 0-based pixels of `to` through the sky, row-major 3x3 with
+ *                           h[8] = 1: WCS(to).world_to_pixel(WCS(from).pixel_to_world(p)), alignment.py:1041-1065
+ *   coreg_carrington_origin X0, Y0 of utils/rectify.py:399-404 */
+int coreg_shift_header(const coreg_wcs2d* ref, double d_crval1, double d_crval2, double d_cdelt1, double d_cdelt2,
+                       double d_crota, int cdelt_semantics, coreg_wcs2d* out);
+int coreg_homography(const coreg_wcs2d* from, const coreg_wcs2d* to, double* h9);
+int coreg_carrington_origin(const coreg_wcs2d* hdr, double* x0, double* y0);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COREG_HIP_H */

@@ -1,0 +1,249 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(euispice_coreg_amd/_lib.py -> libcoreg_hip.so), against the CPU oracle on the same seeded inputs
+and against the committed golden vectors produced by the reference's own rectify.py.
+
+Tolerances (float64 arithmetic on both sides; stated per test):
+  * resampled images: |d| <= 1e-9 * max|image| (coordinate differences ~1e-12 px from libm vs ocml atan/sin)
+  * corr maps: 1e-10 when the latitude trig tables are NumPy's (bit-identical inputs), 1e-6 when the library
+    computes correctly-rounded float32 lat trig itself (SURVEY quirk Q6, fp32-trig ambiguity); identical argmax.
+"""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from tests.conftest import rectify_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _lags(n1=5, n2=5, step=2.0, c1=17.0, c2=-9.0, cdelt1=None, cdelt2=None, crota=None):
+    return (c1 + step * (np.arange(n1) - n1 // 2), c2 + step * (np.arange(n2) - n2 // 2), cdelt1, cdelt2, crota)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["A", "B", "C", "D", "E"])
+def test_resample_carrington_matches_reference_golden(gpu_handle, rectify_golden, case):
+    """coreg_resample_carrington == reference rectify.Rectifier(CarringtonTransform) output (golden vectors)."""
+    from euispice_coreg_amd import _lib
+    c = rectify_case(rectify_golden, case)
+    gpu_handle.set_small(c["image"])
+    grid = _lib.Grid(c["lonlims"], c["latlims"], c["shape"], numpy_lat_trig=True)
+    out = gpu_handle.resample_carrington(c["hdr"], grid, c["solar_r"], order=c["order"])
+    want = c["resampled"]
+    assert out.shape == want.shape
+    # points whose coordinate sits within 1e-9 px of the bounds rule may legitimately flip
+    W, Hh = c["image"].shape[1], c["image"].shape[0]
+    with np.errstate(invalid="ignore"):
+        edge = (np.abs(c["nx"]) < 1e-9) | (np.abs(c["nx"] - (W - 1)) < 1e-9) | (np.abs(c["ny"]) < 1e-9) | \
+               (np.abs(c["ny"] - (Hh - 1)) < 1e-9)
+    same_nan = np.isnan(out) == np.isnan(want)
+    assert (same_nan | edge).all()
+    m = np.isfinite(out) & np.isfinite(want)
+    assert m.sum() > 100
+    assert np.abs(out[m] - want[m]).max() <= 1e-9 * np.nanmax(np.abs(c["image"]))
+
+
+def test_resample_carrington_library_lat_trig_close(gpu_handle, rectify_golden):
+    """With the library's own (correctly rounded) float32 latitude trig the result moves by the fp32-trig
+    ambiguity only (quirk Q6): coordinates <= ~1e-3 px -> samples within 1e-3 of the image range."""
+    from euispice_coreg_amd import _lib
+    c = rectify_case(rectify_golden, "A")
+    gpu_handle.set_small(c["image"])
+    grid = _lib.Grid(c["lonlims"], c["latlims"], c["shape"], numpy_lat_trig=False)
+    out = gpu_handle.resample_carrington(c["hdr"], grid, c["solar_r"], order=c["order"])
+    m = np.isfinite(out) & np.isfinite(c["resampled"])
+    assert m.sum() > 0.95 * np.isfinite(c["resampled"]).sum()
+    assert np.abs(out[m] - c["resampled"][m]).max() <= 1e-3 * np.nanmax(np.abs(c["image"]))
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_resample_helioprojective_vs_oracle(gpu_handle, order):
+    small, hs, large, hl, _ = H.scene(small_n=80, large_n=128)
+    from oracle import coreg_oracle as O
+    st = H.oracle_state(small, hs, large, hl, _lags(), order=order)
+    O.set_initial_header_values(st)
+    sub = O.create_submap_of_large_data(st)  # hdr_large := hdr_small
+    hdr_shift = dict(st.hdr_small)
+    O.shift_header(st, hdr_shift, 21.0, -5.0, 0.0, 0.0, 0.4)
+    want = O.interpolate_on_large_data_grid(st, st.data_small, hdr_shift)
+    gpu_handle.set_small(small)
+    got = gpu_handle.resample_helioprojective(st.hdr_small, hdr_shift, order=order)
+    assert got.dtype == np.float32 and got.shape == want.shape
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    m = np.isfinite(want)
+    assert m.sum() > 1000
+    # float32 outputs: equal up to one float32 ulp where the float64 value sits on a rounding boundary
+    assert np.abs(got[m].astype(np.float64) - want[m]).max() <= 2e-7 * np.abs(want[m]).max()
+    # the once-only reference preparation
+    gpu_handle.prepare_reference_helioprojective(large, hl, hs, order)
+    ref = gpu_handle.get_reference_on_grid(sub.shape, np.float32)
+    assert np.array_equal(np.isnan(ref), np.isnan(sub))
+    m = np.isfinite(sub)
+    assert np.abs(ref[m].astype(np.float64) - sub[m]).max() <= 2e-7 * np.abs(sub[m]).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("use_lds", [0, 1])
+def test_sweep_carrington_vs_oracle(gpu_handle, order, use_lds):
+    small, hs, large, hl, _ = H.scene()
+    lags = _lags(7, 6)
+    shape = (72, 64)
+    want = H.oracle_carrington(small, hs, large, hl, lags, shape, order=order)
+    gpu_handle.set_option("use_lds", use_lds)
+    try:
+        got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, shape, order=order)
+    finally:
+        gpu_handle.set_option("use_lds", 1)
+    H.assert_corr_close(got, want, 1e-10, f"carrington order={order} lds={use_lds}")
+    st = gpu_handle.last_stats()
+    assert st["n_lags"] == 42 and st["used_lds"] == use_lds
+    # reference on the grid itself
+    from oracle import coreg_oracle as O
+    a = O.carrington_transform_fa(np.asarray(large, float), hl, 1.004, list(shape), list(H.CARR_LON), list(H.CARR_LAT),
+                                  order)
+    ref = gpu_handle.get_reference_on_grid(a.shape, np.float64)
+    m = np.isfinite(a) & np.isfinite(ref)
+    assert m.sum() > 0.98 * np.isfinite(a).sum()
+    assert np.abs(ref[m] - a[m]).max() <= 1e-9 * np.nanmax(a)
+
+
+def test_sweep_carrington_library_lat_trig(gpu_handle):
+    """Library-computed latitude trig: corr within the stated 1e-6 and same argmax (quirk Q6)."""
+    small, hs, large, hl, _ = H.scene()
+    lags = _lags(7, 7)
+    shape = (72, 64)
+    want = H.oracle_carrington(small, hs, large, hl, lags, shape)
+    got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, shape, numpy_lat_trig=False)
+    H.assert_corr_close(got, want, 1e-6, "carrington, library lat trig")
+
+
+def test_sweep_carrington_5d_lags(gpu_handle):
+    """CROTA and CDELT lags (intended CDELT semantics, quirk Q2) on the Carrington path."""
+    small, hs, large, hl, _ = H.scene()
+    lags = _lags(4, 3, cdelt1=[-0.05, 0.0, 0.05], cdelt2=[0.0, 0.04], crota=[-0.5, 0.0, 0.3])
+    shape = (64, 56)
+    want = H.oracle_carrington(small, hs, large, hl, lags, shape)
+    got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, shape)
+    assert got.shape == (4, 3, 3, 2, 3, 1)
+    H.assert_corr_close(got, want, 1e-10, "carrington 5-D")
+
+
+def test_sweep_carrington_float64_small_image(gpu_handle):
+    """Pixel values that are not float32-exact take the float64 storage path."""
+    small, hs, large, hl, _ = H.scene(float32_exact=False)
+    lags = _lags(5, 5)
+    shape = (64, 64)
+    want = H.oracle_carrington(small, hs, large, hl, lags, shape)
+    got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, shape)
+    assert gpu_handle.last_stats()["small_is_f32"] == 0
+    H.assert_corr_close(got, want, 1e-10, "carrington f64 storage")
+
+
+def test_sweep_carrington_slices_tiles_groups(gpu_handle):
+    """np.array_split-style lag slices concatenate to the full map; tile shape / group count / LDS size do not
+    change results beyond summation-order rounding."""
+    small, hs, large, hl, _ = H.scene()
+    lags = _lags(9, 7, crota=[0.0, 0.25])
+    shape = (80, 72)
+    full = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, shape)
+    n = full.size
+    parts = []
+    for lo, hi in [(0, 17), (17, 18), (18, 18), (18, 95), (95, n)]:
+        parts.append(H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, shape, lag_begin=lo, lag_end=hi,
+                                      prepare=False))
+    assert np.array_equal(np.concatenate(parts), full.ravel(), equal_nan=True)
+    for opt, val in [("tile_w", 8), ("tile_w", 128), ("n_groups", 8), ("n_groups", 64), ("lds_bytes", 4096),
+                     ("lds_bytes", 159 * 1024)]:
+        gpu_handle.set_option(opt, val)
+        try:
+            alt = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, shape, prepare=False)
+        finally:
+            gpu_handle.set_option("tile_w", 0)
+            gpu_handle.set_option("n_groups", 0)
+            gpu_handle.set_option("lds_bytes", 65536)
+        assert np.nanmax(np.abs(alt - full)) <= 1e-12, (opt, val)
+
+
+def test_sweep_no_overlap_is_nan(gpu_handle):
+    """A lag that moves the small image completely off the grid -> empty mask -> NaN (the reference's numba
+    routine divides by zero there, SURVEY a-15)."""
+    small, hs, large, hl, _ = H.scene()
+    lags = (np.array([17.0, 40000.0]), np.array([-9.0]), None, None, None)
+    got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, (64, 64))
+    assert np.isfinite(got[0, 0, 0, 0, 0, 0]) and np.isnan(got[1, 0, 0, 0, 0, 0])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("use_lds", [0, 1])
+def test_sweep_helioprojective_vs_oracle(gpu_handle, order, use_lds):
+    small, hs, large, hl, _ = H.scene(small_n=80, large_n=128)
+    lags = _lags(6, 5, crota=[0.0, 0.3])
+    want = H.oracle_helio(small, hs, large, hl, lags, order=order)
+    gpu_handle.set_option("use_lds", use_lds)
+    try:
+        got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order)
+    finally:
+        gpu_handle.set_option("use_lds", 1)
+    # float32-rounded samples on both sides: a handful of samples may round differently (1 float32 ulp)
+    H.assert_corr_close(got, want, 1e-7, f"helio order={order} lds={use_lds}")
+
+
+def test_sweep_helioprojective_serial_semantics(gpu_handle):
+    """parallelism=False path of the reference (quirk Q1): target = FULL large-FOV grid, float64 reference."""
+    small, hs, large, hl, _ = H.scene(small_n=64, large_n=96)
+    lags = _lags(5, 5)
+    want = H.oracle_helio(small, hs, large, hl, lags, parallelism=False)
+    got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, serial_semantics=True)
+    H.assert_corr_close(got, want, 1e-7, "helio serial semantics")
+    st = gpu_handle.last_stats()
+    assert st["n_active_points"] < st["n_grid_points"]  # most of the large grid never sees the small image
+
+
+def test_sweep_helioprojective_spice_like_degrees(gpu_handle):
+    """SPICE-like raster: header in degrees, CDELT1 != CDELT2, lags given in arcsec and converted
+    (alignment.py:819-837), CROTA lags (config 4 shape, reduced)."""
+    small, hs, large, hl, _ = H.scene(small_shape=(104, 48), small_cdelt=(4.0 * 5, 1.098 * 9), small_unit="deg",
+                                      large_n=128)
+    lags_arcsec = _lags(5, 5, step=8.0, crota=[-0.4, 0.0, 0.4])
+    want = H.oracle_helio(small, hs, large, hl, lags_arcsec, unit_lag="arcsec")
+    lags_deg = (lags_arcsec[0] / 3600.0, lags_arcsec[1] / 3600.0, None, None, lags_arcsec[4])
+    got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags_deg)
+    H.assert_corr_close(got, want, 1e-7, "helio SPICE-like")
+
+
+def test_sweep_helioprojective_cdelt_semantics(gpu_handle):
+    """CDELT lags: intended semantics match the oracle; reference semantics: d_cdelt2 != 0 -> NaN (dead worker),
+    d_cdelt1 != 0 only forces the PC rebuild (quirk Q2/Q3)."""
+    small, hs, large, hl, _ = H.scene(small_n=64, large_n=96)
+    lags = _lags(3, 3, cdelt1=[0.0, 0.05], cdelt2=[0.0, -0.04])
+    want = H.oracle_helio(small, hs, large, hl, lags)
+    got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags)
+    H.assert_corr_close(got, want, 1e-7, "helio cdelt intended")
+    got_ref = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, cdelt_semantics=1)
+    assert np.isnan(got_ref[:, :, :, 1]).all() and np.isfinite(got_ref[:, :, :, 0]).all()
+    lags1 = _lags(3, 3, cdelt1=[0.0, 0.05])
+    want1 = H.oracle_helio(small, hs, large, hl, lags1, cdelt_semantics="reference")
+    got1 = H.gpu_helio(gpu_handle, small, hs, large, hl, lags1, cdelt_semantics=1)
+    H.assert_corr_close(got1, want1, 1e-7, "helio cdelt1 reference semantics")
+
+
+def test_errors_are_loud(gpu_handle):
+    from euispice_coreg_amd import _lib
+    small, hs, large, hl, _ = H.scene(small_n=48, large_n=64)
+    h2 = _lib.CoregHandle(0)
+    try:
+        with pytest.raises(_lib.CoregError):  # nothing uploaded yet
+            h2.sweep_helioprojective(hs, hs, _lib.LagSet([0.0], [0.0], None, None, None))
+        h2.set_small(small)
+        h2.prepare_reference_helioprojective(large, hl, hs, 2)
+        with pytest.raises(_lib.CoregError):  # unsupported spline order
+            h2.sweep_helioprojective(hs, hs, _lib.LagSet([0.0], [0.0], None, None, None), order=3)
+        with pytest.raises(_lib.CoregError):  # residus is not implemented on the GPU: refuse, never fall back
+            h2.sweep_helioprojective(hs, hs, _lib.LagSet([0.0], [0.0], None, None, None), method=1)
+        with pytest.raises(_lib.CoregError):
+            h2.set_option("no_such_option", 1)
+    finally:
+        h2.close()
