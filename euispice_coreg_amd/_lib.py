@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcoreg_hip.so")
+LIB_PATH = os.environ.get("COREG_HIP_LIB", os.path.join(_HERE, "libcoreg_hip.so"))  # env override: kernel experiments
 
 COREG_OK = 0
 COREG_EINVAL, COREG_EHIP, COREG_ESTATE, COREG_ENOTIMPL, COREG_ENOMEM = -1, -2, -3, -4, -5

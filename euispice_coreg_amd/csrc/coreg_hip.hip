@@ -74,12 +74,12 @@ struct coreg_handle {
     // geometry tables
     DevBuf t_sin_lon, t_cos_lon, t_cos_lat, t_sin_lat;
     // precompute outputs
-    DevBuf base0, base1, aval, tile_count, tile_list, tile_info, tile_bbox;
+    DevBuf pts, tile_count, tile_list, tile_info, tile_bbox;
     // sweep
     DevBuf lane_params, out_index, partials, out_dev, tmp_img;
 
     // options
-    int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = 64 * 1024;
+    int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_skew = 0;
 
     coreg_stats stats;
     std::vector<EventPair> ev_sweep, ev_pre;
@@ -263,10 +263,11 @@ int check_lags(coreg_handle* h, const coreg_lags* l, LagDims* d, int64_t begin, 
 }
 
 // super-patch (sw x sh <= 256 CRVAL1 x CRVAL2 lags per workgroup) minimising padded lane slots
-void choose_patch(int n1, int n2, int* sw_out, int* sh_out) {
+// sw_max: widest patch (in CRVAL1 lags) whose lanes still fall on distinct LDS banks (see k_sweep)
+void choose_patch(int n1, int n2, int sw_max, int* sw_out, int* sh_out) {
     long long best = std::numeric_limits<long long>::max();
     int bw = 1, bh = 1;
-    for (int sw = 1; sw <= std::min(n1, kBlock); ++sw) {
+    for (int sw = 1; sw <= std::min(std::min(n1, kBlock), std::max(sw_max, 1)); ++sw) {
         int sh = std::min(n2, kBlock / sw);
         if (sh < 1) break;
         const long long batches = (long long)((n1 + sw - 1) / sw) * ((n2 + sh - 1) / sh);
@@ -292,7 +293,7 @@ struct SlotList {
 };
 
 // slots for combo c (= (i3*n4 + i4)*n5 + i5) restricted to the raveled slice [begin, end)
-void build_slots(const LagDims& d, long long c, long long begin, long long end, SlotList* s) {
+void build_slots(const LagDims& d, long long c, long long begin, long long end, int sw_max, SlotList* s) {
     s->i1.clear();
     s->i2.clear();
     s->outidx.clear();
@@ -302,7 +303,7 @@ void build_slots(const LagDims& d, long long c, long long begin, long long end, 
     const int i1_hi = (int)((end - 1) / row);
     const int m1 = i1_hi - i1_lo + 1;
     int sw, sh;
-    choose_patch(m1, d.n2, &sw, &sh);
+    choose_patch(m1, d.n2, sw_max, &sw, &sh);
     for (int p1 = 0; p1 * sw < m1; ++p1)
         for (int p2 = 0; p2 * sh < d.n2; ++p2) {
             bool any = false;
@@ -362,9 +363,7 @@ int launch_precompute(coreg_handle* h, const PrecomputeArgs& a, int n_tiles) {
 
 int reserve_tiles(coreg_handle* h, int n_tiles) {
     const size_t pts = (size_t)n_tiles * kTilePts;
-    HIPCHK(h->base0.reserve(pts * sizeof(double)));
-    HIPCHK(h->base1.reserve(pts * sizeof(double)));
-    HIPCHK(h->aval.reserve(pts * sizeof(double)));
+    HIPCHK(h->pts.reserve(pts * sizeof(Pt)));
     HIPCHK(h->tile_count.reserve(n_tiles * sizeof(int)));
     HIPCHK(h->tile_list.reserve(n_tiles * sizeof(int)));
     HIPCHK(h->tile_info.reserve(2 * sizeof(long long)));
@@ -381,16 +380,14 @@ void fill_precompute_common(coreg_handle* h, PrecomputeArgs* a, int tile_w) {
     a->tiles_x = (h->gW + a->tile_w - 1) / a->tile_w;
     a->tiles_y = (h->gH + a->tile_h - 1) / a->tile_h;
     a->pivot_a = h->pivots.as<double>();
-    a->base0 = h->base0.as<double>();
-    a->base1 = h->base1.as<double>();
-    a->aval = h->aval.as<double>();
+    a->pts = h->pts.as<Pt>();
     a->tile_count = h->tile_count.as<int>();
     a->tile_bbox = h->tile_bbox.as<double>();
 }
 
 // one sweep-kernel launch + finalize over the slots in `params` (SoA [np][n_slots])
 int launch_sweep(coreg_handle* h, int mode, int order, int np, const std::vector<double>& params,
-                 const std::vector<long long>& outidx, int n_batches, int n_tiles, int round_f32,
+                 const std::vector<long long>& outidx, int n_batches, int n_tiles, int skew_rows,
                  long long lag_begin, double* out_dev) {
     const long long n_slots = (long long)n_batches * kBlock;
     const int n_groups = pick_groups(h, n_batches, n_tiles);
@@ -408,9 +405,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int np, const std::vector
     a.img = h->small.p;
     a.W = h->sW;
     a.H = h->sH;
-    a.base0 = h->base0.as<double>();
-    a.base1 = h->base1.as<double>();
-    a.aval = h->aval.as<double>();
+    a.pts = h->pts.as<Pt>();
     a.tile_count = h->tile_count.as<int>();
     a.tile_list = h->tile_list.as<int>();
     a.tile_info = h->tile_info.as<long long>();
@@ -421,36 +416,38 @@ int launch_sweep(coreg_handle* h, int mode, int order, int np, const std::vector
     a.n_groups = n_groups;
     a.partials = h->partials.as<double>();
     a.pivots = h->pivots.as<double>();
-    a.round_f32 = round_f32;
     a.use_lds = h->opt_use_lds ? 1 : 0;
-    const size_t esz = h->small_f32 ? sizeof(float) : sizeof(double);
-    const size_t lds_bytes = a.use_lds ? (size_t)h->opt_lds_bytes : 0;
-    a.lds_elems = (int)(lds_bytes / esz);
+    // the dynamic LDS also carries the end-of-kernel point-group reduction: (kPointGroups-1) x 6 x 256 doubles
+    const size_t lds_min = (size_t)(kPointGroups - 1) * kNumSums * kBlock * sizeof(double);
+    const size_t lds_bytes = std::max(lds_min, a.use_lds ? (size_t)h->opt_lds_bytes : 0);
+    a.lds_elems = (int)(lds_bytes / sizeof(double));
+    (void)skew_rows;
     (void)np;
 
-    const dim3 grid((unsigned)((long long)n_groups * n_batches)), block(kBlock);
+    const dim3 grid((unsigned)((long long)n_groups * n_batches)), block(kSweepThreads);
     EventPair* ev = next_event(h, h->ev_sweep, h->ev_sweep_used);
     if (!ev) return fail(h, COREG_EHIP, "hipEventCreate failed");
-#define SW(M, O, TS)                                                                                              \
-    do {                                                                                                          \
-        if (lds_bytes > 48 * 1024)                                                                                \
-            HIPCHK(hipFuncSetAttribute((const void*)(k_sweep<M, O, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)lds_bytes));                                                          \
-        HIPCHK(hipEventRecord(ev->a, h->stream));                                                                 \
-        hipLaunchKernelGGL((k_sweep<M, O, TS>), grid, block, lds_bytes, h->stream, a);                            \
-        HIPCHK(hipEventRecord(ev->b, h->stream));                                                                 \
+#define SW(M, O, TS, R)                                                                                             \
+    do {                                                                                                              \
+        if (lds_bytes > 48 * 1024)                                                                                    \
+            HIPCHK(hipFuncSetAttribute((const void*)(k_sweep<M, O, TS, R>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds_bytes));                                                              \
+        HIPCHK(hipEventRecord(ev->a, h->stream));                                                                     \
+        hipLaunchKernelGGL((k_sweep<M, O, TS, R>), grid, block, lds_bytes, h->stream, a);                             \
+        HIPCHK(hipEventRecord(ev->b, h->stream));                                                                     \
     } while (0)
-#define SW_T(M, O)                         \
-    do {                                   \
-        if (h->small_f32) SW(M, O, float); \
-        else SW(M, O, double);             \
+#define SW_T(M, O, R)                         \
+    do {                                      \
+        if (h->small_f32) SW(M, O, float, R); \
+        else SW(M, O, double, R);             \
     } while (0)
+    // TRANSLATE = Carrington (float64 samples); HOMOGRAPHY = helioprojective (samples rounded to float32)
     if (mode == MODE_TRANSLATE) {
-        if (order == 2) SW_T(MODE_TRANSLATE, 2);
-        else SW_T(MODE_TRANSLATE, 1);
+        if (order == 2) SW_T(MODE_TRANSLATE, 2, false);
+        else SW_T(MODE_TRANSLATE, 1, false);
     } else {
-        if (order == 2) SW_T(MODE_HOMOGRAPHY, 2);
-        else SW_T(MODE_HOMOGRAPHY, 1);
+        if (order == 2) SW_T(MODE_HOMOGRAPHY, 2, true);
+        else SW_T(MODE_HOMOGRAPHY, 1, true);
     }
 #undef SW_T
 #undef SW
@@ -465,7 +462,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int np, const std::vector
     f.out_index = h->out_index.as<long long>();
     f.lag_begin = lag_begin;
     f.out = out_dev;
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, h->stream, f);
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_slots + 63) / 64)), dim3(256), 0, h->stream, f);
     HIPCHK(hipGetLastError());
     return COREG_OK;
 }
@@ -516,6 +513,21 @@ int end_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_dev
     HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
     h->stats.total_gpu_ms = ms;
     return COREG_OK;
+}
+
+// LDS bank geometry of the float64 window: 64 four-byte banks = 32 elements per bank cycle.  Lanes of one lag row
+// step by step1_px elements -> at most 32/step1_px lanes per row stay conflict-free; rows step by step2_px image rows.
+int patch_w_max(coreg_handle* h, double step1_px) {
+    if (h->opt_patch_w > 0) return (int)h->opt_patch_w;
+    if (!(step1_px > 0.0)) return kBlock;
+    return std::max(4, std::min(kBlock, (int)std::floor(31.0 / step1_px) + 1));
+}
+// row skew shift: rows advance by ~step2_px per CRVAL2 lag; shift = log2 of that (power of two), -1 = no skew
+int skew_sh_for(coreg_handle* h, double step2_px) {
+    if (h->opt_skew == 0) return -1;
+    if (!(step2_px >= 1.5)) return 0;
+    int sh = (int)std::lround(std::log2(step2_px));
+    return std::max(0, std::min(5, sh));
 }
 
 int pick_tile_w(coreg_handle* h, double dx_di, double dx_dj, double dy_di, double dy_dj, double span_x,
@@ -580,7 +592,7 @@ void coreg_destroy(coreg_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->small, &h->ref, &h->pivots, &h->red_sum, &h->red_cnt, &h->t_sin_lon, &h->t_cos_lon,
-                      &h->t_cos_lat, &h->t_sin_lat, &h->base0, &h->base1, &h->aval, &h->tile_count, &h->tile_list,
+                      &h->t_cos_lat, &h->t_sin_lat, &h->pts, &h->tile_count, &h->tile_list,
                       &h->tile_info, &h->tile_bbox, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
                       &h->tmp_img};
     for (DevBuf* b : bufs) b->release();
@@ -629,6 +641,11 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
     } else if (n == "n_groups") {
         if (value < 0) return fail(h, COREG_EINVAL, "n_groups must be >= 0");
         h->opt_n_groups = value;
+    } else if (n == "skew") {
+        h->opt_skew = value ? 1 : 0;
+    } else if (n == "patch_w") {
+        if (value < 0 || value > kBlock) return fail(h, COREG_EINVAL, "patch_w must be in [0, 256]");
+        h->opt_patch_w = value;
     } else if (n == "lds_bytes") {
         // 160 KiB per CU minus the kernel's static LDS
         if (value < 1024 || value > 159 * 1024) return fail(h, COREG_EINVAL, "lds_bytes must be in [1 KiB, 159 KiB]");
@@ -821,6 +838,10 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
     CarrTables tabs;
     carr_tables(*grid, hdr_small->crln_obs, tabs);
 
+    const double step1_px = d.n1 > 1 ? std::fabs(lags->crval1[1] - lags->crval1[0]) / std::fabs(hdr_small->cdelt1) : 0;
+    const double step2_px = d.n2 > 1 ? std::fabs(lags->crval2[1] - lags->crval2[0]) / std::fabs(hdr_small->cdelt2) : 0;
+    const int sw_max = patch_w_max(h, step1_px);
+    const int skew_rows = skew_sh_for(h, step2_px);
     // tile shape: local scale of the grid -> pixel map near the grid centre (heuristic only)
     int tile_w = 32;
     {
@@ -830,9 +851,7 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
         carr_term_host(tabs, c0, ic, jc, &a0, &a1);
         carr_term_host(tabs, c0, std::min(ic + 1, grid->n_lon - 1), jc, &b0, &b1);
         carr_term_host(tabs, c0, ic, std::min(jc + 1, grid->n_lat - 1), &c0x, &c0y);
-        const double step1 = d.n1 > 1 ? std::fabs(lags->crval1[1] - lags->crval1[0]) / std::fabs(hdr_small->cdelt1) : 0;
-        const double step2 = d.n2 > 1 ? std::fabs(lags->crval2[1] - lags->crval2[0]) / std::fabs(hdr_small->cdelt2) : 0;
-        tile_w = pick_tile_w(h, b0 - a0, c0x - a0, b1 - a1, c0y - a1, 16 * step1, 16 * step2);
+        tile_w = pick_tile_w(h, b0 - a0, c0x - a0, b1 - a1, c0y - a1, 16 * step1_px, 16 * step2_px);
     }
     PrecomputeArgs pa;
     std::memset(&pa, 0, sizeof(pa));
@@ -859,7 +878,7 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
         if (shift_header(*hdr_small, 0.0, 0.0, lags->cdelt1[i3], lags->cdelt2[i4], lags->crota[i5], cdelt_semantics,
                          &hc))
             continue;  // reference semantics: this lag kills the worker -> NaN (already filled)
-        build_slots(d, c, lag_begin, lag_end, &slots);
+        build_slots(d, c, lag_begin, lag_end, sw_max, &slots);
         if (slots.n_batches == 0) continue;
         const size_t ns = slots.i1.size();
         params.assign(2 * ns, 0.0);
@@ -885,8 +904,8 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
         pa.f1lo = -y0max;
         pa.f1hi = (double)(h->sH - 1) - y0min;
         RETCHK(launch_precompute<MODE_TRANSLATE>(h, pa, n_tiles));
-        RETCHK(launch_sweep(h, MODE_TRANSLATE, order, 2, params, slots.outidx, slots.n_batches, n_tiles, 0, lag_begin,
-                            out_dev));
+        RETCHK(launch_sweep(h, MODE_TRANSLATE, order, 2, params, slots.outidx, slots.n_batches, n_tiles, skew_rows,
+                            lag_begin, out_dev));
     }
     (void)row;
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
@@ -910,6 +929,10 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     RETCHK(begin_sweep(h, n_out, corr_out, out_on_device, &out_dev));
     if (n_out == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 
+    const double step1_px = d.n1 > 1 ? std::fabs(lags->crval1[1] - lags->crval1[0]) / std::fabs(hdr_small->cdelt1) : 0;
+    const double step2_px = d.n2 > 1 ? std::fabs(lags->crval2[1] - lags->crval2[0]) / std::fabs(hdr_small->cdelt2) : 0;
+    const int sw_max = patch_w_max(h, step1_px);
+    const int skew_rows = skew_sh_for(h, step2_px);
     // all slots of all combos -> one launch
     SlotList slots, all;
     std::vector<double> hs;  // AoS while building
@@ -924,7 +947,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     for (long long c = 0; c < d.nc; ++c) {
         const long long first = (lag_begin - c + d.nc - 1) / d.nc;
         if (first * d.nc + c >= lag_end || combo_dead[c]) continue;
-        build_slots(d, c, lag_begin, lag_end, &slots);
+        build_slots(d, c, lag_begin, lag_end, sw_max, &slots);
         for (size_t s = 0; s < slots.i1.size(); ++s) {
             coreg_wcs2d hl = combo_hdr[c];
             hl.crval1 = hdr_small->crval1 + lags->crval1[slots.i1[s]];
@@ -963,9 +986,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
         apply_h(m, u, v, &ax, &ay);
         apply_h(m, u + 1, v, &bx, &by);
         apply_h(m, u, v + 1, &cx, &cy);
-        const double step1 = d.n1 > 1 ? std::fabs(lags->crval1[1] - lags->crval1[0]) / std::fabs(hdr_small->cdelt1) : 0;
-        const double step2 = d.n2 > 1 ? std::fabs(lags->crval2[1] - lags->crval2[0]) / std::fabs(hdr_small->cdelt2) : 0;
-        tile_w = pick_tile_w(h, bx - ax, cx - ax, by - ay, cy - ay, 16 * step1, 16 * step2);
+        tile_w = pick_tile_w(h, bx - ax, cx - ax, by - ay, cy - ay, 16 * step1_px, 16 * step2_px);
     }
     PrecomputeArgs pa;
     std::memset(&pa, 0, sizeof(pa));
@@ -982,8 +1003,8 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     pa.f1lo = std::floor(fy0) - 2.0;
     pa.f1hi = std::ceil(fy1) + 2.0;
     RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles));
-    RETCHK(launch_sweep(h, MODE_HOMOGRAPHY, order, 9, params, all.outidx, all.n_batches, n_tiles,
-                        /*round_f32=*/1, lag_begin, out_dev));
+    RETCHK(launch_sweep(h, MODE_HOMOGRAPHY, order, 9, params, all.outidx, all.n_batches, n_tiles, skew_rows,
+                        lag_begin, out_dev));
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }
 

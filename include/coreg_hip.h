@@ -153,7 +153,9 @@ int coreg_last_stats(const coreg_handle* h, coreg_stats* out);
  *   "use_lds"      1 (default) stage the gather window in LDS, 0 gather from global memory
  *   "tile_w"       0 (default, auto) or a power of two <= 1024: grid-tile width in points (tile = 1024 pts)
  *   "n_groups"     0 (default, auto): tile groups (partial-sum slabs) per lag batch
- *   "lds_bytes"    dynamic LDS per workgroup for the gather window (default 65536, max 159 KiB)
+ *   "lds_bytes"    dynamic LDS per workgroup for the float64 gather window (default and max 159 KiB)
+ *   "skew"         1 shift LDS window rows to spread the lag lattice over banks, 0 (default) off
+ *   "patch_w"      0 (default, auto from the LDS bank geometry) or the width, in CRVAL1 lags, of a lag patch
  * Returns COREG_EINVAL for unknown names. */
 int coreg_set_option(coreg_handle* h, const char* name, int64_t value);
 

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Tuning harness: headline sweep (bench.py workload) under different library options; prints sweep-kernel ms.
+usage: python profiles/tune.py "opt=val,opt=val" "opt=val" ...   (each argument = one configuration)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from euispice_coreg_amd import _lib, synthetic  # noqa: E402
+
+
+def main():
+    small, hs, large, hl, truth = synthetic.make_scene()
+    n = int(os.environ.get("TUNE_NLAG", "60"))
+    lag = np.arange(-n // 2, n - n // 2, 1, dtype=np.float64)
+    lags = _lib.LagSet(lag, lag, None, None, None)
+    shape = (int(os.environ.get("TUNE_GRID", "2048")),) * 2
+    lon = tuple(float(x) for x in os.environ.get("TUNE_LON", "200,300").split(","))
+    lat = tuple(float(x) for x in os.environ.get("TUNE_LAT", "-20,20").split(","))
+    grid = _lib.Grid(lon, lat, shape)
+    h = _lib.CoregHandle(0)
+    h.set_small(small)
+    h.prepare_reference_carrington(large, hl, grid, 1.004, 2)
+    base = None
+    for cfg in (sys.argv[1:] or [""]):
+        defaults = {"use_lds": 1, "tile_w": 0, "n_groups": 0, "lds_bytes": int(os.environ.get("TUNE_LDS", 159 * 1024)), "patch_w": 0, "skew": 0}
+        for kv in filter(None, cfg.split(",")):
+            k, v = kv.split("=")
+            defaults[k] = int(v)
+        for k, v in defaults.items():
+            h.set_option(k, v)
+        ms = []
+        for it in range(6):
+            t0 = time.perf_counter()
+            out = h.sweep_carrington(hs, grid, 1.004, lags)
+            wall = time.perf_counter() - t0
+            st = h.last_stats()
+            if it >= 1:
+                ms.append((st["sweep_kernel_ms"], st["precompute_ms"], st["total_gpu_ms"], wall * 1e3))
+        ms = np.array(ms)
+        if base is None:
+            base = out
+        am = np.unravel_index(np.nanargmax(out), (n, n)) if np.isfinite(out).any() else (0, 0)
+        print(f"{cfg or 'default':40s} kernel {ms[:,0].min():7.3f} ms  pre {ms[:,1].min():6.3f}  gpu {ms[:,2].min():7.3f}  "
+              f"wall {ms[:,3].min():7.3f}  argmax {lag[am[0]]:.0f},{lag[am[1]]:.0f}  maxdiff {np.nanmax(np.abs(out-base)) if np.isfinite(out).any() else -1:.1e}  "
+              f"active {st['n_active_points']}", flush=True)
+    h.close()
+
+
+if __name__ == "__main__":
+    main()

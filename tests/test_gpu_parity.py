@@ -153,16 +153,20 @@ def test_sweep_carrington_slices_tiles_groups(gpu_handle):
     for lo, hi in [(0, 17), (17, 18), (18, 18), (18, 95), (95, n)]:
         parts.append(H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, shape, lag_begin=lo, lag_end=hi,
                                       prepare=False))
-    assert np.array_equal(np.concatenate(parts), full.ravel(), equal_nan=True)
+    cat = np.concatenate(parts)
+    # culling depends on the slice's lag range, so points are grouped differently: equal up to summation rounding
+    assert np.array_equal(np.isnan(cat), np.isnan(full.ravel()))
+    assert np.nanmax(np.abs(cat - full.ravel())) <= 1e-12
     for opt, val in [("tile_w", 8), ("tile_w", 128), ("n_groups", 8), ("n_groups", 64), ("lds_bytes", 4096),
-                     ("lds_bytes", 159 * 1024)]:
+                     ("lds_bytes", 64 * 1024), ("patch_w", 5), ("patch_w", 64)]:
         gpu_handle.set_option(opt, val)
         try:
             alt = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, shape, prepare=False)
         finally:
             gpu_handle.set_option("tile_w", 0)
             gpu_handle.set_option("n_groups", 0)
-            gpu_handle.set_option("lds_bytes", 65536)
+            gpu_handle.set_option("lds_bytes", 159 * 1024)
+            gpu_handle.set_option("patch_w", 0)
         assert np.nanmax(np.abs(alt - full)) <= 1e-12, (opt, val)
 
 
