@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="lag-points in the CPU sample (0 = 12 per core)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="lag-points in the CPU sample (0 = 48 per core)")
     ap.add_argument("--use-lds", type=int, default=1)
     ap.add_argument("--dense", action="store_true", help="extra line: grid tightened onto the small FOV (full overlap)")
     args = ap.parse_args()
@@ -150,8 +150,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stats = h.last_stats()
-    corr = gathered[:L].cpu().numpy() if world == 1 else \
-        torch.cat([gathered[r * chunk:r * chunk + max(0, min((r + 1) * chunk, L) - r * chunk)] for r in range(world)]).cpu().numpy()
+    corr = gathered[:L].cpu().numpy()  # chunk = ceil(L / world): only the last non-empty slice is ragged
     corr = corr.reshape(lag1.size, lag2.size)
 
     if rank == 0:
@@ -197,7 +196,7 @@ def main():
             except AttributeError:
                 avail = os.cpu_count() or 1
             cores = int(os.environ.get("COREG_CPU_CORES", min(avail, 16)))
-            n_sample = args.cpu_sample or 12 * cores
+            n_sample = args.cpu_sample or 48 * cores
             log(f"[bench] CPU baseline: {n_sample} lag-points on {cores} cores ...")
             cb, corr_cpu, subset = cpu_baseline(small, hs, large, hl, lags, n_sample, cores)
             out["cpu_baseline"] = cb

@@ -1,0 +1,2 @@
+from .alignment import Alignment  # noqa: F401
+from .alignment_results import AlignmentResults  # noqa: F401

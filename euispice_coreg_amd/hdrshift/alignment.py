@@ -1,0 +1,236 @@
+"""
+`Alignment` -- drop-in for euispice_coreg.hdrshift.Alignment (hdrshift/alignment.py:45-399) whose lag sweep
+(`_find_best_header_parameters`, alignment.py:613-797) runs on MI355X through libcoreg_hip.so.
+
+Same constructor keywords, same `align_using_helioprojective()` / `align_using_carrington()` signatures, same
+6-D correlation array layout [crval1, crval2, cdelt1, cdelt2, crota, solar_r] and the same `AlignmentResults`
+surface.  Differences, all deliberate and listed in DESIGN.md:
+  * `parallelism` no longer chooses between a process pool and a Python loop: both values run on the GPU.  It keeps
+    its *numerical* meaning for the helioprojective frame: True = reference image resampled once
+    on the small image's own pixel grid, float32 (alignment.py:649-651); False = correlate on the full large-FOV
+    grid, float64 reference (alignment.py:765).
+  * `counts_cpu_max`, `display_progress_bar`, `path_save_figure` are accepted and ignored.
+  * CDELT lags follow the intended semantics of utils/Util.py:199-215 (quirk Q2) unless
+    `cdelt_semantics="reference"`.
+  * inputs may be FITS paths or (data, header) pairs; astropy is optional.
+  * with torch.distributed initialised (one process per GPU) the lag grid is sharded and all-gathered
+    (euispice_coreg_amd/parallel.py).
+There is no CPU fallback: without the HIP library / a GPU the sweep raises.
+"""
+from __future__ import annotations
+
+import copy
+import warnings
+
+import numpy as np
+
+from .. import _lib, parallel
+from ..utils import fits_io, header as hdrutil
+from .alignment_results import AlignmentResults
+
+
+class Alignment:
+
+    def __init__(self, large_fov_known_pointing, small_fov_to_correct, lag_crval1, lag_crval2, lag_cdelt1, lag_cdelt2,
+                 lag_crota, lag_solar_r=None, small_fov_value_min=None, parallelism=False, display_progress_bar=False,
+                 small_fov_value_max=None, counts_cpu_max=40, large_fov_window=-1, small_fov_window=-1,
+                 path_save_figure=None, reprojection_order=2, force_crota_0=False, unit_lag="arcsec",
+                 cdelt_semantics="intended", device=None):
+        self.large_fov_known_pointing = large_fov_known_pointing
+        self.small_fov_to_correct = small_fov_to_correct
+        self.lag_crval1 = lag_crval1
+        self.lag_crval2 = lag_crval2
+        self.lag_cdelt1 = lag_cdelt1
+        self.lag_cdelt2 = lag_cdelt2
+        self.lag_crota = lag_crota
+        self.lag_solar_r = lag_solar_r
+        self.unit_lag = unit_lag
+        self.unit_lag_input = copy.deepcopy(unit_lag)
+        self.lonlims = None
+        self.latlims = None
+        self.shape = None
+        self.reference_date = None
+        self.parallelism = parallelism
+        self.small_fov_window = small_fov_window
+        self.large_fov_window = large_fov_window
+        self.counts = counts_cpu_max
+        self.small_fov_value_min = small_fov_value_min
+        self.small_fov_value_max = small_fov_value_max
+        self.path_save_figure = path_save_figure
+        self.display_progress_bar = display_progress_bar
+        self.force_crota_0 = force_crota_0
+        self.order = reprojection_order
+        self.method = None
+        self.coordinate_frame = None
+        self.data_large = self.data_small = self.hdr_large = self.hdr_small = None
+        if cdelt_semantics not in ("intended", "reference"):
+            raise ValueError("cdelt_semantics must be 'intended' or 'reference'")
+        self.cdelt_semantics = cdelt_semantics
+        self.device = device
+        self.last_stats = None
+        # alignment.py:137-140
+        for name in ("lag_crval1", "lag_crval2", "lag_crota", "lag_cdelt1", "lag_cdelt2"):
+            if getattr(self, name) is None:
+                setattr(self, name, np.array([0.0]))
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _load(self):
+        dl, hl = fits_io.read_image(self.large_fov_known_pointing, self.large_fov_window)
+        ds, hs = fits_io.read_image(self.small_fov_to_correct, self.small_fov_window)
+        self.data_large = np.array(dl, dtype=np.float64)  # alignment.py:191 / :301
+        self.data_small = np.array(ds, dtype=np.float64)  # alignment.py:198 / :314
+        self.hdr_large = fits_io.Header(hl)
+        self.hdr_small = fits_io.Header(hs)
+        hdrutil.check_and_create_pcij_matrix(self.hdr_small, self.force_crota_0)  # alignment.py:232 / :310
+        hdrutil.check_and_create_pcij_matrix(self.hdr_large, self.force_crota_0)
+
+    def _set_initial_header_values(self, ang2pipi=True):
+        """alignment.py:799-842."""
+        h = self.hdr_small
+        self.crval1_ref, self.crval2_ref = h["CRVAL1"], h["CRVAL2"]
+        if "CROTA" in h:
+            self.crota_ref = h["CROTA"]
+        elif "CROTA2" in h:
+            self.crota_ref = h["CROTA2"]
+        else:
+            s = -np.sign(h["PC1_2"]) + (h["PC1_2"] == 0)
+            self.crota_ref = np.rad2deg(np.arccos(h["PC1_1"])) * s
+            h["CROTA"] = np.rad2deg(np.arccos(h["PC1_1"]))
+        self.cdelt1_ref, self.cdelt2_ref = h["CDELT1"], h["CDELT2"]
+        self.unit1, self.unit2 = str(h["CUNIT1"]).strip(), str(h["CUNIT2"]).strip()
+        if self.unit_lag in self.unit1:
+            pass
+        else:
+            warnings.warn("Units of headers in deg: Modyfying inputs units to deg.")
+            for name, unit in (("lag_crval1", self.unit1), ("lag_crval2", self.unit2), ("lag_cdelt1", self.unit1),
+                               ("lag_cdelt2", self.unit2)):
+                v = np.asarray(getattr(self, name), dtype=np.float64)
+                if ang2pipi:
+                    v = hdrutil.ang2pipi(v, self.unit_lag)
+                setattr(self, name, hdrutil.convert(v, self.unit_lag, unit))
+            self.unit_lag = self.unit1
+        if self.unit1 != self.unit2:
+            raise ValueError("CUNIT1 and CUNIT2 must be equal")
+        if self.lag_solar_r is None:
+            self.lag_solar_r = np.array([1.004])
+
+    # ------------------------------------------------------------------------------------------------------------
+    def align_using_carrington(self, lonlims=None, latlims=None, size_deg_carrington=None, shape=None,
+                               reference_date=None, method="correlation", method_carrington_reprojection="fa",
+                               return_type="AlignmentResults"):
+        """alignment.py:144-261."""
+        self.method = method
+        self.coordinate_frame = "final_carrington"
+        if method_carrington_reprojection == "sunpy":
+            raise NotImplementedError("method_carrington_reprojection='sunpy' delegates to sunpy.reproject_to in the "
+                                      "reference (alignment.py:939-985) and is out of scope of the GPU path")
+        if method_carrington_reprojection != "fa":
+            raise ValueError("method_carrington_reprojection must be either 'fa' or 'sunpy")
+        self._load()
+        if reference_date is None:
+            if "DATE-AVG" not in self.hdr_large:
+                raise ValueError("Either provide a reference date manualy or the reference file header must have a "
+                                 "DATE-AVG keyword.")
+            self.reference_date = self.hdr_large["DATE-AVG"]
+        else:
+            self.reference_date = reference_date  # no numerical effect on the 'fa' path (quirk Q5)
+        if (lonlims is None) and (latlims is None) and (size_deg_carrington is not None):
+            crln, crlt = self.hdr_small["CRLN_OBS"], self.hdr_small["CRLT_OBS"]
+            self.lonlims = [crln - 0.5 * size_deg_carrington[0], crln + 0.5 * size_deg_carrington[0]]
+            self.latlims = [crlt - 0.5 * size_deg_carrington[1], crlt + 0.5 * size_deg_carrington[1]]
+            self.shape = [self.hdr_small["NAXIS1"], self.hdr_small["NAXIS2"]]
+        elif (lonlims is not None) and (latlims is not None) and (shape is not None):
+            self.lonlims, self.latlims, self.shape = lonlims, latlims, shape
+        else:
+            raise ValueError("either set lonlims as None, or not. no in between.")
+        if self.shape[0] * self.shape[1] > 25000000:
+            warnings.warn(f"shape parameter is {shape=}, which is very large.Computational time might significantly "
+                          "increase")
+        results = self._find_best_header_parameters()
+        return self._wrap(results, return_type, restore_units=True)
+
+    def align_using_helioprojective(self, method="correlation", return_type="AlignmentResults", fov_limits=None,
+                                    remove_fov_limits=None):
+        """alignment.py:263-342."""
+        if fov_limits is not None or remove_fov_limits is not None:
+            raise NotImplementedError("fov_limits / remove_fov_limits (alignment.py:863-874, 1082-1127) are not "
+                                      "implemented in the GPU path yet")
+        self.lonlims = self.latlims = self.shape = self.reference_date = None
+        self.method = method
+        self.coordinate_frame = "final_helioprojective"
+        self._load()
+        results = self._find_best_header_parameters()
+        return self._wrap(results, return_type, restore_units=True)
+
+    def align_using_initial_carrington(self, method="correlation", return_type="AlignmentResults"):
+        raise NotImplementedError("align_using_initial_carrington (CRLN-CAR / CRLT-CAR input maps, "
+                                  "alignment.py:344-399) is outside the accelerated path")
+
+    def _wrap(self, results, return_type, restore_units):
+        if return_type == "corr":
+            return results
+        if return_type != "AlignmentResults":
+            return results
+        if restore_units:  # alignment.py:242-250 / :325-333
+            for name in ("lag_crval1", "lag_crval2", "lag_cdelt1", "lag_cdelt2"):
+                v = hdrutil.ang2pipi(getattr(self, name), self.unit_lag)
+                setattr(self, name, hdrutil.convert(v, self.unit_lag, self.unit_lag_input))
+            self.unit_lag = self.unit_lag_input
+        return AlignmentResults(corr=results, lag_crval1=self.lag_crval1, lag_crval2=self.lag_crval2,
+                                lag_cdelt1=self.lag_cdelt1, lag_cdelt2=self.lag_cdelt2, lag_crota=self.lag_crota,
+                                unit_lag=self.unit_lag_input, image_to_align_path=self.small_fov_to_correct,
+                                image_to_align_window=self.small_fov_window,
+                                reference_image_path=self.large_fov_known_pointing,
+                                reference_image_window=self.large_fov_window)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _find_best_header_parameters(self, ang2pipi=True):
+        """alignment.py:613-797 on the GPU.  Returns float64 [n_crval1, n_crval2, n_cdelt1, n_cdelt2, n_crota,
+        n_solar_r]; lag-points the library could not evaluate are NaN, never 0 (quirk Q9)."""
+        if self.method == "residus":
+            raise NotImplementedError("method='residus' (alignment.py:544-547, NaN unless every grid pixel overlaps, "
+                                      "quirk Q8) is not implemented on the GPU")
+        if self.method != "correlation":
+            raise NotImplementedError  # alignment.py:549
+        hdrutil.set_threshold_minmax_to_nan(self.data_small, self.small_fov_value_min, self.small_fov_value_max)
+        self._set_initial_header_values(ang2pipi)
+        if np.isnan(self.data_small).all():
+            raise ValueError("minimum or maximum value have set all small FOV to nan")  # alignment.py:655-656
+        if self.unit_lag != self.hdr_small["CUNIT1"]:
+            raise ValueError("lag.unit and cUNIT are not the same")  # alignment.py:406
+
+        lags = _lib.LagSet(self.lag_crval1, self.lag_crval2, self.lag_cdelt1, self.lag_cdelt2, self.lag_crota)
+        sem = _lib.CDELT_INTENDED if self.cdelt_semantics == "intended" else _lib.CDELT_REFERENCE
+        solar_rs = np.atleast_1d(np.asarray(self.lag_solar_r, dtype=np.float64))
+        rank, world = parallel.world_info()
+        lo, hi, chunk = parallel.shard_bounds(lags.size, world, rank)
+        device = self.device
+        if device is None:
+            device = -1
+            if world > 1:
+                import torch
+                device = torch.cuda.current_device()
+        out = np.full(lags.shape + (len(solar_rs),), np.nan)
+        with _lib.CoregHandle(device) as h:
+            h.set_small(self.data_small)
+            for kk, solar_r in enumerate(solar_rs):
+                if self.coordinate_frame == "final_carrington":
+                    grid = _lib.Grid(self.lonlims, self.latlims, self.shape, numpy_lat_trig=True)
+                    h.prepare_reference_carrington(self.data_large, self.hdr_large, grid, solar_r, self.order)
+                    part = h.sweep_carrington(self.hdr_small, grid, solar_r, lags, order=self.order,
+                                              cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
+                else:
+                    if self.parallelism:
+                        h.prepare_reference_helioprojective(self.data_large, self.hdr_large, self.hdr_small,
+                                                            self.order)
+                        target = self.hdr_small
+                    else:
+                        h.set_reference_on_grid(self.data_large)  # quirk Q1: full large grid, float64
+                        target = self.hdr_large
+                    part = h.sweep_helioprojective(target, self.hdr_small, lags, order=self.order,
+                                                   cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
+                if world > 1:
+                    part = parallel.allgather_lag_slices(part, lags.size).cpu().numpy()
+                out[..., kk] = np.asarray(part).reshape(lags.shape)
+            self.last_stats = h.last_stats()
+        return out

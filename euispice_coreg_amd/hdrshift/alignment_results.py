@@ -1,0 +1,159 @@
+"""
+`AlignmentResults` -- drop-in for euispice_coreg.hdrshift.AlignmentResults (hdrshift/AlignmentResults.py:23-354):
+argmax of the 6-D correlation array, 2-D Gaussian sub-lag refinement (scipy.optimize.curve_fit, CPU, a few dozen
+points), corrected-header / corrected-FITS output.  Plotting (hdrshift/AlignmentResults.py:93-147 -> plot/plot.py)
+is presentation code outside the accelerated path and raises NotImplementedError here.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from ..utils import fits_io, header as hdrutil
+
+
+def twoD_Gaussian(xy, amplitude, xo, yo, sigma_x, sigma_y, offset):
+    """AlignmentResults.py:12-21."""
+    x, y = xy
+    x0 = float(xo)
+    y0 = float(yo)
+    g = offset + amplitude * np.exp(-((((x - x0) ** 2) / (2 * sigma_x ** 2)) + (((y - y0) ** 2) / (2 * sigma_y ** 2))))
+    return g.ravel()
+
+
+class AlignmentResults:
+
+    def __init__(self, corr, lag_crval1, lag_crval2, lag_cdelt1, lag_cdelt2, lag_crota, unit_lag,
+                 image_to_align_path=None, image_to_align_window=None, reference_image_path=None,
+                 reference_image_window=None):
+        def arr(v):
+            return np.array([0.0]) if v is None else np.atleast_1d(np.asarray(v, dtype=np.float64))
+
+        lag_crval1, lag_crval2, lag_cdelt1, lag_cdelt2, lag_crota = (arr(v) for v in (lag_crval1, lag_crval2,
+                                                                                      lag_cdelt1, lag_cdelt2,
+                                                                                      lag_crota))
+        corr = np.asarray(corr)
+        self.max_index = np.unravel_index(np.nanargmax(corr), corr.shape)
+        self.corr = corr
+        # the reference stores astropy Quantities here; plain arrays in `unit_lag` (crota in deg) without astropy
+        self.parameters_alignment = {"lag_crval1": lag_crval1, "lag_crval2": lag_crval2, "lag_cdelt1": lag_cdelt1,
+                                     "lag_cdelt2": lag_cdelt2, "lag_crota": lag_crota}
+        to_as = hdrutil.unit_to_deg(unit_lag) / hdrutil.unit_to_deg("arcsec")
+        self.parameters_alignment_arcsec = {"lag_crval1": lag_crval1 * to_as, "lag_crval2": lag_crval2 * to_as,
+                                            "lag_cdelt1": lag_cdelt1 * to_as, "lag_cdelt2": lag_cdelt2 * to_as,
+                                            "lag_crota": lag_crota}
+        self.image_to_align_path = image_to_align_path
+        self.image_to_align_window = image_to_align_window
+        self.reference_image_path = reference_image_path
+        self.reference_image_window = reference_image_window
+        self.unit_lag = unit_lag
+        self.shift_pixels = None
+        self.shift_arcsec = None
+        self._compute_shift()
+
+    # -- AlignmentResults.py:218-341 ---------------------------------------------------------------------------------
+    def _argmax_shift(self):
+        p = self.parameters_alignment_arcsec
+        mi = self.max_index
+        self.shift_pixels = (mi[0], mi[1], mi[2], mi[3], mi[4])
+        self.shift_arcsec = (p["lag_crval1"][mi[0]], p["lag_crval2"][mi[1]], p["lag_cdelt1"][mi[2]],
+                             p["lag_cdelt2"][mi[3]], p["lag_crota"][mi[4]])
+
+    def _compute_shift(self, method="fitting_gaussian"):
+        from scipy.optimize import curve_fit
+        if method != "fitting_gaussian":
+            raise NotImplementedError
+        mi = self.max_index
+        corr2d = self.corr[:, :, mi[2], mi[3], mi[4]]
+        px, py = [mi[0]], [mi[1]]
+        lenx, leny = corr2d.shape[0], corr2d.shape[1]
+        for ii in (-2, -1, 0, 1, 2):
+            for jj in (-2, -1, 0, 1, 2):
+                x, y = mi[0] + ii, mi[1] + jj
+                # (sic) only index -1 is excluded, the peak sample is duplicated: AlignmentResults.py:230-239, quirk Q13
+                if (x != -1) and (x < lenx) and (y != -1) and (y < leny):
+                    px.append(x)
+                    py.append(y)
+        if len(px) < 4:
+            warnings.warn(" Cannot compute shift with Gaussian fitting: not enough points")
+            self._argmax_shift()
+            return None
+        p0 = (np.float64(np.ravel(corr2d[mi[0], mi[1]])[0]), np.float64(mi[0]), np.float64(mi[1]), 1.0, 1.0, 0.9)
+        bounds = ([0.0, mi[0] - 5.0, mi[1] - 5.0, 0.0, 0.0, -10.0], [10.0, mi[0] + 5.0, mi[1] + 5.0, 1000.0, 1000.0, 10.0])
+        try:
+            A = (np.float64(px), np.float64(py))
+            # the un-excluded index -2 wraps around; on an axis shorter than 2 it is out of range and the reference
+            # dies with IndexError -- here that case falls back to the argmax like a failed fit does
+            B = np.float64(corr2d[px, py].ravel())
+            popt, _ = curve_fit(f=twoD_Gaussian, xdata=A, ydata=B, p0=p0, bounds=bounds)
+        except (ValueError, IndexError):
+            warnings.warn("Gaussian fitting failed, setting shift params as the pixel of the maximal correlation")
+            self._argmax_shift()
+            return None
+        p = self.parameters_alignment_arcsec
+        sx = np.interp(popt[1], np.arange(len(p["lag_crval1"])), p["lag_crval1"])
+        sy = np.interp(popt[2], np.arange(len(p["lag_crval2"])), p["lag_crval2"])
+        self.shift_pixels = (popt[1], popt[2], mi[2], mi[3], mi[4])
+        self.shift_arcsec = (sx, sy, p["lag_cdelt1"][mi[2]], p["lag_cdelt2"][mi[3]], p["lag_crota"][mi[4]])
+        return True
+
+    # -- outputs -----------------------------------------------------------------------------------------------------
+    def return_corrected_header(self, window, path_to_l2_input=None):
+        """AlignmentResults.py:191-214."""
+        if path_to_l2_input is None:
+            if self.image_to_align_path is None:
+                raise ValueError("Please provide a path_to_l2_input parameter")
+            path_to_l2_input = self.image_to_align_path
+        _, hdr = fits_io.read_image(path_to_l2_input, window)
+        hdr = hdr.copy()
+        s = self.shift_arcsec
+        hdrutil.correct_pointing_header(hdr, lag_crval1=s[0], lag_crval2=s[1], lag_cdelt1=s[2], lag_cdelt2=s[3],
+                                        lag_crota=s[4])
+        return hdr
+
+    def write_corrected_fits(self, window_list_to_apply_shift, path_to_l3_output, path_to_l2_input=None):
+        """AlignmentResults.py:149-178 -> utils/Util.py:106-159: copy every HDU, correct the pointing keywords of the
+        selected windows (data written as float32, as the reference does)."""
+        if path_to_l2_input is None:
+            if self.image_to_align_path is None:
+                raise ValueError("Please provide a path_to_l2_input parameter")
+            path_to_l2_input = self.image_to_align_path
+        if isinstance(path_to_l2_input, (tuple, list)):
+            hdus = [(np.asarray(path_to_l2_input[0]), fits_io.Header(path_to_l2_input[1]))]
+        else:
+            hdus = fits_io.read_all(path_to_l2_input)
+        s = self.shift_arcsec
+        out, n_corrected = [], 0
+        for ii, (data, hdr) in enumerate(hdus):
+            extname = hdr.get("EXTNAME", "nothing98695")
+            if (extname in window_list_to_apply_shift) or (ii in window_list_to_apply_shift) or \
+                    ((ii - len(hdus)) in window_list_to_apply_shift):
+                hdr = hdr.copy()
+                hdrutil.correct_pointing_header(hdr, lag_crval1=s[0], lag_crval2=s[1], lag_cdelt1=s[2],
+                                                lag_cdelt2=s[3], lag_crota=s[4])
+                data = None if data is None else np.array(data, dtype="<f4")
+                n_corrected += 1
+            out.append((data, hdr))
+        fits_io.write_images(path_to_l3_output, out, overwrite=True)
+        if n_corrected == 0:
+            raise ValueError("has not corrected any window.")
+
+    def plot_correlation(self, *a, **k):
+        raise NotImplementedError("plotting is outside the accelerated path (reference: plot/plot.py)")
+
+    def plot_co_alignment(self, *a, **k):
+        raise NotImplementedError("plotting is outside the accelerated path (reference: plot/plot.py)")
+
+    def savefig(self, filename):
+        raise NotImplementedError
+
+    def saveyaml(self, filename, window, path_to_l2_input=None):
+        raise NotImplementedError
+
+    def __str__(self):
+        s = self.shift_arcsec
+        return (f"\n Shift : \n x = {s[0]} '' \n y = {s[1]} '' \n dx = {s[2]} '' "
+                f"\n dy = {s[3]} '' \n dcrot = {s[4]} deg")
+
+    __repr__ = __str__

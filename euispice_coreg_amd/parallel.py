@@ -1,0 +1,63 @@
+"""
+Multi-GPU lag sharding: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm,
+"gloo" on CPU for tests).  The C-order raveled lag range is cut in `world` contiguous slices -- the same
+partition `np.array_split`-style fan-out the reference applies to its worker processes
+(hdrshift/alignment.py:677-687) -- every rank sweeps its slice on its own GPU with full replicas of both images,
+and ONE all-gather of the per-lag coefficients (a few KB) assembles the correlation map on every rank.
+There is no other data-path collective.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def world_info(group=None):
+    """(rank, world_size) of the default / given process group, (0, 1) when torch.distributed is not in use."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return 0, 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def shard_bounds(n_lags: int, world: int, rank: int):
+    """Contiguous, equal-size (last one ragged) slices: chunk = ceil(n / world)."""
+    chunk = (n_lags + world - 1) // world
+    lo = min(rank * chunk, n_lags)
+    hi = min((rank + 1) * chunk, n_lags)
+    return lo, hi, chunk
+
+
+def allgather_lag_slices(local, n_lags: int, group=None):
+    """Concatenate every rank's slice (rank r holds lags [r*chunk, min((r+1)*chunk, n))) into the full raveled map.
+
+    `local`: this rank's values -- a float64 torch tensor already padded to `chunk` elements (device tensor for
+    nccl), or a numpy array of the unpadded slice (staged through the backend's device).  Returns a torch tensor of
+    n_lags float64 values on the same device as the collective ran on."""
+    import torch
+    import torch.distributed as dist
+    rank, world = world_info(group)
+    lo, hi, chunk = shard_bounds(n_lags, world, rank)
+    backend = dist.get_backend(group) if world > 1 else None
+    if isinstance(local, np.ndarray):
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        buf = torch.full((chunk,), float("nan"), dtype=torch.float64, device=dev)
+        if hi > lo:
+            buf[:hi - lo] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64)).to(dev)
+        local = buf
+    if world == 1:
+        return local[:n_lags]
+    if local.numel() != chunk:
+        raise ValueError(f"local slice must be padded to chunk={chunk} elements")
+    out = torch.empty((chunk * world,), dtype=torch.float64, device=local.device)
+    try:
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    except (RuntimeError, NotImplementedError):
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local.contiguous(), group=group)
+        out = torch.cat(parts)
+    # rank r's valid part is [r*chunk, r*chunk + len_r): with chunk = ceil(n/world) the concatenation of the valid
+    # parts is simply the first n_lags elements when only the LAST non-empty slice is ragged -- which is the case here
+    return out[:n_lags]

@@ -1,0 +1,121 @@
+"""CPU tests of the host-side mirror of the reference interface: AlignmentResults (pinned by the reference's own
+fixture), the minimal FITS reader/writer, header correction, and the multi-rank lag sharding (gloo, world_size 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.test_oracle_golden import REF_CORR
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_alignment_results_reference_fixture():
+    """euispice_coreg/hdrshift/test/test_AlignmentResults.py:161-173 (tolerance 2e-2)."""
+    from euispice_coreg_amd.hdrshift import AlignmentResults
+    R = AlignmentResults(corr=REF_CORR, lag_crval1=np.arange(15, 26, 1), lag_crval2=np.arange(5, 11, 1),
+                         lag_cdelt1=None, lag_cdelt2=[0], lag_crota=[0.75], unit_lag="arcsec")
+    assert tuple(int(i) for i in R.max_index) == (9, 1, 0, 0, 0, 0)
+    assert abs(R.shift_pixels[0] - 9.33682107) < 2e-2
+    assert abs(R.shift_pixels[1] - 1.42187891) < 2e-2
+    assert abs(R.shift_arcsec[0] - (15 + R.shift_pixels[0])) < 1e-9
+    assert R.shift_arcsec[4] == 0.75
+    assert "Shift" in str(R)
+    # agrees with the oracle's restatement of the same routine
+    from oracle import coreg_oracle as O
+    _, px, _ = O.compute_shift(REF_CORR, np.arange(15, 26, 1.0), np.arange(5, 11, 1.0))
+    assert abs(px[0] - R.shift_pixels[0]) < 1e-9 and abs(px[1] - R.shift_pixels[1]) < 1e-9
+
+
+def test_alignment_results_too_few_points_falls_back_to_argmax():
+    from euispice_coreg_amd.hdrshift import AlignmentResults
+    corr = np.array([0.1, 0.3, 0.2]).reshape(3, 1, 1, 1, 1, 1)
+    with pytest.warns(UserWarning):
+        R = AlignmentResults(corr, [1.0, 2.0, 3.0], [0.0], None, None, None, "arcsec")
+    assert R.shift_arcsec[0] == 2.0
+
+
+def test_fits_roundtrip_and_corrected_fits(tmp_path):
+    from euispice_coreg_amd.hdrshift import AlignmentResults
+    from euispice_coreg_amd.utils import fits_io
+    from tests import helpers as H
+    small, hs, _, _, _ = H.scene(small_n=32, large_n=32)
+    p = str(tmp_path / "small.fits")
+    fits_io.write_images(p, [(None, {}), (small.astype(np.float32), hs)])
+    data, hdr = fits_io.read_image(p, -1)
+    assert data.dtype == np.float32 and np.array_equal(data, small.astype(np.float32), equal_nan=True)
+    for k in ("CRVAL1", "CDELT2", "PC1_2", "CROTA", "DSUN_OBS", "NAXIS1"):
+        assert hdr[k] == pytest.approx(hs[k], rel=1e-15), k
+    assert hdr["CUNIT1"] == "arcsec" and hdr["DATE-AVG"] == hs["DATE-AVG"]
+    R = AlignmentResults(REF_CORR, np.arange(15, 26, 1), np.arange(5, 11, 1), None, [0], [0.75], "arcsec",
+                         image_to_align_path=p, image_to_align_window=-1)
+    out = str(tmp_path / "corrected.fits")
+    R.write_corrected_fits([-1], out)
+    d2, h2 = fits_io.read_image(out, 1)
+    assert np.array_equal(d2, data, equal_nan=True)
+    assert h2["CRVAL1"] == pytest.approx(hs["CRVAL1"] + R.shift_arcsec[0], rel=1e-14)
+    assert h2["CRVAL2"] == pytest.approx(hs["CRVAL2"] + R.shift_arcsec[1], rel=1e-14)
+    assert h2["CROTA"] == pytest.approx(hs["CROTA"] + 0.75, rel=1e-14)
+    assert h2["PC1_1"] == pytest.approx(np.cos(np.deg2rad(hs["CROTA"] + 0.75)), rel=1e-14)
+    hc = R.return_corrected_header(-1)
+    assert hc["CRVAL1"] == h2["CRVAL1"]
+    with pytest.raises(ValueError):
+        R.write_corrected_fits(["no-such-window"], out)
+
+
+def test_alignment_constructor_and_errors():
+    from euispice_coreg_amd.hdrshift import Alignment
+    from tests import helpers as H
+    small, hs, large, hl, _ = H.scene(small_n=32, large_n=32)
+    A = Alignment((large, hl), (small, hs), lag_crval1=[0.0], lag_crval2=[0.0], lag_cdelt1=None, lag_cdelt2=None,
+                  lag_crota=None)
+    assert np.array_equal(A.lag_crota, [0.0]) and A.order == 2 and A.counts == 40
+    with pytest.raises(ValueError):
+        A.align_using_carrington(lonlims=(0, 1))  # "either set lonlims as None, or not. no in between."
+    with pytest.raises(ValueError):
+        A.align_using_carrington(lonlims=(0, 1), latlims=(0, 1), shape=(8, 8), method_carrington_reprojection="xx")
+    hs2 = dict(hs)
+    for k in ("PC1_1", "PC1_2", "PC2_1", "PC2_2", "CROTA"):
+        hs2.pop(k)
+    B = Alignment((large, hl), (small, hs2), [0.0], [0.0], None, None, None)
+    with pytest.raises(ValueError):  # no CROTA / PCi_j and force_crota_0 not set (alignment.py:592)
+        B.align_using_helioprojective()
+
+
+def test_shard_bounds_cover_range():
+    from euispice_coreg_amd import parallel
+    for n in (0, 1, 7, 3600, 14641):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                lo, hi, chunk = parallel.shard_bounds(n, world, r)
+                assert 0 <= lo <= hi <= n and hi - lo <= chunk
+                seen.extend(range(lo, hi))
+            assert seen == list(range(n))
+
+
+def test_allgather_lag_slices_gloo_world2(tmp_path):
+    """N > 1 path on CPU: two ranks (gloo), each 'sweeps' its slice, one all-gather assembles the map."""
+    script = tmp_path / "worker.py"
+    script.write_text(
+        "import os, sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch.distributed as dist\n"
+        "from euispice_coreg_amd import parallel\n"
+        "dist.init_process_group('gloo')\n"
+        "rank, world = parallel.world_info()\n"
+        "for n in (1, 5, 121, 3600):\n"
+        "    lo, hi, chunk = parallel.shard_bounds(n, world, rank)\n"
+        "    local = np.arange(lo, hi, dtype=np.float64) * 0.5 + 1.0\n"
+        "    full = parallel.allgather_lag_slices(local, n).numpy()\n"
+        "    assert np.array_equal(full, np.arange(n) * 0.5 + 1.0), (rank, n, full)\n"
+        "dist.barrier(); dist.destroy_process_group()\n"
+        "print('rank', rank, 'ok')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29561", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2

@@ -1,0 +1,125 @@
+"""
+CPU tests of the C ABI that need no GPU: the shared library loads, exports every symbol include/coreg_hip.h
+declares, and its host-side header arithmetic (header shifting, TAN->TAN homography, Carrington origin) agrees
+with the oracle.  No compute entry point is called here.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import coreg_oracle as O
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()  # hipcc cross-compiles without a GPU; no-op when the .so is newer than its sources
+    from euispice_coreg_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "coreg_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(coreg_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    cdll = lib.load_library()
+    bound = {name for name, _, _ in lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(cdll, name), name
+    assert b"gfx950" in cdll.coreg_version()
+
+
+def test_struct_layouts_match_header(lib):
+    import ctypes as C
+    assert C.sizeof(lib.Wcs2d) == 8 + 16 * 8
+    assert C.sizeof(lib.Lags) == 5 * 16
+    assert C.sizeof(lib.CarrGrid) == 6 * 8 + 2 * 8
+    assert C.sizeof(lib.Stats) == 3 * 8 + 4 * 8 + 2 * 4
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path, lib):
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        lib.load_library()
+
+
+def _state():
+    small, hs, large, hl, _ = H.scene(small_n=48, large_n=64)
+    st = H.oracle_state(small, hs, large, hl, ([0.0], [0.0], None, None, None))
+    O.set_initial_header_values(st)
+    return st
+
+
+@pytest.mark.parametrize("d", [(24.0, 6.0, 0.0, 0.0, 0.0), (-3.0, 11.5, 0.0, 0.0, 0.75), (1.0, 2.0, 0.02, 0.0, 0.0),
+                               (1.0, 2.0, 0.0, -0.03, 0.0), (0.0, 0.0, 0.01, -0.02, -0.4)])
+def test_shift_header_matches_oracle(lib, d):
+    """coreg_shift_header == alignment.py:401-468 restated in the oracle (intended CDELT semantics), including the
+    'PC rebuilt only when a crota/cdelt lag is non-zero' rule (quirk Q3)."""
+    st = _state()
+    st.hdr_small["PC1_2"] *= 1.0000001  # make the header PC slightly inconsistent with CROTA: Q3 becomes visible
+    want = dict(st.hdr_small)
+    O.shift_header(st, want, *d)
+    rc, got = lib.shift_header(st.hdr_small, *d)
+    assert rc == 0
+    for k, f in [("CRVAL1", "crval1"), ("CRVAL2", "crval2"), ("CDELT1", "cdelt1"), ("CDELT2", "cdelt2"),
+                 ("PC1_1", "pc1_1"), ("PC1_2", "pc1_2"), ("PC2_1", "pc2_1"), ("PC2_2", "pc2_2"), ("CROTA", "crota")]:
+        assert getattr(got, f) == pytest.approx(want[k], rel=0, abs=1e-15 * max(1.0, abs(want[k]))), k
+
+
+def test_shift_header_reference_cdelt_semantics(lib):
+    st = _state()
+    rc, got = lib.shift_header(st.hdr_small, 1.0, 2.0, 0.02, 0.0, 0.0, cdelt_semantics=lib.CDELT_REFERENCE)
+    assert rc == 0 and got.cdelt1 == st.hdr_small["CDELT1"]  # d_cdelt1 is never written (alignment.py:423-430)
+    rc, _ = lib.shift_header(st.hdr_small, 1.0, 2.0, 0.0, 0.01, 0.0, cdelt_semantics=lib.CDELT_REFERENCE)
+    assert rc == 1  # the reference's worker dies (alignment.py:440)
+
+
+@pytest.mark.parametrize("d", [(24.0, 6.0, 0.0, 0.0, 0.75), (-30.0, 30.0, 0.0, 0.0, 0.0), (5.0, -5.0, 0.01, -0.02, -1.0)])
+def test_homography_matches_oracle_tan(lib, d):
+    """coreg_homography(hdr_target -> shifted hdr) reproduces the per-pixel spherical-trig route
+    WCS.world_to_pixel(ang2pipi(WCS.pixel_to_world())) (alignment.py:1038-1069) to < 1e-9 px."""
+    st = _state()
+    hdr = dict(st.hdr_small)
+    O.shift_header(st, hdr, *d)
+    x, y = O.extract_coordinates_pixels(st.hdr_small, hdr)
+    hm = lib.homography(st.hdr_small, hdr)
+    jj, ii = np.mgrid[0:st.hdr_small["NAXIS2"], 0:st.hdr_small["NAXIS1"]].astype(float)
+    w = hm[2, 0] * ii + hm[2, 1] * jj + hm[2, 2]
+    assert np.abs((hm[0, 0] * ii + hm[0, 1] * jj + hm[0, 2]) / w - x).max() < 1e-9
+    assert np.abs((hm[1, 0] * ii + hm[1, 1] * jj + hm[1, 2]) / w - y).max() < 1e-9
+    # small grid -> large header (the once-only sub-map, alignment.py:993)
+    x, y = O.extract_coordinates_pixels(st.hdr_small, st.hdr_large)
+    hm = lib.homography(st.hdr_small, st.hdr_large)
+    w = hm[2, 0] * ii + hm[2, 1] * jj + hm[2, 2]
+    assert np.abs((hm[0, 0] * ii + hm[0, 1] * jj + hm[0, 2]) / w - x).max() < 1e-9
+
+
+def test_homography_matches_wcslib_golden(lib, wcs_golden):
+    from tests.conftest import golden_header
+    g = wcs_golden
+    for tag in ["lag_hri", "sub_hri_fsi", "lag_spice", "lag_cdelt"]:
+        ha, hb = golden_header(g, tag + "/A"), golden_header(g, tag + "/B")
+        ha.setdefault("CROTA", 0.0)
+        hb.setdefault("CROTA", 0.0)
+        hm = lib.homography(ha, hb)
+        gx, gy = g[tag + "/gx"], g[tag + "/gy"]
+        w = hm[2, 0] * gx + hm[2, 1] * gy + hm[2, 2]
+        assert np.abs((hm[0, 0] * gx + hm[0, 1] * gy + hm[0, 2]) / w - g[tag + "/x"]).max() < 1e-9, tag
+        assert np.abs((hm[1, 0] * gx + hm[1, 1] * gy + hm[1, 2]) / w - g[tag + "/y"]).max() < 1e-9, tag
+
+
+def test_carrington_origin_matches_oracle(lib):
+    st = _state()
+    hdr = dict(st.hdr_small)
+    O.shift_header(st, hdr, 12.0, -7.0, 0.0, 0.0, 0.5)
+    p = O.carrington_params(hdr, 1.004)
+    x0, y0 = lib.carrington_origin(hdr)
+    assert x0 == pytest.approx(p["x0"], abs=1e-11) and y0 == pytest.approx(p["y0"], abs=1e-11)

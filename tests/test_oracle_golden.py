@@ -1,0 +1,144 @@
+"""
+CPU tests: the oracle (oracle/coreg_oracle.py) against
+  * golden vectors produced by the reference's own utils/rectify.py (tests/golden/make_golden_rectify.py),
+  * golden vectors produced by astropy.wcs / wcslib (tests/golden/make_golden_wcs.py),
+  * the correlation-map fixture embedded in the reference's tests
+    (euispice_coreg/hdrshift/test/test_AlignmentResults.py:33-126, known answer :172-173),
+  * scipy.ndimage.map_coordinates itself (scalar model of the order-1/2 semantics).
+"""
+import numpy as np
+import pytest
+
+from oracle import coreg_oracle as O
+from tests.conftest import golden_header, rectify_case
+
+
+@pytest.mark.parametrize("case", ["A", "B", "C", "D", "E"])
+def test_carrington_coords_bit_equal_reference(rectify_golden, case):
+    """CarringtonTransform + Rectifier grid: (nx, ny) bit-identical to the reference (NEP-50 dtype flow, quirk Q6)."""
+    c = rectify_case(rectify_golden, case)
+    nx, ny = O.carrington_coords(c["hdr"], c["solar_r"], c["shape"], c["lonlims"], c["latlims"])
+    assert nx.dtype == np.float64
+    assert np.array_equal(nx, c["nx"], equal_nan=True)
+    assert np.array_equal(ny, c["ny"], equal_nan=True)
+
+
+@pytest.mark.parametrize("case", ["A", "B", "C", "D", "E"])
+def test_carrington_resample_bit_equal_reference(rectify_golden, case):
+    c = rectify_case(rectify_golden, case)
+    res = O.carrington_transform_fa(c["image"], c["hdr"], c["solar_r"], c["shape"], c["lonlims"], c["latlims"],
+                                    order=c["order"])
+    assert np.array_equal(res, c["resampled"], equal_nan=True)
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_spline_model_matches_reference_interpol2d_edges(rectify_golden, order):
+    """Bounds rule, mirrored edge taps, NaN taps, NaN coordinates (SURVEY a-14, quirk Q11), via the reference's
+    rectify.interpol2d run on scipy 1.7.1."""
+    g = rectify_golden
+    m = O.spline_sample_model(g["edge/image"], g["edge/x"], g["edge/y"], np.nan, order)
+    want = g["edge/res_order%d" % order]
+    assert np.array_equal(np.isnan(m), np.isnan(want))
+    assert np.nanmax(np.abs(m - want)) <= 1e-12
+    # float32 destination == float32(float64 result)
+    assert np.array_equal(m.astype(np.float32), g["edge/res32_order%d" % order], equal_nan=True)
+    # and the oracle's own entry point (scipy of this interpreter)
+    got = O.interpol2d(g["edge/image"], g["edge/x"], g["edge/y"], fill=-32762, order=order)
+    got = np.where(got == -32762, np.nan, got)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) <= 1e-12
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_spline_model_matches_scipy_random(order):
+    rng = np.random.default_rng(3)
+    img = rng.normal(size=(23, 31))
+    img[5, 7] = np.nan
+    x = rng.uniform(-2, 33, size=4000)
+    y = rng.uniform(-2, 25, size=4000)
+    want = O.interpol2d(img, x, y, fill=np.nan, order=order)
+    got = O.spline_sample_model(img, x, y, np.nan, order)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) <= 1e-13
+
+
+@pytest.mark.parametrize("name", ["hri", "fsi", "spice", "far"])
+def test_tan_wcs_matches_wcslib(wcs_golden, name):
+    g = wcs_golden
+    w = O.TanWCS(golden_header(g, name))
+    lon, lat = w.pixel_to_world(g[name + "/px"], g[name + "/py"])
+    assert np.abs(lon - g[name + "/lon"]).max() <= 1e-12
+    assert np.abs(lat - g[name + "/lat"]).max() <= 1e-12
+    bx, by = w.world_to_pixel(O.ang2pipi(g[name + "/lon"]), O.ang2pipi(g[name + "/lat"]))
+    assert np.abs(bx - g[name + "/back_x"]).max() <= 1e-9
+    assert np.abs(by - g[name + "/back_y"]).max() <= 1e-9
+
+
+@pytest.mark.parametrize("tag", ["lag_hri", "sub_hri_fsi", "lag_spice", "lag_cdelt"])
+def test_tan_composite_matches_wcslib(wcs_golden, tag):
+    """pixel grid of A -> world -> ang2pipi -> pixels of B (one helioprojective lag-point, alignment.py:1038-1069)."""
+    g = wcs_golden
+    wa, wb = O.TanWCS(golden_header(g, tag + "/A")), O.TanWCS(golden_header(g, tag + "/B"))
+    lon, lat = wa.pixel_to_world(g[tag + "/gx"], g[tag + "/gy"])
+    x, y = wb.world_to_pixel(O.ang2pipi(lon), O.ang2pipi(lat))
+    assert np.abs(x - g[tag + "/x"]).max() <= 1e-9
+    assert np.abs(y - g[tag + "/y"]).max() <= 1e-9
+
+
+def test_ang2pipi():
+    a = np.array([-540.0, -180.0, -179.0, 0.0, 179.0, 180.0, 181.0, 359.0, 360.0, 725.0])
+    got = O.ang2pipi(a)
+    assert np.all((got > -180.0) & (got <= 180.0))
+    assert np.allclose((got - a) % 360.0, 0.0)
+    assert got[5] == 180.0 and got[1] == 180.0
+
+
+def test_c_correlate_is_pearson():
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=1000) * 30 + 500
+    b = 0.3 * a + rng.normal(size=1000) * 10
+    r = O.c_correlate(a, b)[0]
+    assert abs(r - np.corrcoef(a, b)[0, 1]) < 1e-13
+    assert np.isnan(O.c_correlate(np.array([]), np.array([]))[0])
+
+
+# the 11x6 correlation map of euispice_coreg/hdrshift/test/test_AlignmentResults.py:33-126 (data fixture)
+REF_CORR = np.array([
+    [0.94431532, 0.94491356, 0.94490277, 0.94429364, 0.94309195, 0.94131598],
+    [0.9487374, 0.94936037, 0.94934872, 0.94870775, 0.94744547, 0.94558114],
+    [0.95292, 0.95356913, 0.95355487, 0.95288052, 0.95155507, 0.94959962],
+    [0.95678181, 0.95745709, 0.95743886, 0.95673169, 0.95534362, 0.95329829],
+    [0.96025253, 0.96095169, 0.96093119, 0.96019453, 0.95874962, 0.95662224],
+    [0.963255, 0.96397323, 0.96395091, 0.96318901, 0.96169552, 0.95949712],
+    [0.96570708, 0.9664386, 0.96641366, 0.96563084, 0.9640988, 0.96184383],
+    [0.9675529, 0.96828706, 0.96825363, 0.96745105, 0.96588888, 0.96359088],
+    [0.9687609, 0.9694829, 0.96943329, 0.96861061, 0.96702333, 0.96469464],
+    [0.96932341, 0.9700199, 0.9699457, 0.96910128, 0.96749419, 0.96514772],
+    [0.96927416, 0.96994215, 0.96984541, 0.96898563, 0.96737077, 0.96502305],
+]).reshape(11, 6, 1, 1, 1, 1)
+
+
+def test_compute_shift_reference_fixture():
+    """Known answer of the reference's own test (shift_pixels ~ (9.33682107, 1.42187891) +- 1e-2,
+    test_AlignmentResults.py:172-173).  scipy.optimize.curve_fit drifts across versions by ~1.2e-2 in x
+    (SURVEY section 4): tolerance 2e-2, argmax exact."""
+    lag1 = np.arange(15, 26, 1).astype(float)
+    lag2 = np.arange(5, 11, 1).astype(float)
+    max_index, shift_px, shift_arcsec = O.compute_shift(REF_CORR, lag1, lag2)
+    assert tuple(int(i) for i in max_index[:2]) == (9, 1)
+    assert abs(shift_px[0] - 9.33682107) < 2e-2
+    assert abs(shift_px[1] - 1.42187891) < 2e-2
+    assert abs(shift_arcsec[0] - (15 + shift_px[0])) < 1e-9
+
+
+def test_oracle_parallel_fanout_equals_serial():
+    """counts > 1 (np.array_split chunks over processes, shared-memory images) == in-process loop."""
+    from tests import helpers as H
+    small, hs, large, hl, _ = H.scene(small_n=48, large_n=64)
+    lags = (17.0 + 2.0 * (np.arange(4) - 2), -9.0 + 2.0 * (np.arange(3) - 1), None, None, [0.0, 0.3])
+    a = H.oracle_carrington(small, hs, large, hl, lags, (40, 36))
+    b = H.oracle_carrington(small, hs, large, hl, lags, (40, 36), counts=3)
+    assert np.array_equal(a, b, equal_nan=True)
+    a = H.oracle_helio(small, hs, large, hl, lags)
+    b = H.oracle_helio(small, hs, large, hl, lags, counts=2)
+    assert np.array_equal(a, b, equal_nan=True)
