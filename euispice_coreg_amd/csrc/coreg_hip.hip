@@ -49,6 +49,27 @@ struct DevBuf {
     }
 };
 
+struct PinBuf {  // page-locked host staging (async H2D without a host sync)
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
 };
@@ -71,15 +92,18 @@ struct coreg_handle {
     int ref_dtype = -1;
     // pivots[0] = mean(reference), pivots[1] = mean(small)
     DevBuf pivots, red_sum, red_cnt;
-    // geometry tables
+    // geometry tables (+ the host copy they were built from: re-uploaded only when the grid changes)
     DevBuf t_sin_lon, t_cos_lon, t_cos_lat, t_sin_lat;
+    CarrTables tabs;
+    std::vector<double> tabs_key;
+    PinBuf pin_params, pin_outidx;
     // precompute outputs
     DevBuf pts, tile_count, tile_list, tile_info, tile_bbox;
     // sweep
     DevBuf lane_params, out_index, partials, out_dev, tmp_img;
 
     // options
-    int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_skew = 0;
+    int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0;
 
     coreg_stats stats;
     std::vector<EventPair> ev_sweep, ev_pre;
@@ -163,17 +187,27 @@ int upload_image(coreg_handle* h, const double* img, size_t n, DevBuf& buf, bool
 
 int upload_carr_tables(coreg_handle* h, const coreg_carr_grid& g, const coreg_wcs2d& hdr, CarrDev* dev) {
     if (g.n_lon < 1 || g.n_lat < 1) return fail(h, COREG_EINVAL, "carrington grid: n_lon/n_lat must be >= 1");
-    CarrTables t;
-    carr_tables(g, hdr.crln_obs, t);
-    HIPCHK(h->t_sin_lon.reserve(g.n_lon * sizeof(double)));
-    HIPCHK(h->t_cos_lon.reserve(g.n_lon * sizeof(double)));
-    HIPCHK(h->t_cos_lat.reserve(g.n_lat * sizeof(float)));
-    HIPCHK(h->t_sin_lat.reserve(g.n_lat * sizeof(float)));
-    HIPCHK(hipMemcpyAsync(h->t_sin_lon.p, t.sin_lon.data(), g.n_lon * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->t_cos_lon.p, t.cos_lon.data(), g.n_lon * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->t_cos_lat.p, t.cos_lat.data(), g.n_lat * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->t_sin_lat.p, t.sin_lat.data(), g.n_lat * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));  // host vectors die here
+    // key: everything the tables depend on (caller-supplied latitude trig by value)
+    std::vector<double> key = {g.lon0, g.lon1, (double)g.n_lon, g.lat0, g.lat1, (double)g.n_lat, hdr.crln_obs,
+                               g.lat_cos ? 1.0 : 0.0, g.lat_sin ? 1.0 : 0.0};
+    if (g.lat_cos) key.insert(key.end(), g.lat_cos, g.lat_cos + g.n_lat);
+    if (g.lat_sin) key.insert(key.end(), g.lat_sin, g.lat_sin + g.n_lat);
+    if (key != h->tabs_key || !h->t_sin_lon.p) {
+        CarrTables& t = h->tabs;
+        carr_tables(g, hdr.crln_obs, t);
+        HIPCHK(h->t_sin_lon.reserve(g.n_lon * sizeof(double)));
+        HIPCHK(h->t_cos_lon.reserve(g.n_lon * sizeof(double)));
+        HIPCHK(h->t_cos_lat.reserve(g.n_lat * sizeof(float)));
+        HIPCHK(h->t_sin_lat.reserve(g.n_lat * sizeof(float)));
+        // h->tabs outlives the copies (it is only rebuilt after the next key mismatch, behind this same stream)
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpyAsync(h->t_sin_lon.p, t.sin_lon.data(), g.n_lon * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->t_cos_lon.p, t.cos_lon.data(), g.n_lon * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->t_cos_lat.p, t.cos_lat.data(), g.n_lat * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->t_sin_lat.p, t.sin_lat.data(), g.n_lat * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->tabs_key.swap(key);
+    }
     dev->sin_lon = h->t_sin_lon.as<double>();
     dev->cos_lon = h->t_cos_lon.as<double>();
     dev->cos_lat = h->t_cos_lat.as<float>();
@@ -262,28 +296,58 @@ int check_lags(coreg_handle* h, const coreg_lags* l, LagDims* d, int64_t begin, 
     return COREG_OK;
 }
 
-// super-patch (sw x sh <= 256 CRVAL1 x CRVAL2 lags per workgroup) minimising padded lane slots
-// sw_max: widest patch (in CRVAL1 lags) whose lanes still fall on distinct LDS banks (see k_sweep)
-void choose_patch(int n1, int n2, int sw_max, int* sw_out, int* sh_out) {
-    long long best = std::numeric_limits<long long>::max();
-    int bw = 1, bh = 1;
-    for (int sw = 1; sw <= std::min(std::min(n1, kBlock), std::max(sw_max, 1)); ++sw) {
-        int sh = std::min(n2, kBlock / sw);
-        if (sh < 1) break;
-        const long long batches = (long long)((n1 + sw - 1) / sw) * ((n2 + sh - 1) / sh);
-        // shrink sh to the smallest value giving the same batch count (squarer, smaller windows)
-        const int rows = (n2 + sh - 1) / sh;
-        sh = (n2 + rows - 1) / rows;
-        const int big = std::max(sw, sh), small = std::min(sw, sh);
-        const long long cost = batches * 1024 + (long long)(big - small) + (big > 4 * small ? 512 : 0);
-        if (cost < best) {
-            best = cost;
-            bw = sw;
-            bh = sh;
+// Local pixel-space geometry of a sweep (host estimates; they steer the plan, never the results):
+// small-image pixels per grid step (d?_di, d?_dj) and per CRVAL1 / CRVAL2 lag step (a?, b?).
+struct Geometry {
+    double dx_di = 1, dx_dj = 0, dy_di = 0, dy_dj = 1;
+    double ax = 0, ay = 0, bx = 0, by = 0;
+};
+struct Plan {
+    int tile_w = 32;      // grid tile = tile_w x (kTilePts / tile_w) points
+    int sw = 16, sh = 16; // lag patch of a workgroup: sw CRVAL1 lags x sh CRVAL2 lags (sw * sh <= 256)
+    double window = 0;    // estimated LDS window (elements)
+};
+
+// Tile shape and lag patch chosen together: fewest lag batches (= least padded lane slots) among the combinations
+// whose LDS window (tile extent (+) patch extent, in pixels) fits; ties -> smaller window.  m1 x n2 = lag plane.
+Plan choose_plan(coreg_handle* h, const Geometry& g, int m1, int n2, long long lds_elems) {
+    Plan best, fallback;
+    double best_cost = std::numeric_limits<double>::max(), fb_win = std::numeric_limits<double>::max();
+    const int sw_hi = h->opt_patch_w > 0 ? std::min<int>((int)h->opt_patch_w, kBlock) : kBlock;
+    for (int tw = 4; tw <= 256; tw *= 2) {
+        if (h->opt_tile_w > 0 && tw != h->opt_tile_w) continue;
+        const int th = kTilePts / tw;
+        if (th < 1) continue;
+        const double tex = tw * std::fabs(g.dx_di) + th * std::fabs(g.dx_dj);
+        const double tey = tw * std::fabs(g.dy_di) + th * std::fabs(g.dy_dj);
+        for (int sw = 1; sw <= std::min(m1, sw_hi); ++sw) {
+            int sh = std::min(n2, kBlock / sw);
+            if (sh < 1) break;
+            const int cols = (m1 + sw - 1) / sw, rows = (n2 + sh - 1) / sh;
+            sh = (n2 + rows - 1) / rows;                    // smallest sh with the same batch count
+            const int sw2 = (m1 + cols - 1) / cols;         // likewise for sw
+            const double ex = tex + sw2 * std::fabs(g.ax) + sh * std::fabs(g.bx) + 6.0;
+            const double ey = tey + sw2 * std::fabs(g.ay) + sh * std::fabs(g.by) + 6.0;
+            const double win = (ex + 1.0) * ey;
+            if (win < fb_win) {
+                fb_win = win;
+                fallback.tile_w = tw;
+                fallback.sw = sw2;
+                fallback.sh = sh;
+                fallback.window = win;
+            }
+            if (win > 0.94 * (double)lds_elems) continue;
+            const double cost = (double)cols * rows * (1.0 + 0.08 * win / (double)lds_elems);
+            if (cost < best_cost) {
+                best_cost = cost;
+                best.tile_w = tw;
+                best.sw = sw2;
+                best.sh = sh;
+                best.window = win;
+            }
         }
     }
-    *sw_out = bw;
-    *sh_out = bh;
+    return best_cost < std::numeric_limits<double>::max() ? best : fallback;
 }
 
 struct SlotList {
@@ -293,17 +357,21 @@ struct SlotList {
 };
 
 // slots for combo c (= (i3*n4 + i4)*n5 + i5) restricted to the raveled slice [begin, end)
-void build_slots(const LagDims& d, long long c, long long begin, long long end, int sw_max, SlotList* s) {
+void build_slots(const LagDims& d, long long c, long long begin, long long end, int sw, int sh, SlotList* s) {
     s->i1.clear();
     s->i2.clear();
     s->outidx.clear();
     s->n_batches = 0;
+    {
+        const size_t cap = (size_t)((d.n1 + sw - 1) / sw + 1) * ((d.n2 + sh - 1) / sh) * kBlock;
+        s->i1.reserve(cap);
+        s->i2.reserve(cap);
+        s->outidx.reserve(cap);
+    }
     const long long row = (long long)d.n2 * d.nc;
     const int i1_lo = (int)(begin / row);
     const int i1_hi = (int)((end - 1) / row);
     const int m1 = i1_hi - i1_lo + 1;
-    int sw, sh;
-    choose_patch(m1, d.n2, sw_max, &sw, &sh);
     for (int p1 = 0; p1 * sw < m1; ++p1)
         for (int p2 = 0; p2 * sh < d.n2; ++p2) {
             bool any = false;
@@ -385,21 +453,13 @@ void fill_precompute_common(coreg_handle* h, PrecomputeArgs* a, int tile_w) {
     a->tile_bbox = h->tile_bbox.as<double>();
 }
 
-// one sweep-kernel launch + finalize over the slots in `params` (SoA [np][n_slots])
-int launch_sweep(coreg_handle* h, int mode, int order, int np, const std::vector<double>& params,
-                 const std::vector<long long>& outidx, int n_batches, int n_tiles, int skew_rows,
-                 long long lag_begin, double* out_dev) {
+// one sweep-kernel launch + finalize over n_batches * 256 slots whose parameters (SoA [np][n_slots]) and output
+// indices are already on the device
+int launch_sweep(coreg_handle* h, int mode, int order, const double* params_dev, const long long* outidx_dev,
+                 int n_batches, int n_tiles, long long lag_begin, double* out_dev) {
     const long long n_slots = (long long)n_batches * kBlock;
     const int n_groups = pick_groups(h, n_batches, n_tiles);
-    HIPCHK(h->lane_params.reserve(params.size() * sizeof(double)));
-    HIPCHK(h->out_index.reserve(outidx.size() * sizeof(long long)));
     HIPCHK(h->partials.reserve((size_t)n_groups * kNumSums * n_slots * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(h->lane_params.p, params.data(), params.size() * sizeof(double), hipMemcpyHostToDevice,
-                          h->stream));
-    HIPCHK(hipMemcpyAsync(h->out_index.p, outidx.data(), outidx.size() * sizeof(long long), hipMemcpyHostToDevice,
-                          h->stream));
-    // the host vectors are reused by the caller's next combo: make the copies complete first
-    HIPCHK(hipStreamSynchronize(h->stream));
 
     SweepArgs a;
     a.img = h->small.p;
@@ -410,7 +470,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int np, const std::vector
     a.tile_list = h->tile_list.as<int>();
     a.tile_info = h->tile_info.as<long long>();
     a.tile_bbox = h->tile_bbox.as<double>();
-    a.lane_params = h->lane_params.as<double>();
+    a.lane_params = params_dev;
     a.n_slots = n_slots;
     a.n_batches = n_batches;
     a.n_groups = n_groups;
@@ -421,17 +481,20 @@ int launch_sweep(coreg_handle* h, int mode, int order, int np, const std::vector
     const size_t lds_min = (size_t)(kPointGroups - 1) * kNumSums * kBlock * sizeof(double);
     const size_t lds_bytes = std::max(lds_min, a.use_lds ? (size_t)h->opt_lds_bytes : 0);
     a.lds_elems = (int)(lds_bytes / sizeof(double));
-    (void)skew_rows;
-    (void)np;
 
     const dim3 grid((unsigned)((long long)n_groups * n_batches)), block(kSweepThreads);
     EventPair* ev = next_event(h, h->ev_sweep, h->ev_sweep_used);
     if (!ev) return fail(h, COREG_EHIP, "hipEventCreate failed");
 #define SW(M, O, TS, R)                                                                                             \
     do {                                                                                                              \
-        if (lds_bytes > 48 * 1024)                                                                                    \
-            HIPCHK(hipFuncSetAttribute((const void*)(k_sweep<M, O, TS, R>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)lds_bytes));                                                              \
+        {                                                                                                             \
+            static size_t attr_bytes = 0; /* per instantiation: raise the dynamic-LDS limit once, not per launch */   \
+            if (lds_bytes > 48 * 1024 && lds_bytes > attr_bytes) {                                                    \
+                HIPCHK(hipFuncSetAttribute((const void*)(k_sweep<M, O, TS, R>),                                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));              \
+                attr_bytes = lds_bytes;                                                                               \
+            }                                                                                                         \
+        }                                                                                                             \
         HIPCHK(hipEventRecord(ev->a, h->stream));                                                                     \
         hipLaunchKernelGGL((k_sweep<M, O, TS, R>), grid, block, lds_bytes, h->stream, a);                             \
         HIPCHK(hipEventRecord(ev->b, h->stream));                                                                     \
@@ -459,7 +522,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int np, const std::vector
     f.partials = h->partials.as<double>();
     f.n_groups = n_groups;
     f.n_slots = n_slots;
-    f.out_index = h->out_index.as<long long>();
+    f.out_index = outidx_dev;
     f.lag_begin = lag_begin;
     f.out = out_dev;
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_slots + 63) / 64)), dim3(256), 0, h->stream, f);
@@ -515,37 +578,24 @@ int end_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_dev
     return COREG_OK;
 }
 
-// LDS bank geometry of the float64 window: 64 four-byte banks = 32 elements per bank cycle.  Lanes of one lag row
-// step by step1_px elements -> at most 32/step1_px lanes per row stay conflict-free; rows step by step2_px image rows.
-int patch_w_max(coreg_handle* h, double step1_px) {
-    if (h->opt_patch_w > 0) return (int)h->opt_patch_w;
-    if (!(step1_px > 0.0)) return kBlock;
-    return std::max(4, std::min(kBlock, (int)std::floor(31.0 / step1_px) + 1));
-}
-// row skew shift: rows advance by ~step2_px per CRVAL2 lag; shift = log2 of that (power of two), -1 = no skew
-int skew_sh_for(coreg_handle* h, double step2_px) {
-    if (h->opt_skew == 0) return -1;
-    if (!(step2_px >= 1.5)) return 0;
-    int sh = (int)std::lround(std::log2(step2_px));
-    return std::max(0, std::min(5, sh));
+long long lds_window_elems(const coreg_handle* h) {
+    const size_t lds_min = (size_t)(kPointGroups - 1) * kNumSums * kBlock * sizeof(double);
+    return (long long)(std::max(lds_min, (size_t)h->opt_lds_bytes) / sizeof(double));
 }
 
-int pick_tile_w(coreg_handle* h, double dx_di, double dx_dj, double dy_di, double dy_dj, double span_x,
-                double span_y) {
-    if (h->opt_tile_w > 0) return (int)h->opt_tile_w;
-    int best_w = 32;
-    double best = std::numeric_limits<double>::max();
-    for (int tw = 4; tw <= 256; tw *= 2) {
-        const int th = kTilePts / tw;
-        const double ex = tw * std::fabs(dx_di) + th * std::fabs(dx_dj) + span_x + 4;
-        const double ey = tw * std::fabs(dy_di) + th * std::fabs(dy_dj) + span_y + 4;
-        const double cost = ex * ey;
-        if (cost < best) {
-            best = cost;
-            best_w = tw;
-        }
-    }
-    return best_w;
+// upload the concatenated per-launch lag parameters / output indices through pinned staging (no host sync)
+int upload_plan(coreg_handle* h, const std::vector<double>& params, const std::vector<long long>& outidx) {
+    HIPCHK(h->pin_params.reserve(params.size() * sizeof(double)));
+    HIPCHK(h->pin_outidx.reserve(outidx.size() * sizeof(long long)));
+    HIPCHK(h->lane_params.reserve(params.size() * sizeof(double)));
+    HIPCHK(h->out_index.reserve(outidx.size() * sizeof(long long)));
+    std::memcpy(h->pin_params.p, params.data(), params.size() * sizeof(double));
+    std::memcpy(h->pin_outidx.p, outidx.data(), outidx.size() * sizeof(long long));
+    HIPCHK(hipMemcpyAsync(h->lane_params.p, h->pin_params.p, params.size() * sizeof(double), hipMemcpyHostToDevice,
+                          h->stream));
+    HIPCHK(hipMemcpyAsync(h->out_index.p, h->pin_outidx.p, outidx.size() * sizeof(long long), hipMemcpyHostToDevice,
+                          h->stream));
+    return COREG_OK;
 }
 
 }  // namespace
@@ -596,6 +646,8 @@ void coreg_destroy(coreg_handle* h) {
                       &h->tile_info, &h->tile_bbox, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
                       &h->tmp_img};
     for (DevBuf* b : bufs) b->release();
+    h->pin_params.release();
+    h->pin_outidx.release();
     for (auto& e : h->ev_sweep) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -642,7 +694,7 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         if (value < 0) return fail(h, COREG_EINVAL, "n_groups must be >= 0");
         h->opt_n_groups = value;
     } else if (n == "skew") {
-        h->opt_skew = value ? 1 : 0;
+        (void)value;  // accepted for compatibility: the LDS row skew was measured to lose and is gone
     } else if (n == "patch_w") {
         if (value < 0 || value > kBlock) return fail(h, COREG_EINVAL, "patch_w must be in [0, 256]");
         h->opt_patch_w = value;
@@ -835,40 +887,54 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
     CarrDev cd;
     std::memset(&cd, 0, sizeof(cd));
     RETCHK(upload_carr_tables(h, *grid, *hdr_small, &cd));
-    CarrTables tabs;
-    carr_tables(*grid, hdr_small->crln_obs, tabs);
 
-    const double step1_px = d.n1 > 1 ? std::fabs(lags->crval1[1] - lags->crval1[0]) / std::fabs(hdr_small->cdelt1) : 0;
-    const double step2_px = d.n2 > 1 ? std::fabs(lags->crval2[1] - lags->crval2[0]) / std::fabs(hdr_small->cdelt2) : 0;
-    const int sw_max = patch_w_max(h, step1_px);
-    const int skew_rows = skew_sh_for(h, step2_px);
-    // tile shape: local scale of the grid -> pixel map near the grid centre (heuristic only)
-    int tile_w = 32;
+    // ---- plan: local geometry (heuristic inputs only) -> tile shape + lag patch
+    Geometry geo;
     {
         const CarrCommon c0 = carr_common(*hdr_small, solar_r);
         const int ic = grid->n_lon / 2, jc = grid->n_lat / 2;
         double a0, a1, b0, b1, c0x, c0y;
-        carr_term_host(tabs, c0, ic, jc, &a0, &a1);
-        carr_term_host(tabs, c0, std::min(ic + 1, grid->n_lon - 1), jc, &b0, &b1);
-        carr_term_host(tabs, c0, ic, std::min(jc + 1, grid->n_lat - 1), &c0x, &c0y);
-        tile_w = pick_tile_w(h, b0 - a0, c0x - a0, b1 - a1, c0y - a1, 16 * step1_px, 16 * step2_px);
+        carr_term_host(h->tabs, c0, ic, jc, &a0, &a1);
+        carr_term_host(h->tabs, c0, std::min(ic + 1, grid->n_lon - 1), jc, &b0, &b1);
+        carr_term_host(h->tabs, c0, ic, std::min(jc + 1, grid->n_lat - 1), &c0x, &c0y);
+        geo.dx_di = b0 - a0;
+        geo.dy_di = b1 - a1;
+        geo.dx_dj = c0x - a0;
+        geo.dy_dj = c0y - a1;
+        // utils/rectify.py:399-404: X0 = -(c d1 + s d2)/cdelt1, Y0 = -(-s d1 + c d2)/cdelt2
+        const double s1 = d.n1 > 1 ? lags->crval1[1] - lags->crval1[0] : 0.0;
+        const double s2 = d.n2 > 1 ? lags->crval2[1] - lags->crval2[0] : 0.0;
+        geo.ax = c0.cr * s1 / hdr_small->cdelt1;
+        geo.ay = c0.sr * s1 / hdr_small->cdelt2;
+        geo.bx = c0.sr * s2 / hdr_small->cdelt1;
+        geo.by = c0.cr * s2 / hdr_small->cdelt2;
     }
+    const long long row = (long long)d.n2 * d.nc;
+    const int m1 = (int)((lag_end - 1) / row) - (int)(lag_begin / row) + 1;
+    const Plan plan = choose_plan(h, geo, m1, d.n2, h->opt_use_lds ? lds_window_elems(h) : (1LL << 40));
+
     PrecomputeArgs pa;
     std::memset(&pa, 0, sizeof(pa));
-    // reserve before filling pointers
     {
-        const int th = kTilePts / tile_w;
-        const int n_tiles = ((h->gW + tile_w - 1) / tile_w) * ((h->gH + th - 1) / th);
-        RETCHK(reserve_tiles(h, n_tiles));
+        const int th = kTilePts / plan.tile_w;
+        RETCHK(reserve_tiles(h, ((h->gW + plan.tile_w - 1) / plan.tile_w) * ((h->gH + th - 1) / th)));
     }
-    fill_precompute_common(h, &pa, tile_w);
+    fill_precompute_common(h, &pa, plan.tile_w);
     const int n_tiles = pa.tiles_x * pa.tiles_y;
 
+    // ---- every (cdelt1, cdelt2, crota) combination = one precompute + one sweep launch; all lag parameters of all
+    //      launches are staged together and uploaded once
+    struct Launch {
+        size_t slot_off;
+        int n_batches;
+        CarrCommon cc;
+        double f0lo, f0hi, f1lo, f1hi;
+    };
+    std::vector<Launch> launches;
+    std::vector<double> params;  // per launch: [X0 x ns][Y0 x ns]
+    std::vector<long long> outidx;
     SlotList slots;
-    std::vector<double> params;
-    const long long row = (long long)d.n2 * d.nc;
     for (long long c = 0; c < d.nc; ++c) {
-        // does the slice touch this combo at all?
         {
             const long long first = (lag_begin - c + d.nc - 1) / d.nc;  // smallest k with k*nc + c >= begin
             if (first * d.nc + c >= lag_end) continue;
@@ -878,36 +944,63 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
         if (shift_header(*hdr_small, 0.0, 0.0, lags->cdelt1[i3], lags->cdelt2[i4], lags->crota[i5], cdelt_semantics,
                          &hc))
             continue;  // reference semantics: this lag kills the worker -> NaN (already filled)
-        build_slots(d, c, lag_begin, lag_end, sw_max, &slots);
+        build_slots(d, c, lag_begin, lag_end, plan.sw, plan.sh, &slots);
         if (slots.n_batches == 0) continue;
         const size_t ns = slots.i1.size();
-        params.assign(2 * ns, 0.0);
+        Launch L;
+        L.slot_off = outidx.size();
+        L.n_batches = slots.n_batches;
+        L.cc = carr_common(hc, solar_r);
+        const size_t pbase = params.size();
+        params.resize(pbase + 2 * ns);
         double x0min = 1e300, x0max = -1e300, y0min = 1e300, y0max = -1e300;
+        // utils/rectify.py:396-404 with the roll trig hoisted out of the per-lag loop (same values, same order)
+        const double roll = hc.crota * kDeg2Rad;
+        const double rc = std::cos(roll), rs = std::sin(roll);
+        const double nan = std::numeric_limits<double>::quiet_NaN();
         for (size_t s = 0; s < ns; ++s) {
-            coreg_wcs2d hl = hc;
-            hl.crval1 = hdr_small->crval1 + lags->crval1[slots.i1[s]];  // alignment.py:404
-            hl.crval2 = hdr_small->crval2 + lags->crval2[slots.i2[s]];  // alignment.py:412
-            double x0, y0;
-            carr_origin(hl, &x0, &y0);
-            params[s] = x0;
-            params[ns + s] = y0;
+            // padding lanes get NaN: they fail the bounds rule for every point, so waves made only of padding
+            // skip every point with one branch (their slots are never written by k_finalize)
+            if (slots.outidx[s] < 0) {
+                params[pbase + s] = nan;
+                params[pbase + ns + s] = nan;
+                continue;
+            }
+            const double v1 = hdr_small->crval1 + lags->crval1[slots.i1[s]];  // alignment.py:404
+            const double v2 = hdr_small->crval2 + lags->crval2[slots.i2[s]];  // alignment.py:412
+            const double dx = rc * v1 + rs * v2;
+            const double dy = -rs * v1 + rc * v2;
+            const double x0 = (hc.crpix1 - 1) - dx / hc.cdelt1;
+            const double y0 = (hc.crpix2 - 1) - dy / hc.cdelt2;
+            params[pbase + s] = x0;
+            params[pbase + ns + s] = y0;
             x0min = std::min(x0min, x0);
             x0max = std::max(x0max, x0);
             y0min = std::min(y0min, y0);
             y0max = std::max(y0max, y0);
         }
-        set_carr_common(&cd, carr_common(hc, solar_r));
-        pa.carr = cd;
+        outidx.insert(outidx.end(), slots.outidx.begin(), slots.outidx.end());
         // a point can be in bounds for some lag only if X0 + t0 in [0, W-1] for some X0 in [x0min, x0max]
-        pa.f0lo = -x0max;
-        pa.f0hi = (double)(h->sW - 1) - x0min;
-        pa.f1lo = -y0max;
-        pa.f1hi = (double)(h->sH - 1) - y0min;
-        RETCHK(launch_precompute<MODE_TRANSLATE>(h, pa, n_tiles));
-        RETCHK(launch_sweep(h, MODE_TRANSLATE, order, 2, params, slots.outidx, slots.n_batches, n_tiles, skew_rows,
-                            lag_begin, out_dev));
+        L.f0lo = -x0max;
+        L.f0hi = (double)(h->sW - 1) - x0min;
+        L.f1lo = -y0max;
+        L.f1hi = (double)(h->sH - 1) - y0min;
+        launches.push_back(L);
     }
-    (void)row;
+    if (launches.empty()) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+    RETCHK(upload_plan(h, params, outidx));
+    for (const Launch& L : launches) {
+        set_carr_common(&cd, L.cc);
+        pa.carr = cd;
+        pa.f0lo = L.f0lo;
+        pa.f0hi = L.f0hi;
+        pa.f1lo = L.f1lo;
+        pa.f1hi = L.f1hi;
+        RETCHK(launch_precompute<MODE_TRANSLATE>(h, pa, n_tiles));
+        // SoA block of this launch starts at 2 * slot_off doubles (every earlier launch contributed 2 per slot)
+        RETCHK(launch_sweep(h, MODE_TRANSLATE, order, h->lane_params.as<double>() + 2 * L.slot_off,
+                            h->out_index.as<long long>() + L.slot_off, L.n_batches, n_tiles, lag_begin, out_dev));
+    }
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }
 
@@ -929,31 +1022,66 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     RETCHK(begin_sweep(h, n_out, corr_out, out_on_device, &out_dev));
     if (n_out == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 
-    const double step1_px = d.n1 > 1 ? std::fabs(lags->crval1[1] - lags->crval1[0]) / std::fabs(hdr_small->cdelt1) : 0;
-    const double step2_px = d.n2 > 1 ? std::fabs(lags->crval2[1] - lags->crval2[0]) / std::fabs(hdr_small->cdelt2) : 0;
-    const int sw_max = patch_w_max(h, step1_px);
-    const int skew_rows = skew_sh_for(h, step2_px);
-    // all slots of all combos -> one launch
-    SlotList slots, all;
-    std::vector<double> hs;  // AoS while building
-    std::vector<coreg_wcs2d> combo_hdr((size_t)d.nc);
-    std::vector<char> combo_dead((size_t)d.nc, 0);
-    for (long long c = 0; c < d.nc; ++c) {
-        const int i5 = (int)(c % d.n5), i4 = (int)((c / d.n5) % d.n4), i3 = (int)(c / ((long long)d.n5 * d.n4));
-        combo_dead[c] = (char)shift_header(*hdr_small, 0.0, 0.0, lags->cdelt1[i3], lags->cdelt2[i4], lags->crota[i5],
-                                           cdelt_semantics, &combo_hdr[c]);
+    // ---- plan: local geometry from the maps of the central lag and of its two neighbours
+    Geometry geo;
+    {
+        auto map_of = [&](int i1, int i2, double hm[9]) {
+            coreg_wcs2d hl = *hdr_small;
+            hl.crval1 = hdr_small->crval1 + lags->crval1[i1];
+            hl.crval2 = hdr_small->crval2 + lags->crval2[i2];
+            homography(*hdr_target, hl, hm);
+        };
+        const int c1 = d.n1 / 2, c2 = d.n2 / 2;
+        double m0[9], m1h[9], m2h[9];
+        map_of(c1, c2, m0);
+        map_of(std::min(c1 + 1, d.n1 - 1), c2, m1h);
+        map_of(c1, std::min(c2 + 1, d.n2 - 1), m2h);
+        const double u = hdr_target->naxis1 * 0.5, v = hdr_target->naxis2 * 0.5;
+        double x0, y0, x1, y1;
+        apply_h(m0, u, v, &x0, &y0);
+        apply_h(m0, u + 1, v, &x1, &y1);
+        geo.dx_di = x1 - x0;
+        geo.dy_di = y1 - y0;
+        apply_h(m0, u, v + 1, &x1, &y1);
+        geo.dx_dj = x1 - x0;
+        geo.dy_dj = y1 - y0;
+        apply_h(m1h, u, v, &x1, &y1);
+        geo.ax = x1 - x0;
+        geo.ay = y1 - y0;
+        apply_h(m2h, u, v, &x1, &y1);
+        geo.bx = x1 - x0;
+        geo.by = y1 - y0;
     }
+    const long long row = (long long)d.n2 * d.nc;
+    const int m1 = (int)((lag_end - 1) / row) - (int)(lag_begin / row) + 1;
+    const Plan plan = choose_plan(h, geo, m1, d.n2, h->opt_use_lds ? lds_window_elems(h) : (1LL << 40));
+
+    // ---- all slots of all (cdelt1, cdelt2, crota) combinations -> ONE launch
+    SlotList slots;
+    std::vector<long long> outidx;
+    std::vector<double> hs;  // AoS while building
+    int n_batches = 0;
     double fx0 = 1e300, fx1 = -1e300, fy0 = 1e300, fy1 = -1e300;  // cull box in target pixels
     for (long long c = 0; c < d.nc; ++c) {
         const long long first = (lag_begin - c + d.nc - 1) / d.nc;
-        if (first * d.nc + c >= lag_end || combo_dead[c]) continue;
-        build_slots(d, c, lag_begin, lag_end, sw_max, &slots);
+        if (first * d.nc + c >= lag_end) continue;
+        const int i5 = (int)(c % d.n5), i4 = (int)((c / d.n5) % d.n4), i3 = (int)(c / ((long long)d.n5 * d.n4));
+        coreg_wcs2d hc;
+        if (shift_header(*hdr_small, 0.0, 0.0, lags->cdelt1[i3], lags->cdelt2[i4], lags->crota[i5], cdelt_semantics,
+                         &hc))
+            continue;
+        build_slots(d, c, lag_begin, lag_end, plan.sw, plan.sh, &slots);
         for (size_t s = 0; s < slots.i1.size(); ++s) {
-            coreg_wcs2d hl = combo_hdr[c];
+            coreg_wcs2d hl = hc;
             hl.crval1 = hdr_small->crval1 + lags->crval1[slots.i1[s]];
             hl.crval2 = hdr_small->crval2 + lags->crval2[slots.i2[s]];
             double hm[9];
             homography(*hdr_target, hl, hm);
+            if (slots.outidx[s] < 0) {  // padding lane: NaN map -> never in bounds
+                for (int k = 0; k < 9; ++k) hm[k] = std::numeric_limits<double>::quiet_NaN();
+                hs.insert(hs.end(), hm, hm + 9);
+                continue;
+            }
             hs.insert(hs.end(), hm, hm + 9);
             // inverse map of the small image's corners -> which target pixels can ever be in bounds
             double hi[9];
@@ -967,35 +1095,23 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                 fy1 = std::max(fy1, py);
             }
         }
-        all.i1.insert(all.i1.end(), slots.i1.begin(), slots.i1.end());
-        all.outidx.insert(all.outidx.end(), slots.outidx.begin(), slots.outidx.end());
-        all.n_batches += slots.n_batches;
+        outidx.insert(outidx.end(), slots.outidx.begin(), slots.outidx.end());
+        n_batches += slots.n_batches;
     }
-    if (all.n_batches == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
-    const size_t ns = all.outidx.size();
+    if (n_batches == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+    const size_t ns = outidx.size();
     std::vector<double> params(9 * ns);
     for (size_t s = 0; s < ns; ++s)
         for (int k = 0; k < 9; ++k) params[(size_t)k * ns + s] = hs[s * 9 + k];
+    RETCHK(upload_plan(h, params, outidx));
 
-    // tile shape from the local scale of the first lag's map
-    int tile_w = 32;
-    {
-        const double* m = &hs[0];
-        double ax, ay, bx, by, cx, cy;
-        const double u = hdr_target->naxis1 * 0.5, v = hdr_target->naxis2 * 0.5;
-        apply_h(m, u, v, &ax, &ay);
-        apply_h(m, u + 1, v, &bx, &by);
-        apply_h(m, u, v + 1, &cx, &cy);
-        tile_w = pick_tile_w(h, bx - ax, cx - ax, by - ay, cy - ay, 16 * step1_px, 16 * step2_px);
-    }
     PrecomputeArgs pa;
     std::memset(&pa, 0, sizeof(pa));
     {
-        const int th = kTilePts / tile_w;
-        const int n_tiles = ((h->gW + tile_w - 1) / tile_w) * ((h->gH + th - 1) / th);
-        RETCHK(reserve_tiles(h, n_tiles));
+        const int th = kTilePts / plan.tile_w;
+        RETCHK(reserve_tiles(h, ((h->gW + plan.tile_w - 1) / plan.tile_w) * ((h->gH + th - 1) / th)));
     }
-    fill_precompute_common(h, &pa, tile_w);
+    fill_precompute_common(h, &pa, plan.tile_w);
     const int n_tiles = pa.tiles_x * pa.tiles_y;
     // the maps are projective and the image corners bound its interior: +-2 px guards rounding of the inverse
     pa.f0lo = std::floor(fx0) - 2.0;
@@ -1003,8 +1119,8 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     pa.f1lo = std::floor(fy0) - 2.0;
     pa.f1hi = std::ceil(fy1) + 2.0;
     RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles));
-    RETCHK(launch_sweep(h, MODE_HOMOGRAPHY, order, 9, params, all.outidx, all.n_batches, n_tiles, skew_rows,
-                        lag_begin, out_dev));
+    RETCHK(launch_sweep(h, MODE_HOMOGRAPHY, order, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
+                        n_tiles, lag_begin, out_dev));
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }
 

@@ -151,11 +151,10 @@ int coreg_last_stats(const coreg_handle* h, coreg_stats* out);
 
 /* Tuning / test knobs (name -> integer value). Known names:
  *   "use_lds"      1 (default) stage the gather window in LDS, 0 gather from global memory
- *   "tile_w"       0 (default, auto) or a power of two <= 1024: grid-tile width in points (tile = 1024 pts)
+ *   "tile_w"       0 (default, auto) or a power of two in [4, 256]: grid-tile width in points (tile = 1024 pts)
  *   "n_groups"     0 (default, auto): tile groups (partial-sum slabs) per lag batch
  *   "lds_bytes"    dynamic LDS per workgroup for the float64 gather window (default and max 159 KiB)
- *   "skew"         1 shift LDS window rows to spread the lag lattice over banks, 0 (default) off
- *   "patch_w"      0 (default, auto from the LDS bank geometry) or the width, in CRVAL1 lags, of a lag patch
+ *   "patch_w"      0 (default, auto) or the maximum width, in CRVAL1 lags, of a workgroup's lag patch
  * Returns COREG_EINVAL for unknown names. */
 int coreg_set_option(coreg_handle* h, const char* name, int64_t value);
 

@@ -15,7 +15,7 @@ from euispice_coreg_amd import _lib, synthetic  # noqa: E402
 def main():
     small, hs, large, hl, truth = synthetic.make_scene()
     n = int(os.environ.get("TUNE_NLAG", "60"))
-    lag = np.arange(-n // 2, n - n // 2, 1, dtype=np.float64)
+    lag = (np.arange(n) - n // 2).astype(np.float64)
     lags = _lib.LagSet(lag, lag, None, None, None)
     shape = (int(os.environ.get("TUNE_GRID", "2048")),) * 2
     lon = tuple(float(x) for x in os.environ.get("TUNE_LON", "200,300").split(","))
