@@ -1,0 +1,116 @@
+"""
+GPU tests at BASELINE.json's full sizes (2048^2 small image, 3072^2 reference, 2048^2 Carrington grid).
+The oracle needs seconds per lag-point at this size, so the sweeps are checked through size-independent
+properties (LDS vs global gather, slice concatenation, header-offset/lag equivalence, self-correlation = 1)
+plus oracle spot checks on a few lag-points.
+"""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+LON, LAT, SHAPE = (200.0, 300.0), (-20.0, 20.0), (2048, 2048)
+
+
+@pytest.fixture(scope="module")
+def big_scene():
+    from euispice_coreg_amd import synthetic
+    return synthetic.make_scene()
+
+
+@pytest.fixture(scope="module")
+def carr_ready(gpu_handle, big_scene):
+    from euispice_coreg_amd import _lib
+    small, hs, large, hl, truth = big_scene
+    grid = _lib.Grid(LON, LAT, SHAPE)
+    gpu_handle.set_small(small)
+    gpu_handle.prepare_reference_carrington(large, hl, grid, 1.004, 2)
+    return grid
+
+
+def _sweep(h, hs, grid, lags, **kw):
+    from euispice_coreg_amd import _lib
+    ls = _lib.LagSet(*lags)
+    out = h.sweep_carrington(hs, grid, 1.004, ls, **kw)
+    return out.reshape(ls.shape) if "lag_begin" not in kw else out
+
+
+def test_headline_size_properties(gpu_handle, big_scene, carr_ready):
+    small, hs, large, hl, truth = big_scene
+    grid = carr_ready
+    lags = (np.arange(9, 25, 1.0), np.arange(-17, -1, 1.0), None, None, None)  # 16 x 16 around the injected shift
+    full = _sweep(gpu_handle, hs, grid, lags)
+    assert np.isfinite(full).all()
+    am = np.unravel_index(np.argmax(full), full.shape)
+    assert (lags[0][am[0]], lags[1][am[1]]) == (truth["lag_crval1"], truth["lag_crval2"])
+    st = gpu_handle.last_stats()
+    assert st["used_lds"] == 1 and 0 < st["n_active_points"] < st["n_grid_points"]
+    # (1) LDS-window gather == global-memory gather (same arithmetic, same order)
+    gpu_handle.set_option("use_lds", 0)
+    try:
+        glob = _sweep(gpu_handle, hs, grid, lags)
+    finally:
+        gpu_handle.set_option("use_lds", 1)
+    assert np.abs(glob - full).max() <= 1e-13
+    # (2) np.array_split-style slices concatenate to the full map
+    n = full.size
+    parts = [_sweep(gpu_handle, hs, grid, lags, lag_begin=lo, lag_end=hi) for lo, hi in [(0, 100), (100, 101), (101, n)]]
+    assert np.abs(np.concatenate(parts) - full.ravel()).max() <= 1e-12
+    # (3) moving 2 arcsec from the header into the lags changes nothing: hdr(CRVAL + 2) x lag l == hdr x lag (l + 2)
+    hs2 = dict(hs)
+    hs2["CRVAL1"] += 2.0
+    hs2["CRVAL2"] -= 3.0
+    lags2 = (lags[0] - 2.0, lags[1] + 3.0, None, None, None)
+    moved = _sweep(gpu_handle, hs2, grid, lags2)
+    assert np.abs(moved - full).max() <= 1e-10
+    # (4) repeated calls are bit-identical (static schedule, fixed summation order)
+    again = _sweep(gpu_handle, hs, grid, lags)
+    assert np.array_equal(again, full)
+
+
+def test_headline_size_oracle_spot_check(gpu_handle, big_scene, carr_ready):
+    """Three lag-points of the headline workload against the oracle (float64 both sides, NumPy lat trig): 1e-10."""
+    from oracle import coreg_oracle as O
+    small, hs, large, hl, truth = big_scene
+    grid = carr_ready
+    st = H.oracle_state(small, hs, large, hl, ([0.0], [0.0], None, None, None), shape=list(SHAPE), lonlims=list(LON),
+                        latlims=list(LAT), solar_r=(1.004,))
+    O.set_initial_header_values(st)
+    ref = O.prepare_reference(st, "carrington", 1.004)
+    a = gpu_handle.get_reference_on_grid(ref.shape, np.float64)
+    m = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(a), m)
+    assert np.abs(a[m] - ref[m]).max() <= 1e-9 * np.nanmax(ref)
+    for d1, d2, dr in [(17.0, -9.0, 0.0), (-30.0, 29.0, 0.0), (5.0, 5.0, 0.3)]:
+        want = O.step(st, "carrington", st.data_small, ref, d1, d2, 0.0, 0.0, dr, 1.004)
+        got = _sweep(gpu_handle, hs, grid, ([d1], [d2], None, None, [dr]))[0, 0, 0, 0, 0]
+        assert abs(got - want) <= 1e-10, (d1, d2, dr, got, want)
+
+
+def test_helioprojective_full_size(gpu_handle, big_scene):
+    """Config 2 size (2048^2 vs 3072^2, sub-map semantics): oracle spot check + self-correlation property."""
+    from euispice_coreg_amd import _lib
+    from oracle import coreg_oracle as O
+    small, hs, large, hl, truth = big_scene
+    lags = (np.array([13.0, 17.0, 21.0]), np.array([-13.0, -9.0, -5.0]), None, None, [0.0, 0.3])
+    got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags)
+    assert np.isfinite(got).all() and got.shape == (3, 3, 1, 1, 2, 1)
+    am = np.unravel_index(np.argmax(got), got.shape)
+    assert (am[0], am[1], am[4]) == (1, 1, 1)  # injected (17, -9) arcsec, +0.3 deg
+    st = H.oracle_state(small, hs, large, hl, lags)
+    O.set_initial_header_values(st)
+    sub = O.create_submap_of_large_data(st)
+    a = gpu_handle.get_reference_on_grid(sub.shape, np.float32)
+    m = np.isfinite(sub)
+    assert np.array_equal(np.isfinite(a), m)
+    assert np.abs(a[m].astype(np.float64) - sub[m]).max() <= 2e-7 * np.abs(sub[m]).max()
+    want = O.step(st, "helioprojective", st.data_small, sub, 17.0, -9.0, 0.0, 0.0, 0.3, 1.004)
+    assert abs(got[1, 1, 0, 0, 1, 0] - want) <= 1e-7
+    # self-correlation: the small image against its own (un-prefiltered B-spline) resample on its own grid -> r = 1
+    gpu_handle.prepare_reference_helioprojective(small, hs, hs, 2)
+    ls = _lib.LagSet([-2.0, 0.0, 2.0], [-2.0, 0.0, 2.0], None, None, None)
+    self_corr = gpu_handle.sweep_helioprojective(hs, hs, ls).reshape(3, 3)
+    assert abs(self_corr[1, 1] - 1.0) <= 1e-12
+    assert np.argmax(self_corr) == 4 and (self_corr[self_corr != self_corr[1, 1]] < 1.0 - 1e-6).all()
