@@ -86,6 +86,8 @@ SYMBOLS = [
     ("coreg_shift_header", C.c_int,
      [_WP, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _WP]),
     ("coreg_homography", C.c_int, [_WP, _WP, C.POINTER(C.c_double)]),
+    ("coreg_lag_homography", C.c_int,
+     [_WP, _WP, C.POINTER(Lags), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
     ("coreg_carrington_origin", C.c_int, [_WP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 ]
 
@@ -329,6 +331,17 @@ def homography(hdr_from, hdr_to):
     if rc != COREG_OK:
         raise CoregError(rc, "coreg_homography")
     return np.array(h[:]).reshape(3, 3)
+
+
+def lag_homography(hdr_target, hdr_small, lags: "LagSet", idx, cdelt_semantics=CDELT_INTENDED):
+    lib = load_library()
+    a, b = wcs_from_header(hdr_target), wcs_from_header(hdr_small)
+    ii = (C.c_int32 * 5)(*[int(i) for i in idx])
+    h = (C.c_double * 9)()
+    rc = lib.coreg_lag_homography(C.byref(a), C.byref(b), C.byref(lags.c), ii, cdelt_semantics, h)
+    if rc < 0:
+        raise CoregError(rc, "coreg_lag_homography")
+    return rc, np.array(h[:]).reshape(3, 3)
 
 
 def carrington_origin(hdr):

@@ -1062,6 +1062,10 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     std::vector<double> hs;  // AoS while building
     int n_batches = 0;
     double fx0 = 1e300, fx1 = -1e300, fy0 = 1e300, fy1 = -1e300;  // cull box in target pixels
+    HomographyFamily fam;
+    fam.init(*hdr_target, *hdr_small, lags->crval1, d.n1, lags->crval2, d.n2);
+    const int i1_lo = (int)(lag_begin / row), i1_hi = (int)((lag_end - 1) / row);
+    const double nanv = std::numeric_limits<double>::quiet_NaN();
     for (long long c = 0; c < d.nc; ++c) {
         const long long first = (lag_begin - c + d.nc - 1) / d.nc;
         if (first * d.nc + c >= lag_end) continue;
@@ -1071,30 +1075,38 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                          &hc))
             continue;
         build_slots(d, c, lag_begin, lag_end, plan.sw, plan.sh, &slots);
+        if (slots.n_batches == 0) continue;
+        const Mat3d B = HomographyFamily::combo(hc);
+        const size_t at = hs.size();
+        hs.resize(at + 9 * slots.i1.size());
         for (size_t s = 0; s < slots.i1.size(); ++s) {
-            coreg_wcs2d hl = hc;
-            hl.crval1 = hdr_small->crval1 + lags->crval1[slots.i1[s]];
-            hl.crval2 = hdr_small->crval2 + lags->crval2[slots.i2[s]];
-            double hm[9];
-            homography(*hdr_target, hl, hm);
+            double* hm = &hs[at + 9 * s];
             if (slots.outidx[s] < 0) {  // padding lane: NaN map -> never in bounds
-                for (int k = 0; k < 9; ++k) hm[k] = std::numeric_limits<double>::quiet_NaN();
-                hs.insert(hs.end(), hm, hm + 9);
-                continue;
-            }
-            hs.insert(hs.end(), hm, hm + 9);
-            // inverse map of the small image's corners -> which target pixels can ever be in bounds
-            double hi[9];
-            homography(hl, *hdr_target, hi);
-            for (int k = 0; k < 4; ++k) {
-                double px, py;
-                apply_h(hi, (k & 1) ? (double)(h->sW - 1) : 0.0, (k & 2) ? (double)(h->sH - 1) : 0.0, &px, &py);
-                fx0 = std::min(fx0, px);
-                fx1 = std::max(fx1, px);
-                fy0 = std::min(fy0, py);
-                fy1 = std::max(fy1, py);
+                for (int k = 0; k < 9; ++k) hm[k] = nanv;
+            } else {
+                fam.get(B, slots.i1[s], slots.i2[s], hm);
             }
         }
+        // which target pixels can ever be in bounds: inverse maps of the small image's corners for the lags on the
+        // boundary of the (CRVAL1, CRVAL2) rectangle (corners + edge midpoints + centre; the maps vary smoothly and
+        // monotonically with the lag, the +-3 px margin below covers the curvature in between)
+        const int e1[3] = {i1_lo, (i1_lo + i1_hi) / 2, i1_hi}, e2[3] = {0, (d.n2 - 1) / 2, d.n2 - 1};
+        for (int a1 = 0; a1 < 3; ++a1)
+            for (int a2 = 0; a2 < 3; ++a2) {
+                coreg_wcs2d hl = hc;
+                hl.crval1 = hdr_small->crval1 + lags->crval1[e1[a1]];
+                hl.crval2 = hdr_small->crval2 + lags->crval2[e2[a2]];
+                double hi[9];
+                homography(hl, *hdr_target, hi);
+                for (int k = 0; k < 4; ++k) {
+                    double px, py;
+                    apply_h(hi, (k & 1) ? (double)(h->sW - 1) : 0.0, (k & 2) ? (double)(h->sH - 1) : 0.0, &px, &py);
+                    fx0 = std::min(fx0, px);
+                    fx1 = std::max(fx1, px);
+                    fy0 = std::min(fy0, py);
+                    fy1 = std::max(fy1, py);
+                }
+            }
         outidx.insert(outidx.end(), slots.outidx.begin(), slots.outidx.end());
         n_batches += slots.n_batches;
     }
@@ -1113,11 +1125,11 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     }
     fill_precompute_common(h, &pa, plan.tile_w);
     const int n_tiles = pa.tiles_x * pa.tiles_y;
-    // the maps are projective and the image corners bound its interior: +-2 px guards rounding of the inverse
-    pa.f0lo = std::floor(fx0) - 2.0;
-    pa.f0hi = std::ceil(fx1) + 2.0;
-    pa.f1lo = std::floor(fy0) - 2.0;
-    pa.f1hi = std::ceil(fy1) + 2.0;
+    // the maps are projective and the image corners bound its interior
+    pa.f0lo = std::floor(fx0) - 3.0;
+    pa.f0hi = std::ceil(fx1) + 3.0;
+    pa.f1lo = std::floor(fy0) - 3.0;
+    pa.f1hi = std::ceil(fy1) + 3.0;
     RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles));
     RETCHK(launch_sweep(h, MODE_HOMOGRAPHY, order, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
                         n_tiles, lag_begin, out_dev));
@@ -1140,6 +1152,22 @@ int coreg_shift_header(const coreg_wcs2d* ref, double d_crval1, double d_crval2,
 int coreg_homography(const coreg_wcs2d* from, const coreg_wcs2d* to, double* h9) {
     if (!from || !to || !h9) return COREG_EINVAL;
     homography(*from, *to, h9);
+    return COREG_OK;
+}
+
+int coreg_lag_homography(const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_small, const coreg_lags* lags,
+                         const int32_t idx[5], int cdelt_semantics, double* h9) {
+    if (!hdr_target || !hdr_small || !lags || !idx || !h9) return COREG_EINVAL;
+    if (idx[0] < 0 || idx[0] >= lags->n_crval1 || idx[1] < 0 || idx[1] >= lags->n_crval2 || idx[2] < 0 ||
+        idx[2] >= lags->n_cdelt1 || idx[3] < 0 || idx[3] >= lags->n_cdelt2 || idx[4] < 0 || idx[4] >= lags->n_crota)
+        return COREG_EINVAL;
+    coreg_wcs2d hc;
+    if (shift_header(*hdr_small, 0.0, 0.0, lags->cdelt1[idx[2]], lags->cdelt2[idx[3]], lags->crota[idx[4]],
+                     cdelt_semantics, &hc))
+        return 1;
+    HomographyFamily fam;
+    fam.init(*hdr_target, *hdr_small, lags->crval1, lags->n_crval1, lags->crval2, lags->n_crval2);
+    fam.get(HomographyFamily::combo(hc), idx[0], idx[1], h9);
     return COREG_OK;
 }
 

@@ -129,6 +129,63 @@ inline void homography(const coreg_wcs2d& from, const coreg_wcs2d& to, double h[
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) h[3 * i + j] = (double)(m.m[i][j] / s);
 }
+// The same homography for a whole lag sweep, factored so that the per-lag cost is two 3x3 products and no trig:
+//   H(lag) = [iwc_to_pix(to) * Ninv] * [Rz(phi_p) * T(delta)] * [Rz(-alpha) * R(from) * N * pix_to_iwc(from)]
+//             B: per (cdelt, crota) combo    P: depends on CRVAL2 only     Q: depends on CRVAL1 only
+// (native_to_celestial(to)^T = Rz(phi_p) * T(delta_p) * Rz(-alpha_p), T symmetric).  alpha = CRVAL1 + lag1[i1],
+// delta = CRVAL2 + lag2[i2] in the shifted header (alignment.py:404, :412).
+struct Mat3d {
+    double m[3][3];
+};
+inline Mat3d to_double(const Mat3& a) {
+    Mat3d r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r.m[i][j] = (double)a.m[i][j];
+    return r;
+}
+inline Mat3d mul3(const Mat3d& a, const Mat3d& b) {
+    Mat3d r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+    return r;
+}
+struct HomographyFamily {
+    std::vector<Mat3d> Q;  // [n1]
+    std::vector<Mat3d> P;  // [n2]
+    // from: header whose pixel grid is mapped (target grid); ref: unshifted header being lagged
+    void init(const coreg_wcs2d& from, const coreg_wcs2d& ref, const double* lag1, int n1, const double* lag2,
+              int n2) {
+        const Mat3 N = {{{0, -1, 0}, {1, 0, 0}, {0, 0, 1}}};
+        const Mat3 m1 = mat_mul(native_to_celestial(from), mat_mul(N, pix_to_iwc(from)));
+        const ld d2r = (ld)kPi / 180.0L;
+        Q.resize(n1);
+        for (int i = 0; i < n1; ++i) {
+            const ld ap = (ld)(ref.crval1 + lag1[i]) * (ld)ref.unit_to_deg * d2r;  // float64 sum as alignment.py:404
+            const Mat3 rz = {{{cosl(ap), sinl(ap), 0}, {-sinl(ap), cosl(ap), 0}, {0, 0, 1}}};  // Rz(-alpha)
+            Q[i] = to_double(mat_mul(rz, m1));
+        }
+        const ld pp = (ld)ref.lonpole * d2r;
+        const Mat3 rzp = {{{cosl(pp), -sinl(pp), 0}, {sinl(pp), cosl(pp), 0}, {0, 0, 1}}};  // Rz(phi_p)
+        P.resize(n2);
+        for (int j = 0; j < n2; ++j) {
+            const ld dp = (ld)(ref.crval2 + lag2[j]) * (ld)ref.unit_to_deg * d2r;  // alignment.py:412
+            const Mat3 t = {{{-sinl(dp), 0, cosl(dp)}, {0, -1, 0}, {cosl(dp), 0, sinl(dp)}}};
+            P[j] = to_double(mat_mul(rzp, t));
+        }
+    }
+    // per (cdelt, crota) combination: B = iwc_to_pix(shifted header) * Ninv
+    static Mat3d combo(const coreg_wcs2d& shifted) {
+        const Mat3 Ninv = {{{0, 1, 0}, {-1, 0, 0}, {0, 0, 1}}};
+        return to_double(mat_mul(iwc_to_pix(shifted), Ninv));
+    }
+    void get(const Mat3d& B, int i1, int i2, double h[9]) const {
+        const Mat3d m = mul3(B, mul3(P[i2], Q[i1]));
+        const double s = 1.0 / m.m[2][2];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) h[3 * i + j] = m.m[i][j] * s;
+    }
+};
+
 inline void apply_h(const double h[9], double x, double y, double* ox, double* oy) {
     const double w = h[6] * x + h[7] * y + h[8];
     *ox = (h[0] * x + h[1] * y + h[2]) / w;

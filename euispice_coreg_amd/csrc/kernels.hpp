@@ -78,7 +78,10 @@ __device__ __forceinline__ bool carr_term(const CarrDev& c, int i, int j, double
 
 __device__ __forceinline__ void apply_h(const H9& m, double x, double y, double& ox, double& oy) {
     const double w = fma(m.h[6], x, fma(m.h[7], y, m.h[8]));
-    const double r = 1.0 / w;
+    // w = 1 + O(1e-5) (h[8] = 1, small fields of view): hardware reciprocal + one Newton step is accurate to ~1 ulp
+    // there, far below the 1e-9 px the map itself is known to; a NaN map stays NaN
+    double r = __builtin_amdgcn_rcp(w);
+    r = fma(r, fma(-w, r, 1.0), r);
     ox = fma(m.h[0], x, fma(m.h[1], y, m.h[2])) * r;
     oy = fma(m.h[3], x, fma(m.h[4], y, m.h[5])) * r;
 }

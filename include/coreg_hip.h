@@ -164,10 +164,15 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value);
  *                           the worker (d_cdelt2 != 0), else 0
  *   coreg_homography        0-based pixels of `from` -> 0-based pixels of `to` through the sky, row-major 3x3 with
  *                           h[8] = 1: WCS(to).world_to_pixel(WCS(from).pixel_to_world(p)), alignment.py:1041-1065
+ *   coreg_lag_homography    the map the helioprojective sweep gives lag-point idx = (i_crval1, i_crval2, i_cdelt1,
+ *                           i_cdelt2, i_crota): pixels of hdr_target -> pixels of _shift_header(hdr_small, lag)
+ *                           (factored evaluation used by the sweep); returns 1 for a lag the reference cannot evaluate
  *   coreg_carrington_origin X0, Y0 of utils/rectify.py:399-404 */
 int coreg_shift_header(const coreg_wcs2d* ref, double d_crval1, double d_crval2, double d_cdelt1, double d_cdelt2,
                        double d_crota, int cdelt_semantics, coreg_wcs2d* out);
 int coreg_homography(const coreg_wcs2d* from, const coreg_wcs2d* to, double* h9);
+int coreg_lag_homography(const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_small, const coreg_lags* lags,
+                         const int32_t idx[5], int cdelt_semantics, double* h9);
 int coreg_carrington_origin(const coreg_wcs2d* hdr, double* x0, double* y0);
 
 #ifdef __cplusplus

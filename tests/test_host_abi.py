@@ -116,6 +116,27 @@ def test_homography_matches_wcslib_golden(lib, wcs_golden):
         assert np.abs((hm[1, 0] * gx + hm[1, 1] * gy + hm[1, 2]) / w - g[tag + "/y"]).max() < 1e-9, tag
 
 
+def test_lag_homography_family_matches_direct(lib):
+    """The factored per-lag map used by the sweep (B * P[i2] * Q[i1]) == the direct composition == the oracle."""
+    st = _state()
+    lags = lib.LagSet(np.arange(-30, 31, 6.0), np.arange(-30, 31, 10.0), [0.0, 0.01], [-0.02, 0.0], [-0.5, 0.0, 0.75])
+    jj, ii = np.mgrid[0:st.hdr_small["NAXIS2"], 0:st.hdr_small["NAXIS1"]].astype(float)
+    for idx in [(0, 0, 0, 0, 0), (10, 6, 1, 0, 2), (5, 3, 0, 1, 1), (7, 2, 1, 1, 0)]:
+        d = [lags.arrays[k][idx[k]] for k in range(5)]
+        hdr = dict(st.hdr_small)
+        O.shift_header(st, hdr, d[0], d[1], d[2], d[3], d[4])
+        rc, hm = lib.lag_homography(st.hdr_small, st.hdr_small, lags, idx)
+        assert rc == 0
+        direct = lib.homography(st.hdr_small, hdr)
+        w = hm[2, 0] * ii + hm[2, 1] * jj + hm[2, 2]
+        wd = direct[2, 0] * ii + direct[2, 1] * jj + direct[2, 2]
+        xf, xd = (hm[0, 0] * ii + hm[0, 1] * jj + hm[0, 2]) / w, (direct[0, 0] * ii + direct[0, 1] * jj + direct[0, 2]) / wd
+        yf, yd = (hm[1, 0] * ii + hm[1, 1] * jj + hm[1, 2]) / w, (direct[1, 0] * ii + direct[1, 1] * jj + direct[1, 2]) / wd
+        assert np.abs(xf - xd).max() < 1e-9 and np.abs(yf - yd).max() < 1e-9, idx
+        x, y = O.extract_coordinates_pixels(st.hdr_small, hdr)
+        assert np.abs(xf - x).max() < 1e-9 and np.abs(yf - y).max() < 1e-9, idx
+
+
 def test_carrington_origin_matches_oracle(lib):
     st = _state()
     hdr = dict(st.hdr_small)
