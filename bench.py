@@ -94,10 +94,17 @@ def main():
     import torch.distributed as dist
     from euispice_coreg_amd import _lib, synthetic
 
+    # COREG_BENCH_BACKEND=gloo: rehearse the N > 1 path on a box with fewer GPUs than ranks (ranks share devices,
+    # the all-gather runs on the CPU); the driver's runs use the default, nccl (= RCCL over xGMI)
+    backend = os.environ.get("COREG_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     t0 = time.time()
     small, hs, large, hl, truth = synthetic.make_scene()
@@ -123,11 +130,18 @@ def main():
     mine = torch.full((chunk,), float("nan"), dtype=torch.float64, device="cuda")
     gathered = torch.empty((chunk * world,), dtype=torch.float64, device="cuda") if world > 1 else mine
 
+    gathered_host = [None]
+
     def step():
         h.sweep_carrington(hs, grid, SOLAR_R, lagset, order=ORDER, lag_begin=lo, lag_end=hi,
                            out_dev_ptr=mine.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, mine)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, mine)  # the ONE collective of the path
+            else:
+                parts = [torch.empty(chunk, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(parts, mine.cpu())
+                gathered_host[0] = torch.cat(parts)
 
     for _ in range(args.warmup):
         step()
@@ -146,11 +160,12 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stats = h.last_stats()
-    corr = gathered[:L].cpu().numpy()  # chunk = ceil(L / world): only the last non-empty slice is ragged
+    # chunk = ceil(L / world): only the last non-empty slice is ragged, so the map is the first L gathered values
+    corr = (gathered_host[0] if gathered_host[0] is not None else gathered)[:L].cpu().numpy()
     corr = corr.reshape(lag1.size, lag2.size)
 
     if rank == 0:
