@@ -96,10 +96,12 @@ struct Spline<2> {
     static __device__ __forceinline__ void eval(double c, int& start, double w[3]) {
         const double f = floor(c + 0.5);
         const double t = c - f;
-        w[1] = 0.75 - t * t;
-        const double y = 0.5 - t;
-        w[0] = 0.5 * y * y;
-        w[2] = 1.0 - w[0] - w[1];
+        // scipy: w1 = 0.75 - t^2, w0 = 0.5 (0.5 - t)^2, w2 = 1 - w0 - w1 (= 0.5 (0.5 + t)^2 = w0 + t); evaluated here
+        // in 5 operations, equal to scipy's values to ~1 ulp
+        const double u = t * t;
+        w[1] = 0.75 - u;
+        w[0] = fma(0.5, u, fma(-0.5, t, 0.125));
+        w[2] = w[0] + t;
         start = (int)f - 1;
     }
 };
@@ -455,7 +457,9 @@ struct Taps<2> {
 // simply skip -- no selects, no clamped addresses.
 // LDS path: the float64 window (mirrored apron included, pivot already subtracted unless ROUND) lives at LDS byte
 // address `win`; element (r, c) is at r*pitch + c.
-template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND>
+// INTERIOR: the caller has proved that every (point of the tile) x (lag of the workgroup) is inside the image, so the
+// bounds rule cannot trigger and is not evaluated (padding lanes never get here).
+template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool INTERIOR = false>
 __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                           int ox, int oy, int W, int H, double wmax, double hmax, double px0, double py0,
                                           const H9& hm, double b0, double b1, double av, double pivot_b) {
@@ -467,7 +471,7 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
     } else {
         apply_h(hm, b0, b1, nx, ny);
     }
-    if ((nx >= 0.0) & (nx <= wmax) & (ny >= 0.0) & (ny <= hmax)) {
+    if (INTERIOR || ((nx >= 0.0) & (nx <= wmax) & (ny >= 0.0) & (ny <= hmax))) {
         int sx, sy;
         double wx[N], wy[N];
         double v = 0.0;
@@ -530,7 +534,7 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
 
 // Walk this point-group's share of the compacted points of one tile: chunks of kChunk points, chunk c belongs to
 // point-group (c % kPointGroups).  Point data are wave-uniform: the loads below use uniform addresses (scalar loads).
-template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND>
+template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool INTERIOR = false>
 __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                             int ox, int oy, int W, int H, double px0, double py0,
                                             const H9& hm, const Pt* __restrict__ pts, int cnt, double pivot_b, int pg) {
@@ -546,15 +550,15 @@ __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __
         for (int k = 0; k < kChunk; ++k) pt[k] = q[k];
 #pragma unroll
         for (int k = 0; k < kChunk; ++k)
-            point_lag<MODE, ORDER, TS, LDS, ROUND>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0, py0,
-                                                   hm, pt[k].b0, pt[k].b1, pt[k].a, pivot_b);
+            point_lag<MODE, ORDER, TS, LDS, ROUND, INTERIOR>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0, py0,
+                                                             hm, pt[k].b0, pt[k].b1, pt[k].a, pivot_b);
     }
     // ragged tail (< kChunk points): owned by the point-group next in the rotation
     if (pg == n_full % kPointGroups) {
         for (int p = n_full * kChunk; p < cnt; ++p) {
             const Pt pt = pts[p];
-            point_lag<MODE, ORDER, TS, LDS, ROUND>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0, py0,
-                                                   hm, pt.b0, pt.b1, pt.a, pivot_b);
+            point_lag<MODE, ORDER, TS, LDS, ROUND, INTERIOR>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0, py0,
+                                                             hm, pt.b0, pt.b1, pt.a, pivot_b);
         }
     }
 }
@@ -590,6 +594,9 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) hm.h[k] = a.lane_params[(long long)k * a.n_slots + slot];
     }
+
+    // padding lanes carry NaN parameters (never in bounds)
+    const bool pad_lane = MODE == MODE_TRANSLATE ? (px0 != px0) : (hm.h[8] != hm.h[8]);
 
     Acc acc = {0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
@@ -646,6 +653,8 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
         mxy = fmax(fmax(wred[0][3], wred[1][3]), fmax(wred[2][3], wred[3][3]));
         // no in-bounds sample possible for this (tile, batch)?  (uniform)
         if (!(mxx >= 0.0) || !(mnx <= (double)(W - 1)) || !(mxy >= 0.0) || !(mny <= (double)(H - 1))) continue;
+        // every (point, lag) of this visit inside the image?  (uniform; the box covers all non-padding lanes)
+        const bool interior = (mnx >= 0.0) & (mxx <= (double)(W - 1)) & (mny >= 0.0) & (mxy <= (double)(H - 1));
         // integer window with the mirrored apron: taps of in-bounds samples lie in [floor(c)-1, floor(c)+2]
         const int ox = max((int)floor(fmax(mnx, 0.0)) - 1, -1);
         const int oy = max((int)floor(fmax(mny, 0.0)) - 1, -1);
@@ -669,8 +678,14 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
                 }
             }
             __syncthreads();
-            tile_points<MODE, ORDER, TS, true, ROUND>(acc, win, img, pitch, ox, oy, W, H, px0, py0, hm, pts,
-                                                      cnt, pivot_b, pg);
+            if (interior) {
+                if (!pad_lane)
+                    tile_points<MODE, ORDER, TS, true, ROUND, true>(acc, win, img, pitch, ox, oy, W, H, px0, py0, hm,
+                                                                    pts, cnt, pivot_b, pg);
+            } else {
+                tile_points<MODE, ORDER, TS, true, ROUND>(acc, win, img, pitch, ox, oy, W, H, px0, py0, hm, pts, cnt,
+                                                          pivot_b, pg);
+            }
         } else {
             tile_points<MODE, ORDER, TS, false, ROUND>(acc, win, img, 0, 0, 0, W, H, px0, py0, hm, pts, cnt,
                                                        pivot_b, pg);
