@@ -76,6 +76,7 @@ SYMBOLS = [
     ("coreg_get_reference_on_grid", C.c_int, [_P, _P, C.c_int]),
     ("coreg_resample_carrington", C.c_int, [_P, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int, _P]),
     ("coreg_resample_helioprojective", C.c_int, [_P, _WP, _WP, C.c_int, _P]),
+    ("coreg_resample_helioprojective_f64", C.c_int, [_P, _WP, _WP, C.c_int, _P]),
     ("coreg_sweep_carrington", C.c_int,
      [_P, _WP, C.POINTER(CarrGrid), C.c_double, C.POINTER(Lags), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P,
       C.c_int]),
@@ -269,11 +270,12 @@ class CoregHandle:
                                                       out.ctypes.data))
         return out
 
-    def resample_helioprojective(self, hdr_target, hdr, order=2):
+    def resample_helioprojective(self, hdr_target, hdr, order=2, dtype=np.float32):
         wt, w = wcs_from_header(hdr_target), wcs_from_header(hdr)
-        out = np.empty((wt.naxis2, wt.naxis1), dtype=np.float32)
-        self._chk(self._lib.coreg_resample_helioprojective(self._h, C.byref(wt), C.byref(w), int(order),
-                                                           out.ctypes.data))
+        out = np.empty((wt.naxis2, wt.naxis1), dtype=dtype)
+        fn = self._lib.coreg_resample_helioprojective if out.dtype == np.float32 else \
+            self._lib.coreg_resample_helioprojective_f64
+        self._chk(fn(self._h, C.byref(wt), C.byref(w), int(order), out.ctypes.data))
         return out
 
     # -- sweeps

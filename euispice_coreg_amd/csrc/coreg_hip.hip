@@ -841,8 +841,8 @@ int coreg_resample_carrington(coreg_handle* h, const coreg_wcs2d* hdr, const cor
     return COREG_OK;
 }
 
-int coreg_resample_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr, int order,
-                                   float* out) {
+static int resample_helio(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr, int order, void* out,
+                          bool out_f32) {
     if (!h) return COREG_EINVAL;
     if (!hdr_target || !hdr || !out) return fail(h, COREG_EINVAL, "resample_helioprojective: bad argument");
     if (!h->small.p) return fail(h, COREG_ESTATE, "coreg_set_small has not been called");
@@ -857,13 +857,23 @@ int coreg_resample_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_targe
     a.H = h->sH;
     a.gw = hdr_target->naxis1;
     a.gh = hdr_target->naxis2;
-    const size_t bytes = (size_t)a.gw * a.gh * sizeof(float);
+    const size_t bytes = (size_t)a.gw * a.gh * (out_f32 ? sizeof(float) : sizeof(double));
     HIPCHK(h->out_dev.reserve(bytes));
     a.out = h->out_dev.p;
-    RETCHK(dispatch_resample(h, MODE_HOMOGRAPHY, order, h->small_f32, true, a, 0));
+    RETCHK(dispatch_resample(h, MODE_HOMOGRAPHY, order, h->small_f32, out_f32, a, 0));
     HIPCHK(hipMemcpyAsync(out, h->out_dev.p, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return COREG_OK;
+}
+
+int coreg_resample_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr, int order,
+                                   float* out) {
+    return resample_helio(h, hdr_target, hdr, order, out, true);
+}
+
+int coreg_resample_helioprojective_f64(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr,
+                                       int order, double* out) {
+    return resample_helio(h, hdr_target, hdr, order, out, false);
 }
 
 int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const coreg_carr_grid* grid, double solar_r,

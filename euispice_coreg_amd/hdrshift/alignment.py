@@ -25,7 +25,7 @@ import warnings
 import numpy as np
 
 from .. import _lib, parallel
-from ..utils import fits_io, header as hdrutil
+from ..utils import fits_io, header as hdrutil, wcs_tan
 from .alignment_results import AlignmentResults
 
 
@@ -152,14 +152,11 @@ class Alignment:
     def align_using_helioprojective(self, method="correlation", return_type="AlignmentResults", fov_limits=None,
                                     remove_fov_limits=None):
         """alignment.py:263-342."""
-        if fov_limits is not None or remove_fov_limits is not None:
-            raise NotImplementedError("fov_limits / remove_fov_limits (alignment.py:863-874, 1082-1127) are not "
-                                      "implemented in the GPU path yet")
         self.lonlims = self.latlims = self.shape = self.reference_date = None
         self.method = method
         self.coordinate_frame = "final_helioprojective"
         self._load()
-        results = self._find_best_header_parameters()
+        results = self._find_best_header_parameters(fov_limits=fov_limits, remove_fov_limits=remove_fov_limits)
         return self._wrap(results, return_type, restore_units=True)
 
     def align_using_initial_carrington(self, method="correlation", return_type="AlignmentResults"):
@@ -184,7 +181,47 @@ class Alignment:
                                 reference_image_window=self.large_fov_window)
 
     # ------------------------------------------------------------------------------------------------------------
-    def _find_best_header_parameters(self, ang2pipi=True):
+    def _set_remove_fov_limits_to_nan(self, remove_fov_limits):
+        """alignment.py:863-874: pixels of the small image inside the lon/lat box -> NaN.  Limits: astropy Quantities
+        or plain numbers in the input lag unit."""
+        lon, lat = wcs_tan.pixel_lonlat(self.hdr_small)
+        lonl = wcs_tan._lims_deg(remove_fov_limits[0], self.unit_lag_input)
+        latl = wcs_tan._lims_deg(remove_fov_limits[1], self.unit_lag_input)
+        inside = (lon >= lonl[0]) & (lon <= lonl[1]) & (lat >= latl[0]) & (lat <= latl[1])
+        self.data_small[inside] = np.nan
+
+    def _select_fov_in_small_data(self, fov_limits, handle):
+        """alignment.py:1082-1127: re-grid the small image on a regular lon/lat grid restricted to `fov_limits`
+        (new header: PC = identity, CROTA = 0).  Literal restatement, including the reference's use of the ROW count
+        for CRPIX1 / NAXIS1 (it mixes the two axes, harmless for square selections).  The resample runs on the GPU."""
+        h = self.hdr_small
+        lon, lat = wcs_tan.pixel_lonlat(h)
+        lonl = wcs_tan._lims_deg(fov_limits[0], self.unit_lag_input)
+        latl = wcs_tan._lims_deg(fov_limits[1], self.unit_lag_input)
+        long, latg, dlon, dlat = wcs_tan.build_regular_grid(lon, lat, lonl, latl)
+        if long.size == 0:
+            raise ValueError("fov_limits select no pixel of the small image")
+        mid = [long.shape[0] // 2, long.shape[1] // 2]
+        hg = h.copy()
+        u1, u2 = hdrutil.unit_to_deg(h["CUNIT1"]), hdrutil.unit_to_deg(h["CUNIT2"])
+        hg["CRVAL1"] = float(long[mid[0], mid[1]]) / u1
+        hg["CRVAL2"] = float(latg[mid[0], mid[1]]) / u2
+        hg["CRPIX1"] = mid[0] + 1
+        hg["CRPIX2"] = mid[1] + 1
+        hg["CDELT1"] = float(dlon) / u1
+        hg["CDELT2"] = float(dlat) / u2
+        hg["PC1_1"], hg["PC2_2"], hg["PC1_2"], hg["PC2_1"] = 1.0, 1.0, 0.0, 0.0
+        hg["CROTA"] = 0.0
+        hg["CROTA2"] = 0.0
+        hg["NAXIS1"] = long.shape[0]
+        hg["NAXIS2"] = long.shape[1]
+        hg.pop("ZNAXIS1", None)
+        hg.pop("ZNAXIS2", None)
+        handle.set_small(self.data_small)
+        self.data_small = handle.resample_helioprojective(hg, h, order=self.order, dtype=np.float64)
+        self.hdr_small = hg
+
+    def _find_best_header_parameters(self, ang2pipi=True, fov_limits=None, remove_fov_limits=None):
         """alignment.py:613-797 on the GPU.  Returns float64 [n_crval1, n_crval2, n_cdelt1, n_cdelt2, n_crota,
         n_solar_r]; lag-points the library could not evaluate are NaN, never 0 (quirk Q9)."""
         if self.method == "residus":
@@ -192,7 +229,20 @@ class Alignment:
                                       "quirk Q8) is not implemented on the GPU")
         if self.method != "correlation":
             raise NotImplementedError  # alignment.py:549
+        device = self.device
+        rank, world = parallel.world_info()
+        if device is None:
+            device = -1
+            if world > 1:
+                import torch
+                device = torch.cuda.current_device()
+        # alignment.py:844-861: thresholds, then the box to remove, then the sub-FOV re-grid
         hdrutil.set_threshold_minmax_to_nan(self.data_small, self.small_fov_value_min, self.small_fov_value_max)
+        if remove_fov_limits is not None:
+            self._set_remove_fov_limits_to_nan(remove_fov_limits)
+        if fov_limits is not None:
+            with _lib.CoregHandle(device) as h0:
+                self._select_fov_in_small_data(fov_limits, h0)
         self._set_initial_header_values(ang2pipi)
         if np.isnan(self.data_small).all():
             raise ValueError("minimum or maximum value have set all small FOV to nan")  # alignment.py:655-656
@@ -202,14 +252,7 @@ class Alignment:
         lags = _lib.LagSet(self.lag_crval1, self.lag_crval2, self.lag_cdelt1, self.lag_cdelt2, self.lag_crota)
         sem = _lib.CDELT_INTENDED if self.cdelt_semantics == "intended" else _lib.CDELT_REFERENCE
         solar_rs = np.atleast_1d(np.asarray(self.lag_solar_r, dtype=np.float64))
-        rank, world = parallel.world_info()
         lo, hi, chunk = parallel.shard_bounds(lags.size, world, rank)
-        device = self.device
-        if device is None:
-            device = -1
-            if world > 1:
-                import torch
-                device = torch.cuda.current_device()
         out = np.full(lags.shape + (len(solar_rs),), np.nan)
         with _lib.CoregHandle(device) as h:
             h.set_small(self.data_small)

@@ -131,6 +131,10 @@ int coreg_resample_carrington(coreg_handle* h, const coreg_wcs2d* hdr, const cor
                               int order, double* out);
 int coreg_resample_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr,
                                    int order, float* out);
+/* same map, float64 destination: the once-only re-grid of the small image onto a regular sub-FOV grid
+ * (alignment.py:1120-1126, dst = zeros_like(xg)) */
+int coreg_resample_helioprojective_f64(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr,
+                                       int order, double* out);
 
 /* The sweep: replaces the per-lag loop alignment.py:470-578 + :613-797 for one lag_solar_r value.
  * hdr_small is the UNSHIFTED header of the image to align; its CRVAL/CDELT/CROTA are the *_ref values of

@@ -407,6 +407,56 @@ def set_threshold_minmax_to_nan(data_small, vmin=None, vmax=None):
     data_small[~(c1 & c2)] = np.nan
 
 
+def set_remove_fov_limits_to_nan(st: "SweepState", lonlims_deg, latlims_deg):
+    """alignment.py:863-874 (limits in degrees)."""
+    lon, lat = extract_EUI_coordinates(st.hdr_small)
+    inside = np.logical_and(np.logical_and(lon >= lonlims_deg[0], lon <= lonlims_deg[1]),
+                            np.logical_and(lat >= latlims_deg[0], lat <= latlims_deg[1]))
+    st.data_small[inside] = np.nan
+
+
+def build_regular_grid(longitude, latitude, lonlims=None, latlims=None):
+    """PlotFits.build_regular_grid, utils/Util.py:873-906, everything in degrees."""
+    x = np.abs(longitude[0, 1] - longitude[0, 0])
+    y = np.abs(latitude[0, 1] - latitude[0, 0])
+    dlon = np.sqrt(x ** 2 + y ** 2)
+    x = np.abs(longitude[1, 0] - longitude[0, 0])
+    y = np.abs(latitude[1, 0] - latitude[0, 0])
+    dlat = np.sqrt(x ** 2 + y ** 2)
+    longitude1D = np.arange(np.min(longitude), np.max(longitude), dlon)
+    latitude1D = np.arange(np.min(latitude), np.max(latitude), dlat)
+    if (lonlims is not None) or (latlims is not None):
+        longitude1D = longitude1D[(longitude1D > lonlims[0]) & (longitude1D < lonlims[1])]
+        latitude1D = latitude1D[(latitude1D > latlims[0]) & (latitude1D < latlims[1])]
+    long, latg = np.meshgrid(longitude1D, latitude1D)
+    return long, latg, dlon, dlat
+
+
+def select_fov_in_small_data(st: "SweepState", lonlims_deg, latlims_deg):
+    """alignment.py:1082-1127 (limits in degrees), literal: CRPIX1/NAXIS1 take the ROW count of the regular grid."""
+    lon, lat = extract_EUI_coordinates(st.hdr_small)
+    long, latg, dlon, dlat = build_regular_grid(lon, lat, lonlims_deg, latlims_deg)
+    mid = [long.shape[0] // 2, long.shape[1] // 2]
+    hg = dict(st.hdr_small)
+    u1, u2 = unit_to_deg(hg["CUNIT1"]), unit_to_deg(hg["CUNIT2"])
+    hg["CRVAL1"] = long[mid[0], mid[1]] / u1
+    hg["CRVAL2"] = latg[mid[0], mid[1]] / u2
+    hg["CRPIX1"] = mid[0] + 1
+    hg["CRPIX2"] = mid[1] + 1
+    hg["CDELT1"] = dlon / u1
+    hg["CDELT2"] = dlat / u2
+    hg["PC1_1"], hg["PC2_2"], hg["PC1_2"], hg["PC2_1"] = 1.0, 1.0, 0.0, 0.0
+    hg["CROTA"] = 0.0
+    hg["CROTA2"] = 0.0
+    hg["NAXIS1"] = long.shape[0]
+    hg["NAXIS2"] = long.shape[1]
+    xg, yg = extract_coordinates_pixels(hg, st.hdr_small)
+    out = np.zeros_like(xg)
+    interpol2d(st.data_small, x=xg, y=yg, order=st.order, fill=np.nan, dst=out)
+    st.data_small = out
+    st.hdr_small = hg
+
+
 # --------------------------------------------------------------------------------------
 # Carrington: rectify.py:282-423 (transforms), :842-888 (Rectifier), alignment.py:889-901
 def carrington_grid(shape, lonlims, latlims, dtype=np.float32):

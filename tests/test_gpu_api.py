@@ -59,6 +59,31 @@ def test_align_using_helioprojective_dropin(fits_pair, parallelism):
     assert len(res.shift_arcsec) == 5 and res.unit_lag == "arcsec"
 
 
+def test_fov_limits_and_remove_fov_limits(fits_pair):
+    """alignment.py:844-874, 1082-1127: box set to NaN, then re-grid of the small image on a regular sub-FOV grid
+    (GPU resample), then the sweep -- against the oracle's restatement of the same pre-processing."""
+    from euispice_coreg_amd.hdrshift import Alignment
+    from oracle import coreg_oracle as O
+    ps, pl, small, hs, large, hl, truth = fits_pair
+    lag1, lag2 = np.arange(9, 26, 4.0), np.arange(-17, 0, 4.0)
+    fov = [[-700.0, -100.0], [100.0, 700.0]]      # arcsec: a square part of the small FOV
+    rem = [[-450.0, -400.0], [350.0, 420.0]]      # arcsec: box to blank
+    A = Alignment(pl, ps, lag_crval1=lag1, lag_crval2=lag2, lag_cdelt1=None, lag_cdelt2=None, lag_crota=None,
+                  parallelism=True)
+    res = A.align_using_helioprojective(fov_limits=fov, remove_fov_limits=rem)
+    sm = small.astype(np.float32).astype(np.float64)
+    st = H.oracle_state(sm, hs, large.astype(np.float32).astype(np.float64), hl, (lag1, lag2, None, None, None))
+    O.set_remove_fov_limits_to_nan(st, [v / 3600.0 for v in rem[0]], [v / 3600.0 for v in rem[1]])
+    assert np.isnan(st.data_small).sum() > np.isnan(sm).sum()
+    O.select_fov_in_small_data(st, [v / 3600.0 for v in fov[0]], [v / 3600.0 for v in fov[1]])
+    assert st.data_small.shape == A.data_small.shape and st.data_small.shape[0] < small.shape[0]
+    m = np.isfinite(st.data_small)
+    assert np.array_equal(np.isfinite(A.data_small), m)
+    assert np.abs(A.data_small[m] - st.data_small[m]).max() <= 1e-9 * np.nanmax(sm)
+    want = O.find_best_header_parameters(st, "helioprojective")
+    H.assert_corr_close(res.corr, want, 1e-7, "fov_limits + remove_fov_limits")
+
+
 def test_alignment_refuses_unimplemented_paths(fits_pair):
     from euispice_coreg_amd.hdrshift import Alignment
     ps, pl = fits_pair[0], fits_pair[1]
