@@ -455,8 +455,8 @@ void fill_precompute_common(coreg_handle* h, PrecomputeArgs* a, int tile_w) {
 
 // one sweep-kernel launch + finalize over n_batches * 256 slots whose parameters (SoA [np][n_slots]) and output
 // indices are already on the device
-int launch_sweep(coreg_handle* h, int mode, int order, const double* params_dev, const long long* outidx_dev,
-                 int n_batches, int n_tiles, long long lag_begin, double* out_dev) {
+int launch_sweep(coreg_handle* h, int mode, int order, int method, const double* params_dev,
+                 const long long* outidx_dev, int n_batches, int n_tiles, long long lag_begin, double* out_dev) {
     const long long n_slots = (long long)n_batches * kBlock;
     const int n_groups = pick_groups(h, n_batches, n_tiles);
     HIPCHK(h->partials.reserve((size_t)n_groups * kNumSums * n_slots * sizeof(double)));
@@ -485,24 +485,29 @@ int launch_sweep(coreg_handle* h, int mode, int order, const double* params_dev,
     const dim3 grid((unsigned)((long long)n_groups * n_batches)), block(kSweepThreads);
     EventPair* ev = next_event(h, h->ev_sweep, h->ev_sweep_used);
     if (!ev) return fail(h, COREG_EHIP, "hipEventCreate failed");
-#define SW(M, O, TS, R)                                                                                             \
+#define SW(M, O, TS, R, Q)                                                                                          \
     do {                                                                                                              \
         {                                                                                                             \
             static size_t attr_bytes = 0; /* per instantiation: raise the dynamic-LDS limit once, not per launch */   \
             if (lds_bytes > 48 * 1024 && lds_bytes > attr_bytes) {                                                    \
-                HIPCHK(hipFuncSetAttribute((const void*)(k_sweep<M, O, TS, R>),                                       \
+                HIPCHK(hipFuncSetAttribute((const void*)(k_sweep<M, O, TS, R, Q>),                                    \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));              \
                 attr_bytes = lds_bytes;                                                                               \
             }                                                                                                         \
         }                                                                                                             \
         HIPCHK(hipEventRecord(ev->a, h->stream));                                                                     \
-        hipLaunchKernelGGL((k_sweep<M, O, TS, R>), grid, block, lds_bytes, h->stream, a);                             \
+        hipLaunchKernelGGL((k_sweep<M, O, TS, R, Q>), grid, block, lds_bytes, h->stream, a);                          \
         HIPCHK(hipEventRecord(ev->b, h->stream));                                                                     \
     } while (0)
-#define SW_T(M, O, R)                         \
-    do {                                      \
-        if (h->small_f32) SW(M, O, float, R); \
-        else SW(M, O, double, R);             \
+#define SW_Q(M, O, TS, R)                                        \
+    do {                                                         \
+        if (method == COREG_METHOD_RESIDUS) SW(M, O, TS, R, true); \
+        else SW(M, O, TS, R, false);                             \
+    } while (0)
+#define SW_T(M, O, R)                           \
+    do {                                        \
+        if (h->small_f32) SW_Q(M, O, float, R); \
+        else SW_Q(M, O, double, R);             \
     } while (0)
     // TRANSLATE = Carrington (float64 samples); HOMOGRAPHY = helioprojective (samples rounded to float32)
     if (mode == MODE_TRANSLATE) {
@@ -512,6 +517,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, const double* params_dev,
         if (order == 2) SW_T(MODE_HOMOGRAPHY, 2, true);
         else SW_T(MODE_HOMOGRAPHY, 1, true);
     }
+#undef SW_Q
 #undef SW_T
 #undef SW
     HIPCHK(hipGetLastError());
@@ -525,6 +531,8 @@ int launch_sweep(coreg_handle* h, int mode, int order, const double* params_dev,
     f.out_index = outidx_dev;
     f.lag_begin = lag_begin;
     f.out = out_dev;
+    f.residus = method == COREG_METHOD_RESIDUS ? 1 : 0;
+    f.n_required = (long long)h->gW * h->gH;
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_slots + 63) / 64)), dim3(256), 0, h->stream, f);
     HIPCHK(hipGetLastError());
     return COREG_OK;
@@ -881,8 +889,8 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
                            int64_t lag_end, double* corr_out, int out_on_device) {
     if (!h) return COREG_EINVAL;
     if (!hdr_small || !grid) return fail(h, COREG_EINVAL, "sweep_carrington: null header/grid");
-    if (method != COREG_METHOD_CORRELATION)
-        return fail(h, COREG_ENOTIMPL, "only method='correlation' is implemented on the GPU");
+    if (method != COREG_METHOD_CORRELATION && method != COREG_METHOD_RESIDUS)
+        return fail(h, COREG_ENOTIMPL, "method must be COREG_METHOD_CORRELATION or COREG_METHOD_RESIDUS");
     RETCHK(check_order(h, order));
     LagDims d;
     RETCHK(check_lags(h, lags, &d, lag_begin, lag_end));
@@ -930,6 +938,7 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
         RETCHK(reserve_tiles(h, ((h->gW + plan.tile_w - 1) / plan.tile_w) * ((h->gH + th - 1) / th)));
     }
     fill_precompute_common(h, &pa, plan.tile_w);
+    pa.residus = method == COREG_METHOD_RESIDUS ? 1 : 0;
     const int n_tiles = pa.tiles_x * pa.tiles_y;
 
     // ---- every (cdelt1, cdelt2, crota) combination = one precompute + one sweep launch; all lag parameters of all
@@ -1008,7 +1017,7 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
         pa.f1hi = L.f1hi;
         RETCHK(launch_precompute<MODE_TRANSLATE>(h, pa, n_tiles));
         // SoA block of this launch starts at 2 * slot_off doubles (every earlier launch contributed 2 per slot)
-        RETCHK(launch_sweep(h, MODE_TRANSLATE, order, h->lane_params.as<double>() + 2 * L.slot_off,
+        RETCHK(launch_sweep(h, MODE_TRANSLATE, order, method, h->lane_params.as<double>() + 2 * L.slot_off,
                             h->out_index.as<long long>() + L.slot_off, L.n_batches, n_tiles, lag_begin, out_dev));
     }
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
@@ -1019,8 +1028,8 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                                 int64_t lag_end, double* corr_out, int out_on_device) {
     if (!h) return COREG_EINVAL;
     if (!hdr_target || !hdr_small) return fail(h, COREG_EINVAL, "sweep_helioprojective: null header");
-    if (method != COREG_METHOD_CORRELATION)
-        return fail(h, COREG_ENOTIMPL, "only method='correlation' is implemented on the GPU");
+    if (method != COREG_METHOD_CORRELATION && method != COREG_METHOD_RESIDUS)
+        return fail(h, COREG_ENOTIMPL, "method must be COREG_METHOD_CORRELATION or COREG_METHOD_RESIDUS");
     RETCHK(check_order(h, order));
     LagDims d;
     RETCHK(check_lags(h, lags, &d, lag_begin, lag_end));
@@ -1134,6 +1143,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
         RETCHK(reserve_tiles(h, ((h->gW + plan.tile_w - 1) / plan.tile_w) * ((h->gH + th - 1) / th)));
     }
     fill_precompute_common(h, &pa, plan.tile_w);
+    pa.residus = method == COREG_METHOD_RESIDUS ? 1 : 0;
     const int n_tiles = pa.tiles_x * pa.tiles_y;
     // the maps are projective and the image corners bound its interior
     pa.f0lo = std::floor(fx0) - 3.0;
@@ -1141,7 +1151,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     pa.f1lo = std::floor(fy0) - 3.0;
     pa.f1hi = std::ceil(fy1) + 3.0;
     RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles));
-    RETCHK(launch_sweep(h, MODE_HOMOGRAPHY, order, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
+    RETCHK(launch_sweep(h, MODE_HOMOGRAPHY, order, method, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
                         n_tiles, lag_begin, out_dev));
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }

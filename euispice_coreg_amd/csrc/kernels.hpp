@@ -263,6 +263,7 @@ struct PrecomputeArgs {
     int tiles_x, tiles_y;
     CarrDev carr;             // MODE_TRANSLATE
     double f0lo, f0hi, f1lo, f1hi;  // cull box on the base coordinates (inclusive)
+    int residus;              // 1: method 'residus' -> pts hold the raw reference value and 1/sqrt(value)
     const double* pivot_a;    // device scalar: mean of the finite reference values
     Pt* pts;                  // [n_tiles][kTilePts] compacted points
     int* tile_count;          // [n_tiles]
@@ -307,8 +308,8 @@ __global__ void __launch_bounds__(256) k_precompute(const PrecomputeArgs a) {
             Pt pt;
             pt.b0 = b0;
             pt.b1 = b1;
-            pt.a = av - pivot;
-            pt.pad = 0.0;
+            pt.a = a.residus ? av : av - pivot;
+            pt.pad = a.residus ? 1.0 / sqrt(av) : 0.0;  // alignment.py:545 norm = sqrt(data_large)
             a.pts[tbase + off + rank] = pt;
             mn0 = fmin(mn0, b0);
             mx0 = fmax(mx0, b0);
@@ -459,10 +460,12 @@ struct Taps<2> {
 // address `win`; element (r, c) is at r*pitch + c.
 // INTERIOR: the caller has proved that every (point of the tile) x (lag of the workgroup) is inside the image, so the
 // bounds rule cannot trigger and is not evaluated (padding lanes never get here).
-template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool INTERIOR = false>
+// RESID (method 'residus', alignment.py:544-547): d = (a - b) / sqrt(a) summed instead of the Pearson moments;
+// `isa` = 1/sqrt(a).  No NaN mask exists in that method: k_finalize returns NaN unless EVERY grid point contributed.
+template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false>
 __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                           int ox, int oy, int W, int H, double wmax, double hmax, double px0, double py0,
-                                          const H9& hm, double b0, double b1, double av, double pivot_b) {
+                                          const H9& hm, double b0, double b1, double av, double isa, double pivot_b) {
     constexpr int N = Spline<ORDER>::N;
     double nx, ny;
     if (MODE == MODE_TRANSLATE) {
@@ -521,7 +524,15 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
             // LDS window already holds (pixel - pivot): the spline weights sum to 1
             bm = LDS ? v : v - pivot_b;
         }
-        if (isfinite(v)) {
+        if (RESID) {
+            const double braw = (ROUND || !LDS) ? v : v + pivot_b;  // undo the pivot folded into the LDS window
+            const double d = (av - braw) * isa;
+            if (isfinite(d)) {
+                acc.n += 1;
+                acc.b += d;
+                acc.bb = fma(d, d, acc.bb);
+            }
+        } else if (isfinite(v)) {
             acc.n += 1;
             acc.a += av;
             acc.b += bm;
@@ -534,7 +545,7 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
 
 // Walk this point-group's share of the compacted points of one tile: chunks of kChunk points, chunk c belongs to
 // point-group (c % kPointGroups).  Point data are wave-uniform: the loads below use uniform addresses (scalar loads).
-template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool INTERIOR = false>
+template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false>
 __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                             int ox, int oy, int W, int H, double px0, double py0,
                                             const H9& hm, const Pt* __restrict__ pts, int cnt, double pivot_b, int pg) {
@@ -550,20 +561,21 @@ __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __
         for (int k = 0; k < kChunk; ++k) pt[k] = q[k];
 #pragma unroll
         for (int k = 0; k < kChunk; ++k)
-            point_lag<MODE, ORDER, TS, LDS, ROUND, INTERIOR>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0, py0,
-                                                             hm, pt[k].b0, pt[k].b1, pt[k].a, pivot_b);
+            point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0,
+                                                                    py0, hm, pt[k].b0, pt[k].b1, pt[k].a, pt[k].pad,
+                                                                    pivot_b);
     }
     // ragged tail (< kChunk points): owned by the point-group next in the rotation
     if (pg == n_full % kPointGroups) {
         for (int p = n_full * kChunk; p < cnt; ++p) {
             const Pt pt = pts[p];
-            point_lag<MODE, ORDER, TS, LDS, ROUND, INTERIOR>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0, py0,
-                                                             hm, pt.b0, pt.b1, pt.a, pivot_b);
+            point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0,
+                                                                    py0, hm, pt.b0, pt.b1, pt.a, pt.pad, pivot_b);
         }
     }
 }
 
-template <int MODE, int ORDER, typename TS, bool ROUND>
+template <int MODE, int ORDER, typename TS, bool ROUND, bool RESID>
 __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double* lds = (double*)lds_raw;
@@ -680,15 +692,15 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
             __syncthreads();
             if (interior) {
                 if (!pad_lane)
-                    tile_points<MODE, ORDER, TS, true, ROUND, true>(acc, win, img, pitch, ox, oy, W, H, px0, py0, hm,
-                                                                    pts, cnt, pivot_b, pg);
+                    tile_points<MODE, ORDER, TS, true, ROUND, RESID, true>(acc, win, img, pitch, ox, oy, W, H, px0, py0,
+                                                                           hm, pts, cnt, pivot_b, pg);
             } else {
-                tile_points<MODE, ORDER, TS, true, ROUND>(acc, win, img, pitch, ox, oy, W, H, px0, py0, hm, pts, cnt,
-                                                          pivot_b, pg);
+                tile_points<MODE, ORDER, TS, true, ROUND, RESID>(acc, win, img, pitch, ox, oy, W, H, px0, py0, hm, pts,
+                                                                 cnt, pivot_b, pg);
             }
         } else {
-            tile_points<MODE, ORDER, TS, false, ROUND>(acc, win, img, 0, 0, 0, W, H, px0, py0, hm, pts, cnt,
-                                                       pivot_b, pg);
+            tile_points<MODE, ORDER, TS, false, ROUND, RESID>(acc, win, img, 0, 0, 0, W, H, px0, py0, hm, pts, cnt,
+                                                              pivot_b, pg);
         }
     }
 
@@ -734,6 +746,8 @@ struct FinalizeArgs {
     const long long* out_index;  // C-order raveled lag index of each slot, or -1 (padding)
     long long lag_begin;
     double* out;  // [lag_end - lag_begin]
+    int residus;          // 1: np.std((A - B) / sqrt(A)) over ALL grid points (alignment.py:544-547)
+    long long n_required;  // residus: number of grid points G; fewer contributions -> NaN (no mask in that method)
 };
 __global__ void __launch_bounds__(256) k_finalize(const FinalizeArgs a) {
     // 64 lag slots per block; 4 threads per slot each add every 4th slab, then one adds the four in order
@@ -764,7 +778,12 @@ __global__ void __launch_bounds__(256) k_finalize(const FinalizeArgs a) {
     }
     const double n = s[0];
     double r = __builtin_nan("");
-    if (n > 0.0) {
+    if (a.residus) {
+        if (n == (double)a.n_required) {
+            const double m = s[2] / n;
+            r = sqrt(fmax(s[4] / n - m * m, 0.0));
+        }
+    } else if (n > 0.0) {
         const double cov = s[5] - s[1] * s[2] / n;
         const double va = s[3] - s[1] * s[1] / n;
         const double vb = s[4] - s[2] * s[2] / n;

@@ -224,10 +224,11 @@ class Alignment:
     def _find_best_header_parameters(self, ang2pipi=True, fov_limits=None, remove_fov_limits=None):
         """alignment.py:613-797 on the GPU.  Returns float64 [n_crval1, n_crval2, n_cdelt1, n_cdelt2, n_crota,
         n_solar_r]; lag-points the library could not evaluate are NaN, never 0 (quirk Q9)."""
-        if self.method == "residus":
-            raise NotImplementedError("method='residus' (alignment.py:544-547, NaN unless every grid pixel overlaps, "
-                                      "quirk Q8) is not implemented on the GPU")
-        if self.method != "correlation":
+        if self.method == "correlation":
+            method = _lib.METHOD_CORRELATION
+        elif self.method == "residus":
+            method = _lib.METHOD_RESIDUS  # alignment.py:544-547: no NaN mask, NaN unless every grid pixel overlaps
+        else:
             raise NotImplementedError  # alignment.py:549
         device = self.device
         rank, world = parallel.world_info()
@@ -260,7 +261,7 @@ class Alignment:
                 if self.coordinate_frame == "final_carrington":
                     grid = _lib.Grid(self.lonlims, self.latlims, self.shape, numpy_lat_trig=True)
                     h.prepare_reference_carrington(self.data_large, self.hdr_large, grid, solar_r, self.order)
-                    part = h.sweep_carrington(self.hdr_small, grid, solar_r, lags, order=self.order,
+                    part = h.sweep_carrington(self.hdr_small, grid, solar_r, lags, order=self.order, method=method,
                                               cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
                 else:
                     if self.parallelism:
@@ -270,7 +271,7 @@ class Alignment:
                     else:
                         h.set_reference_on_grid(self.data_large)  # quirk Q1: full large grid, float64
                         target = self.hdr_large
-                    part = h.sweep_helioprojective(target, self.hdr_small, lags, order=self.order,
+                    part = h.sweep_helioprojective(target, self.hdr_small, lags, order=self.order, method=method,
                                                    cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
                 if world > 1:
                     part = parallel.allgather_lag_slices(part, lags.size).cpu().numpy()

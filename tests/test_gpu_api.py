@@ -89,7 +89,7 @@ def test_alignment_refuses_unimplemented_paths(fits_pair):
     ps, pl = fits_pair[0], fits_pair[1]
     A = Alignment(pl, ps, [0.0], [0.0], None, None, None)
     with pytest.raises(NotImplementedError):
-        A.align_using_helioprojective(method="residus")
+        A.align_using_helioprojective(method="no-such-method")
     with pytest.raises(NotImplementedError):
         A.align_using_carrington(lonlims=(228, 262), latlims=(-12, 22), shape=(32, 32),
                                  method_carrington_reprojection="sunpy")

@@ -234,6 +234,49 @@ def test_sweep_helioprojective_cdelt_semantics(gpu_handle):
     H.assert_corr_close(got1, want1, 1e-7, "helio cdelt1 reference semantics")
 
 
+def test_method_residus(gpu_handle):
+    """method='residus' (alignment.py:544-547): np.std((A - B) / sqrt(A)) over ALL grid pixels, no NaN mask (quirk Q8):
+    a number only when every grid pixel overlaps, NaN otherwise."""
+    from euispice_coreg_amd import _lib
+    from oracle import coreg_oracle as O
+    small, hs, large, hl, _ = H.scene(nan_frac=0.0)
+    lags = _lags(3, 3)
+    # grid well inside the small FOV for every lag: full overlap -> finite
+    lon, lat, shape = (243.0, 249.0), (2.0, 8.0), (40, 36)
+    st = H.oracle_state(small, hs, large, hl, lags, shape=list(shape), lonlims=list(lon), latlims=list(lat),
+                        solar_r=(1.004,))
+    want = O.find_best_header_parameters(st, "carrington", method="residus")
+    assert np.isfinite(want).all()
+    grid = _lib.Grid(lon, lat, shape)
+    ls = _lib.LagSet(*lags)
+    gpu_handle.set_small(small)
+    gpu_handle.prepare_reference_carrington(large, hl, grid, 1.004, 2)
+    got = gpu_handle.sweep_carrington(hs, grid, 1.004, ls, method=_lib.METHOD_RESIDUS).reshape(want.shape)
+    assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+    assert np.argmin(got) == np.argmin(want)
+    # the usual grid (partly outside the FOV): NaN for every lag, as in the reference
+    st = H.oracle_state(small, hs, large, hl, lags, shape=[48, 40], lonlims=list(H.CARR_LON), latlims=list(H.CARR_LAT),
+                        solar_r=(1.004,))
+    want = O.find_best_header_parameters(st, "carrington", method="residus")
+    assert np.isnan(want).all()
+    got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, (48, 40))  # correlation still fine there
+    assert np.isfinite(got).all()
+    grid = _lib.Grid(H.CARR_LON, H.CARR_LAT, (48, 40))
+    got = gpu_handle.sweep_carrington(hs, grid, 1.004, ls, method=_lib.METHOD_RESIDUS)
+    assert np.isnan(got).all()
+    # helioprojective: float32 arithmetic in the reference (float32 sub-map and sample) -> 1e-5 relative
+    s2, hs2, l2, hl2, _ = H.scene(small_n=64, large_n=96, nan_frac=0.0)
+    st = H.oracle_state(s2, hs2, l2, hl2, ([0.0], [0.0], None, None, None))
+    want = O.find_best_header_parameters(st, "helioprojective", method="residus")
+    gpu_handle.set_small(s2)
+    gpu_handle.prepare_reference_helioprojective(l2, hl2, hs2, 2)
+    got = gpu_handle.sweep_helioprojective(hs2, hs2, _lib.LagSet([0.0], [0.0], None, None, None),
+                                           method=_lib.METHOD_RESIDUS)
+    assert np.isnan(want).all() == np.isnan(got).all()
+    if np.isfinite(want).all():
+        assert abs(got[0] - want.ravel()[0]) <= 1e-5 * abs(want.ravel()[0])
+
+
 def test_errors_are_loud(gpu_handle):
     from euispice_coreg_amd import _lib
     small, hs, large, hl, _ = H.scene(small_n=48, large_n=64)
@@ -245,8 +288,8 @@ def test_errors_are_loud(gpu_handle):
         h2.prepare_reference_helioprojective(large, hl, hs, 2)
         with pytest.raises(_lib.CoregError):  # unsupported spline order
             h2.sweep_helioprojective(hs, hs, _lib.LagSet([0.0], [0.0], None, None, None), order=3)
-        with pytest.raises(_lib.CoregError):  # residus is not implemented on the GPU: refuse, never fall back
-            h2.sweep_helioprojective(hs, hs, _lib.LagSet([0.0], [0.0], None, None, None), method=1)
+        with pytest.raises(_lib.CoregError):  # unknown method: refuse, never fall back
+            h2.sweep_helioprojective(hs, hs, _lib.LagSet([0.0], [0.0], None, None, None), method=7)
         with pytest.raises(_lib.CoregError):
             h2.set_option("no_such_option", 1)
     finally:
