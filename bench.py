@@ -45,6 +45,22 @@ except Exception:
     pass
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per k_sweep launch from the committed rocprofv3 PMC summary of this same command
+    (profiles/r01_pmc_summary.txt; FETCH_SIZE/WRITE_SIZE are KiB per dispatch, FETCH_SIZE doubled: gfx950 counts
+    128-B read requests as 64 B -- MI355X_MICROARCH.md, HBM section).  None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.txt")
+    try:
+        vals = {}
+        for line in open(path):
+            parts = line.split()
+            if len(parts) >= 4 and parts[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[parts[0]] = float(parts[3])
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -191,7 +207,9 @@ def main():
                        "lag_points": L, "grid": list(GRID_SHAPE), "parallelism": f"lag-shard x{world} + 1 all-gather",
                        "small_stored_f32": bool(stats["small_is_f32"]), "use_lds": bool(stats["used_lds"])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.txt)",
+                         "algorithmic_bytes_per_launch": b_lag * lags_per_launch,
                          "kernel": "k_sweep<TRANSLATE,2,f32>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_lag": b_lag, "lags_per_launch": lags_per_launch,
                          "note": "algorithmic bytes = one-lag-per-pass model (SURVEY 8d); the kernel batches 256 lags "
