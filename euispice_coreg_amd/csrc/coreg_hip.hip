@@ -98,7 +98,7 @@ struct coreg_handle {
     std::vector<double> tabs_key;
     PinBuf pin_params, pin_outidx;
     // precompute outputs
-    DevBuf pts, tile_count, tile_list, tile_info, tile_bbox;
+    DevBuf pts, tile_count, tile_list, tile_cum, group_first, tile_info, tile_bbox;
     // sweep
     DevBuf lane_params, out_index, partials, out_dev, tmp_img;
 
@@ -106,6 +106,9 @@ struct coreg_handle {
     int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0;
 
     coreg_stats stats;
+    bool stats_pending = false;   // a device-output sweep is in flight: timings are collected on demand
+    PinBuf pin_info;              // tile_info read-back of the in-flight sweep
+    hipEvent_t ev_upload = nullptr;  // completes when the last lag-parameter upload has left the pinned staging
     std::vector<EventPair> ev_sweep, ev_pre;
     size_t ev_sweep_used = 0, ev_pre_used = 0;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
@@ -407,14 +410,16 @@ void build_slots(const LagDims& d, long long c, long long begin, long long end, 
 }
 
 int pick_groups(coreg_handle* h, int n_batches, int n_tiles) {
+    // the compacted points are cut in n_groups EQUAL shares (k_tile_list), so n_groups * n_batches workgroups of equal
+    // work: 256 groups make every round of 256 CUs full; fewer when there are many lag batches
     long long g = h->opt_n_groups > 0 ? h->opt_n_groups : (4096 + n_batches - 1) / n_batches;
-    g = std::min<long long>(g, n_tiles);
-    g = std::max<long long>(8, std::min<long long>(512, ((g + 7) / 8) * 8));
+    (void)n_tiles;
+    g = std::max<long long>(8, std::min<long long>(h->opt_n_groups > 0 ? 1000 : 256, ((g + 7) / 8) * 8));
     return (int)g;
 }
 
 template <int MODE>
-int launch_precompute(coreg_handle* h, const PrecomputeArgs& a, int n_tiles) {
+int launch_precompute(coreg_handle* h, const PrecomputeArgs& a, int n_tiles, int n_groups) {
     EventPair* ev = next_event(h, h->ev_pre, h->ev_pre_used);
     if (!ev) return fail(h, COREG_EHIP, "hipEventCreate failed");
     HIPCHK(hipEventRecord(ev->a, h->stream));
@@ -422,8 +427,9 @@ int launch_precompute(coreg_handle* h, const PrecomputeArgs& a, int n_tiles) {
         hipLaunchKernelGGL((k_precompute<MODE, float>), dim3(n_tiles), dim3(256), 0, h->stream, a);
     else
         hipLaunchKernelGGL((k_precompute<MODE, double>), dim3(n_tiles), dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, h->stream, (const int*)a.tile_count, n_tiles,
-                       h->tile_list.as<int>(), h->tile_info.as<long long>());
+    hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, h->stream, (const int*)a.tile_count, n_tiles, n_groups,
+                       h->tile_list.as<int>(), h->tile_cum.as<int>(), h->group_first.as<int>(),
+                       h->tile_info.as<long long>());
     HIPCHK(hipEventRecord(ev->b, h->stream));
     HIPCHK(hipGetLastError());
     return COREG_OK;
@@ -434,7 +440,9 @@ int reserve_tiles(coreg_handle* h, int n_tiles) {
     HIPCHK(h->pts.reserve(pts * sizeof(Pt)));
     HIPCHK(h->tile_count.reserve(n_tiles * sizeof(int)));
     HIPCHK(h->tile_list.reserve(n_tiles * sizeof(int)));
-    HIPCHK(h->tile_info.reserve(2 * sizeof(long long)));
+    HIPCHK(h->tile_cum.reserve((n_tiles + 1) * sizeof(int)));
+    HIPCHK(h->group_first.reserve(1024 * sizeof(int)));
+    HIPCHK(h->tile_info.reserve(4 * sizeof(long long)));
     HIPCHK(h->tile_bbox.reserve((size_t)n_tiles * 4 * sizeof(double)));
     return COREG_OK;
 }
@@ -468,6 +476,8 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     a.pts = h->pts.as<Pt>();
     a.tile_count = h->tile_count.as<int>();
     a.tile_list = h->tile_list.as<int>();
+    a.tile_cum = h->tile_cum.as<int>();
+    a.group_first = h->group_first.as<int>();
     a.tile_info = h->tile_info.as<long long>();
     a.tile_bbox = h->tile_bbox.as<double>();
     a.lane_params = params_dev;
@@ -533,12 +543,17 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     f.out = out_dev;
     f.residus = method == COREG_METHOD_RESIDUS ? 1 : 0;
     f.n_required = (long long)h->gW * h->gH;
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_slots + 63) / 64)), dim3(256), 0, h->stream, f);
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_slots + 63) / 64)), dim3(64 * kFinLanes), 0, h->stream, f);
     HIPCHK(hipGetLastError());
     return COREG_OK;
 }
 
+int collect_stats(coreg_handle* h);
+
 int begin_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_device, double** out_dev) {
+    // timings of a still-uncollected device-output sweep are dropped (its events are re-recorded below): starting the
+    // next sweep never waits for the previous one
+    h->stats_pending = false;
     if (!h->small.p) return fail(h, COREG_ESTATE, "coreg_set_small has not been called");
     if (!h->ref.p) return fail(h, COREG_ESTATE, "no reference image on the target grid");
     if (!corr_out && n_out > 0) return fail(h, COREG_EINVAL, "corr_out is null");
@@ -563,15 +578,11 @@ int begin_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_d
     return COREG_OK;
 }
 
-int end_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_device, double* out_dev) {
-    HIPCHK(hipEventRecord(h->ev_t1, h->stream));
-    if (!out_on_device && n_out > 0)
-        HIPCHK(hipMemcpyAsync(corr_out, out_dev, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    long long info[2] = {0, 0};
-    if (h->tile_info.p)
-        HIPCHK(hipMemcpyAsync(info, h->tile_info.p, sizeof(info), hipMemcpyDeviceToHost, h->stream));
+int collect_stats(coreg_handle* h) {
+    if (!h->stats_pending) return COREG_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->stats.n_active_points = info[1];
+    h->stats_pending = false;
+    if (h->pin_info.p) h->stats.n_active_points = ((const long long*)h->pin_info.p)[1];
     float ms = 0.f;
     for (size_t i = 0; i < h->ev_sweep_used; ++i) {
         HIPCHK(hipEventElapsedTime(&ms, h->ev_sweep[i].a, h->ev_sweep[i].b));
@@ -586,6 +597,21 @@ int end_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_dev
     return COREG_OK;
 }
 
+// Host output: copy back and wait.  Device output: return at once -- the sweep is stream-ordered work like any other
+// (a following collective on the same stream sees the results); timings are gathered when coreg_last_stats asks.
+int end_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_device, double* out_dev) {
+    HIPCHK(hipEventRecord(h->ev_t1, h->stream));
+    if (!out_on_device && n_out > 0)
+        HIPCHK(hipMemcpyAsync(corr_out, out_dev, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h->pin_info.reserve(4 * sizeof(long long)));
+    std::memset(h->pin_info.p, 0, 4 * sizeof(long long));
+    if (h->tile_info.p)
+        HIPCHK(hipMemcpyAsync(h->pin_info.p, h->tile_info.p, 3 * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    h->stats_pending = true;
+    if (!out_on_device) return collect_stats(h);
+    return COREG_OK;
+}
+
 long long lds_window_elems(const coreg_handle* h) {
     const size_t lds_min = (size_t)(kPointGroups - 1) * kNumSums * kBlock * sizeof(double);
     return (long long)(std::max(lds_min, (size_t)h->opt_lds_bytes) / sizeof(double));
@@ -597,12 +623,14 @@ int upload_plan(coreg_handle* h, const std::vector<double>& params, const std::v
     HIPCHK(h->pin_outidx.reserve(outidx.size() * sizeof(long long)));
     HIPCHK(h->lane_params.reserve(params.size() * sizeof(double)));
     HIPCHK(h->out_index.reserve(outidx.size() * sizeof(long long)));
+    HIPCHK(hipEventSynchronize(h->ev_upload));  // previous upload has left the staging buffers
     std::memcpy(h->pin_params.p, params.data(), params.size() * sizeof(double));
     std::memcpy(h->pin_outidx.p, outidx.data(), outidx.size() * sizeof(long long));
     HIPCHK(hipMemcpyAsync(h->lane_params.p, h->pin_params.p, params.size() * sizeof(double), hipMemcpyHostToDevice,
                           h->stream));
     HIPCHK(hipMemcpyAsync(h->out_index.p, h->pin_outidx.p, outidx.size() * sizeof(long long), hipMemcpyHostToDevice,
                           h->stream));
+    HIPCHK(hipEventRecord(h->ev_upload, h->stream));
     return COREG_OK;
 }
 
@@ -634,6 +662,7 @@ int coreg_create(coreg_handle** out, int device) {
     h->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_t1) != hipSuccess ||
+        hipEventCreate(&h->ev_upload) != hipSuccess || hipEventRecord(h->ev_upload, h->stream) != hipSuccess ||
         h->pivots.reserve(2 * sizeof(double)) != hipSuccess ||
         hipMemsetAsync(h->pivots.p, 0, 2 * sizeof(double), h->stream) != hipSuccess) {
         delete h;
@@ -650,7 +679,7 @@ void coreg_destroy(coreg_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->small, &h->ref, &h->pivots, &h->red_sum, &h->red_cnt, &h->t_sin_lon, &h->t_cos_lon,
-                      &h->t_cos_lat, &h->t_sin_lat, &h->pts, &h->tile_count, &h->tile_list,
+                      &h->t_cos_lat, &h->t_sin_lat, &h->pts, &h->tile_count, &h->tile_list, &h->tile_cum, &h->group_first,
                       &h->tile_info, &h->tile_bbox, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
                       &h->tmp_img};
     for (DevBuf* b : bufs) b->release();
@@ -666,6 +695,8 @@ void coreg_destroy(coreg_handle* h) {
     }
     if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
     if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
+    if (h->ev_upload) (void)hipEventDestroy(h->ev_upload);
+    h->pin_info.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -675,6 +706,7 @@ const char* coreg_last_error(const coreg_handle* h) { return h ? h->err.c_str() 
 int coreg_set_stream(coreg_handle* h, void* hip_stream) {
     if (!h) return COREG_EINVAL;
     RETCHK(bind_device(h));
+    RETCHK(collect_stats(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->own_stream && h->stream) HIPCHK(hipStreamDestroy(h->stream));
     h->stream = (hipStream_t)hip_stream;
@@ -1015,7 +1047,7 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
         pa.f0hi = L.f0hi;
         pa.f1lo = L.f1lo;
         pa.f1hi = L.f1hi;
-        RETCHK(launch_precompute<MODE_TRANSLATE>(h, pa, n_tiles));
+        RETCHK(launch_precompute<MODE_TRANSLATE>(h, pa, n_tiles, pick_groups(h, L.n_batches, n_tiles)));
         // SoA block of this launch starts at 2 * slot_off doubles (every earlier launch contributed 2 per slot)
         RETCHK(launch_sweep(h, MODE_TRANSLATE, order, method, h->lane_params.as<double>() + 2 * L.slot_off,
                             h->out_index.as<long long>() + L.slot_off, L.n_batches, n_tiles, lag_begin, out_dev));
@@ -1150,14 +1182,16 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     pa.f0hi = std::ceil(fx1) + 3.0;
     pa.f1lo = std::floor(fy0) - 3.0;
     pa.f1hi = std::ceil(fy1) + 3.0;
-    RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles));
+    RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles, pick_groups(h, n_batches, n_tiles)));
     RETCHK(launch_sweep(h, MODE_HOMOGRAPHY, order, method, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
                         n_tiles, lag_begin, out_dev));
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }
 
-int coreg_last_stats(const coreg_handle* h, coreg_stats* out) {
+int coreg_last_stats(coreg_handle* h, coreg_stats* out) {
     if (!h || !out) return COREG_EINVAL;
+    RETCHK(bind_device(h));
+    RETCHK(collect_stats(h));  // waits for an in-flight device-output sweep
     *out = h->stats;
     return COREG_OK;
 }

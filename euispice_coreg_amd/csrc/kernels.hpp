@@ -278,6 +278,39 @@ __global__ void __launch_bounds__(256) k_precompute(const PrecomputeArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double pivot = a.pivot_a[0];
     const double inf = __builtin_inf();
+    if (MODE == MODE_TRANSLATE) {
+        // Whole tile outside the cull box?  The map (i, j) -> (t0, t1) is smooth and, over one tile, monotone to well
+        // within the margin used here, so the tile's nine sample points (corners, edge midpoints, centre) bound it:
+        // if all nine are visible and their box, widened by a quarter of its own size plus 4 px, misses the cull
+        // box, no point of the tile can be kept.  (Tiles touching the limb -- any sample behind it -- are never skipped.)
+        __shared__ int s_skip;
+        const int i0 = tx * a.tile_w, j0 = ty * a.tile_h;
+        const int i1 = min(i0 + a.tile_w, a.gw) - 1, j1 = min(j0 + a.tile_h, a.gh) - 1;
+        if (wave == 0) {  // lanes 0..8 evaluate one sample each, the rest repeat sample 8
+            const int k = min(lane, 8);
+            const int ii = (k % 3 == 0) ? i0 : ((k % 3 == 1) ? (i0 + i1) / 2 : i1);
+            const int jj = (k / 3 == 0) ? j0 : ((k / 3 == 1) ? (j0 + j1) / 2 : j1);
+            double t0, t1;
+            const bool vis = carr_term(a.carr, ii, jj, t0, t1);
+            double q0lo = t0, q0hi = t0, q1lo = t1, q1hi = t1;
+            for (int o = 8; o > 0; o >>= 1) {  // lanes 0..15 hold all nine samples
+                q0lo = fmin(q0lo, __shfl_xor(q0lo, o));
+                q0hi = fmax(q0hi, __shfl_xor(q0hi, o));
+                q1lo = fmin(q1lo, __shfl_xor(q1lo, o));
+                q1hi = fmax(q1hi, __shfl_xor(q1hi, o));
+            }
+            const bool all_vis = (__ballot(vis) & 0x1ffull) == 0x1ffull;
+            const double m0 = 0.25 * (q0hi - q0lo) + 4.0, m1 = 0.25 * (q1hi - q1lo) + 4.0;
+            if (lane == 0)
+                s_skip = all_vis &&
+                         (q0hi + m0 < a.f0lo || q0lo - m0 > a.f0hi || q1hi + m1 < a.f1lo || q1lo - m1 > a.f1hi);
+        }
+        __syncthreads();
+        if (s_skip) {
+            if (threadIdx.x == 0) a.tile_count[tile] = 0;
+            return;
+        }
+    }
     double mn0 = inf, mx0 = -inf, mn1 = inf, mx1 = -inf;
     int base_pos = 0;
     const size_t tbase = (size_t)tile * kTilePts;
@@ -342,16 +375,23 @@ __global__ void __launch_bounds__(256) k_precompute(const PrecomputeArgs a) {
     }
 }
 
-// list of non-empty tiles in tile order (single workgroup, deterministic); info[0] = count, info[1] = total points
-__global__ void __launch_bounds__(1024) k_tile_list(const int* __restrict__ tile_count, int n_tiles, int* tile_list,
-                                                    long long* info) {
+// Work partition (single workgroup, deterministic):
+//   tile_list  = non-empty tiles in tile order; tile_cum[k] = work units before list entry k, one unit =
+//   kChunk * kPointGroups points (tile_cum[n_nonempty] = total);  group_first[g] = list entry in which the units of
+//   tile group g start when the total is cut in n_groups equal shares;
+//   info[0] = non-empty tiles, info[1] = kept points, info[2] = work units.
+constexpr int kUnitPts = kChunk * kPointGroups;
+__global__ void __launch_bounds__(1024) k_tile_list(const int* __restrict__ tile_count, int n_tiles, int n_groups,
+                                                    int* tile_list, int* tile_cum, int* group_first, long long* info) {
     __shared__ int wcnt[16];
+    __shared__ int wunits[16];
     __shared__ long long wpts[16];
-    __shared__ int s_base;
+    __shared__ int s_base, s_units;
     __shared__ long long s_pts;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
         s_base = 0;
+        s_units = 0;
         s_pts = 0;
     }
     __syncthreads();
@@ -359,34 +399,64 @@ __global__ void __launch_bounds__(1024) k_tile_list(const int* __restrict__ tile
         const int t = t0 + threadIdx.x;
         const int c = t < n_tiles ? tile_count[t] : 0;
         const bool nz = c > 0;
+        const int units = (c + kUnitPts - 1) / kUnitPts;
         const unsigned long long bal = __ballot(nz);
         const int rank = __popcll(bal & ((1ull << lane) - 1ull));
         long long pts = c;
+        int uincl = units;  // inclusive wave scan of the units
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(uincl, o);
+            if (lane >= o) uincl += v;
+        }
         for (int o = 32; o > 0; o >>= 1) pts += __shfl_xor(pts, o);
+        if (lane == 63) wunits[wave] = uincl;
         if (lane == 0) {
             wcnt[wave] = __popcll(bal);
             wpts[wave] = pts;
         }
         __syncthreads();
-        int off = s_base;
-        for (int w = 0; w < wave; ++w) off += wcnt[w];
-        if (nz) tile_list[off + rank] = t;
+        int off = s_base, uoff = s_units;
+        for (int w = 0; w < wave; ++w) {
+            off += wcnt[w];
+            uoff += wunits[w];
+        }
+        if (nz) {
+            tile_list[off + rank] = t;
+            tile_cum[off + rank] = uoff + uincl - units;
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
-            int tot = 0;
+            int tot = 0, tu = 0;
             long long tp = 0;
             for (int w = 0; w < 16; ++w) {
                 tot += wcnt[w];
+                tu += wunits[w];
                 tp += wpts[w];
             }
             s_base += tot;
+            s_units += tu;
             s_pts += tp;
         }
         __syncthreads();
     }
+    const int n_list = s_base, total = s_units;
     if (threadIdx.x == 0) {
-        info[0] = s_base;
+        tile_cum[n_list] = total;
+        info[0] = n_list;
         info[1] = s_pts;
+        info[2] = total;
+    }
+    __syncthreads();
+    // first list entry of each group's unit range [g * total / n_groups, ...): largest k with tile_cum[k] <= start
+    for (int g = threadIdx.x; g <= n_groups; g += 1024) {
+        const long long start = (long long)g * total / n_groups;
+        int lo = 0, hi = n_list;  // answer in [0, n_list]
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (mid <= n_list && (long long)tile_cum[mid] <= start) lo = mid;
+            else hi = mid - 1;
+        }
+        group_first[g] = lo;
     }
 }
 
@@ -397,7 +467,9 @@ struct SweepArgs {
     const Pt* pts;  // tile-major compacted points
     const int* tile_count;
     const int* tile_list;
-    const long long* tile_info;  // [0] = number of non-empty tiles
+    const int* tile_cum;         // work units before each list entry (see k_tile_list)
+    const int* group_first;      // first list entry of each tile group
+    const long long* tile_info;  // [0] = non-empty tiles, [1] = kept points, [2] = work units
     const double* tile_bbox;
     const double* lane_params;  // SoA [NP][n_slots]; TRANSLATE: X0, Y0; HOMOGRAPHY: h0..h8
     long long n_slots;          // n_batches * 256
@@ -548,13 +620,13 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
 template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false>
 __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                             int ox, int oy, int W, int H, double px0, double py0,
-                                            const H9& hm, const Pt* __restrict__ pts, int cnt, double pivot_b, int pg) {
+                                            const H9& hm, const Pt* __restrict__ pts, int p_begin, int p_end,
+                                            double pivot_b, int pg) {
+    // points [p_begin, p_end) of the tile: p_begin is a multiple of kChunk * kPointGroups, p_end is one too or the
+    // tile's point count
     const double wmax = (double)(W - 1), hmax = (double)(H - 1);
-#ifdef COREG_DIAG_SKIP_POINTS
-    cnt = min(cnt, COREG_DIAG_SKIP_POINTS);  // diagnostic build only: time everything but the point loop
-#endif
-    const int n_full = cnt / kChunk;
-    for (int c = pg; c < n_full; c += kPointGroups) {
+    const int n_full = p_end / kChunk;
+    for (int c = p_begin / kChunk + pg; c < n_full; c += kPointGroups) {
         const Pt* __restrict__ q = pts + c * kChunk;
         Pt pt[kChunk];
 #pragma unroll
@@ -567,7 +639,7 @@ __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __
     }
     // ragged tail (< kChunk points): owned by the point-group next in the rotation
     if (pg == n_full % kPointGroups) {
-        for (int p = n_full * kChunk; p < cnt; ++p) {
+        for (int p = n_full * kChunk; p < p_end; ++p) {
             const Pt pt = pts[p];
             point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0,
                                                                     py0, hm, pt.b0, pt.b1, pt.a, pt.pad, pivot_b);
@@ -614,14 +686,23 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
 
     const TS* __restrict__ img = (const TS*)a.img;
     const int W = a.W, H = a.H;
-    const int n_tiles = (int)a.tile_info[0];
     const double inf = __builtin_inf();
+    // this tile group's share of the work: units [u_lo, u_hi) of the concatenated compacted points
+    const long long total_units = a.tile_info[2];
+    const int u_lo = (int)((long long)group * total_units / a.n_groups);
+    const int u_hi = (int)((long long)(group + 1) * total_units / a.n_groups);
+    const int n_list = (int)a.tile_info[0];
     const double pivot_b = a.pivots[1];
     const unsigned win = (unsigned)(uintptr_t)lds;  // LDS byte address of the window
 
-    for (int tl = group; tl < n_tiles; tl += a.n_groups) {
+    for (int tl = a.group_first[group]; tl < n_list && u_lo < u_hi; ++tl) {
+        const int ubase = a.tile_cum[tl];
+        if (ubase >= u_hi) break;
         const int tile = a.tile_list[tl];
         const int cnt = a.tile_count[tile];
+        const int p_begin = max(u_lo - ubase, 0) * kUnitPts;
+        const int p_end = min((u_hi - ubase) * kUnitPts, cnt);
+        if (p_begin >= p_end) continue;
         const double* bb = a.tile_bbox + (size_t)tile * 4;
         const double bx0 = bb[0], bx1 = bb[1], by0 = bb[2], by1 = bb[3];
 
@@ -693,14 +774,14 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
             if (interior) {
                 if (!pad_lane)
                     tile_points<MODE, ORDER, TS, true, ROUND, RESID, true>(acc, win, img, pitch, ox, oy, W, H, px0, py0,
-                                                                           hm, pts, cnt, pivot_b, pg);
+                                                                           hm, pts, p_begin, p_end, pivot_b, pg);
             } else {
                 tile_points<MODE, ORDER, TS, true, ROUND, RESID>(acc, win, img, pitch, ox, oy, W, H, px0, py0, hm, pts,
-                                                                 cnt, pivot_b, pg);
+                                                                 p_begin, p_end, pivot_b, pg);
             }
         } else {
-            tile_points<MODE, ORDER, TS, false, ROUND, RESID>(acc, win, img, 0, 0, 0, W, H, px0, py0, hm, pts, cnt,
-                                                              pivot_b, pg);
+            tile_points<MODE, ORDER, TS, false, ROUND, RESID>(acc, win, img, 0, 0, 0, W, H, px0, py0, hm, pts, p_begin,
+                                                              p_end, pivot_b, pg);
         }
     }
 
@@ -749,16 +830,17 @@ struct FinalizeArgs {
     int residus;          // 1: np.std((A - B) / sqrt(A)) over ALL grid points (alignment.py:544-547)
     long long n_required;  // residus: number of grid points G; fewer contributions -> NaN (no mask in that method)
 };
-__global__ void __launch_bounds__(256) k_finalize(const FinalizeArgs a) {
-    // 64 lag slots per block; 4 threads per slot each add every 4th slab, then one adds the four in order
-    __shared__ double red[3][kNumSums][64];
+constexpr int kFinLanes = 16;  // threads per lag slot in k_finalize
+__global__ void __launch_bounds__(64 * kFinLanes) k_finalize(const FinalizeArgs a) {
+    // 64 lag slots per block; kFinLanes threads per slot each add every kFinLanes-th slab, then one adds them in order
+    __shared__ double red[kFinLanes - 1][kNumSums][64];
     const int ls = threadIdx.x & 63, j = threadIdx.x >> 6;
     const long long slot = (long long)blockIdx.x * 64 + ls;
     double s[kNumSums];
 #pragma unroll
     for (int k = 0; k < kNumSums; ++k) s[k] = 0.0;
     if (slot < a.n_slots) {
-        for (int g = j; g < a.n_groups; g += 4) {
+        for (int g = j; g < a.n_groups; g += kFinLanes) {
             const double* p = a.partials + (size_t)g * kNumSums * a.n_slots + slot;
 #pragma unroll
             for (int k = 0; k < kNumSums; ++k) s[k] += p[(size_t)k * a.n_slots];
@@ -772,7 +854,7 @@ __global__ void __launch_bounds__(256) k_finalize(const FinalizeArgs a) {
     if (j != 0 || slot >= a.n_slots) return;
     const long long idx = a.out_index[slot];
     if (idx < 0) return;
-    for (int g = 0; g < 3; ++g) {
+    for (int g = 0; g < kFinLanes - 1; ++g) {
 #pragma unroll
         for (int k = 0; k < kNumSums; ++k) s[k] += red[g][k][ls];
     }

@@ -30,6 +30,52 @@ def shard_bounds(n_lags: int, world: int, rank: int):
     return lo, hi, chunk
 
 
+def block_grid(n1: int, n2: int, world: int):
+    """Factor `world` = g1 x g2 so that the (CRVAL1, CRVAL2) lag plane n1 x n2 is cut in g1 x g2 blocks as square as
+    possible (compact lag patches per GPU = small LDS windows, no padded lanes).  Returns (g1, g2)."""
+    best, best_cost = (world, 1), None
+    for g1 in range(1, world + 1):
+        if world % g1:
+            continue
+        g2 = world // g1
+        b1, b2 = -(-n1 // g1), -(-n2 // g2)  # ceil
+        if g1 > n1 or g2 > n2:
+            continue
+        cost = (abs(b1 - b2), b1 * b2)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = (g1, g2), cost
+    return best
+
+
+def block_bounds(n1: int, n2: int, world: int, rank: int):
+    """Rank's block of the lag plane: (lo1, hi1, lo2, hi2); blocks are ceil-sized, trailing ones may be smaller/empty."""
+    g1, g2 = block_grid(n1, n2, world)
+    b1, b2 = -(-n1 // g1), -(-n2 // g2)
+    r1, r2 = rank // g2, rank % g2
+    return min(r1 * b1, n1), min((r1 + 1) * b1, n1), min(r2 * b2, n2), min((r2 + 1) * b2, n2)
+
+
+def block_gather_index(shape5, world: int):
+    """Index array `perm` (int64, prod(shape5) long) with full.ravel() = gathered[perm], where `gathered` is the
+    concatenation over ranks of each rank's C-order block [hi1-lo1, hi2-lo2, n3, n4, n5] padded to `chunk` values.
+    Returns (perm, chunk)."""
+    n1, n2, n3, n4, n5 = shape5
+    inner = n3 * n4 * n5
+    g1, g2 = block_grid(n1, n2, world)
+    chunk = (-(-n1 // g1)) * (-(-n2 // g2)) * inner
+    perm = np.empty((n1, n2, inner), dtype=np.int64)
+    for r in range(world):
+        lo1, hi1, lo2, hi2 = block_bounds(n1, n2, world, r)
+        if hi1 <= lo1 or hi2 <= lo2:
+            continue
+        w2 = hi2 - lo2
+        i1 = np.arange(lo1, hi1)[:, None, None]
+        i2 = np.arange(lo2, hi2)[None, :, None]
+        k = np.arange(inner)[None, None, :]
+        perm[lo1:hi1, lo2:hi2, :] = r * chunk + ((i1 - lo1) * w2 + (i2 - lo2)) * inner + k
+    return perm.reshape(-1), chunk
+
+
 def allgather_lag_slices(local, n_lags: int, group=None):
     """Concatenate every rank's slice (rank r holds lags [r*chunk, min((r+1)*chunk, n))) into the full raveled map.
 

@@ -141,7 +141,9 @@ int coreg_resample_helioprojective_f64(coreg_handle* h, const coreg_wcs2d* hdr_t
  * alignment.py:799-814 and each lag-point applies _shift_header (alignment.py:401-468) to it.
  * [lag_begin, lag_end) selects a contiguous slice of the C-order raveled lag index (np.array_split-style
  * sharding, alignment.py:677-687); corr_out receives lag_end - lag_begin float64 values
- * (host memory, or device memory when out_on_device != 0). */
+ * (host memory, or device memory when out_on_device != 0).  With a host buffer the call returns when the values are
+ * there; with a device buffer it only enqueues the work on the handle's stream (coreg_set_stream) and returns:
+ * anything ordered after it on that stream -- an RCCL all-gather, a copy -- sees the results. */
 int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const coreg_carr_grid* grid,
                            double solar_r, const coreg_lags* lags, int order, int method, int cdelt_semantics,
                            int64_t lag_begin, int64_t lag_end, double* corr_out, int out_on_device);
@@ -151,7 +153,8 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                                 const coreg_lags* lags, int order, int method, int cdelt_semantics,
                                 int64_t lag_begin, int64_t lag_end, double* corr_out, int out_on_device);
 
-int coreg_last_stats(const coreg_handle* h, coreg_stats* out);
+/* Waits for an in-flight device-output sweep (those return without synchronising the stream). */
+int coreg_last_stats(coreg_handle* h, coreg_stats* out);
 
 /* Tuning / test knobs (name -> integer value). Known names:
  *   "use_lds"      1 (default) stage the gather window in LDS, 0 gather from global memory

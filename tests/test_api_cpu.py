@@ -96,6 +96,27 @@ def test_shard_bounds_cover_range():
             assert seen == list(range(n))
 
 
+def test_block_sharding_covers_plane():
+    """2-D block sharding of the (CRVAL1, CRVAL2) plane: blocks tile the plane, the gather index reassembles it."""
+    from euispice_coreg_amd import parallel
+    assert parallel.block_grid(60, 60, 8) in ((4, 2), (2, 4)) and parallel.block_grid(60, 60, 4) == (2, 2)
+    assert parallel.block_grid(121, 1, 8) == (8, 1)
+    for shape5 in [(60, 60, 1, 1, 1), (61, 7, 2, 1, 3), (5, 9, 1, 1, 1), (3, 1, 1, 2, 1)]:
+        full = np.arange(int(np.prod(shape5)), dtype=np.float64).reshape(shape5)
+        for world in (1, 2, 3, 4, 8):
+            perm, chunk = parallel.block_gather_index(shape5, world)
+            gathered = np.full(world * chunk, np.nan)
+            seen = np.zeros(shape5[:2], dtype=int)
+            for r in range(world):
+                lo1, hi1, lo2, hi2 = parallel.block_bounds(shape5[0], shape5[1], world, r)
+                blk = full[lo1:hi1, lo2:hi2].ravel()
+                assert blk.size <= chunk
+                gathered[r * chunk:r * chunk + blk.size] = blk
+                seen[lo1:hi1, lo2:hi2] += 1
+            assert (seen == 1).all(), (shape5, world)
+            assert np.array_equal(gathered[perm], full.ravel()), (shape5, world)
+
+
 def test_allgather_lag_slices_gloo_world2(tmp_path):
     """N > 1 path on CPU: two ranks (gloo), each 'sweeps' its slice, one all-gather assembles the map."""
     script = tmp_path / "worker.py"
