@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""
+Golden correlation maps for BASELINE.json configs[0]: synthetic 512x512 small-FOV vs 1024x1024 large-FOV,
+helioprojective, lag_crval1/2 in [-5, 5] step 1 arcsec around the injected shift, crota/cdelt fixed,
+parallelism=False CPU path (full large grid, float64 reference -- quirk Q1) and, for comparison, the
+parallelism=True semantics (sub-map, float32 reference).  Produced by the CPU oracle
+(oracle/coreg_oracle.py, itself pinned by rectify_golden.npz / wcs_golden.npz); inputs are regenerated from the seed.
+
+    python tests/golden/make_golden_cfg1.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from euispice_coreg_amd import synthetic  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+SEED = 20220317
+
+
+def scene():
+    return synthetic.make_scene(small_n=512, large_n=1024, seed=SEED)
+
+
+def lags(truth):
+    return (truth["lag_crval1"] + np.arange(-5, 6, 1.0), truth["lag_crval2"] + np.arange(-5, 6, 1.0), None, None, None)
+
+
+if __name__ == "__main__":
+    small, hs, large, hl, truth = scene()
+    lg = lags(truth)
+    serial = H.oracle_helio(small, hs, large, hl, lg, parallelism=False, counts=os.cpu_count())
+    par = H.oracle_helio(small, hs, large, hl, lg, parallelism=True, counts=os.cpu_count())
+    carr = H.oracle_carrington(small, hs, large, hl, lg, (512, 512), (228.0, 262.0), (-12.0, 22.0),
+                               counts=os.cpu_count())
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cfg1_corr.npz")
+    np.savez_compressed(dst, serial=serial, parallel=par, carrington=carr, lag_crval1=lg[0], lag_crval2=lg[1],
+                        seed=SEED, small_sum=np.nansum(small), large_sum=np.nansum(large))
+    for k, v in (("serial", serial), ("parallel", par), ("carrington", carr)):
+        print(k, v.shape, "argmax", np.unravel_index(np.nanargmax(v), v.shape)[:2], "max", np.nanmax(v))
+    print("wrote", dst, os.path.getsize(dst), "bytes")

@@ -294,3 +294,28 @@ def test_errors_are_loud(gpu_handle):
             h2.set_option("no_such_option", 1)
     finally:
         h2.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def test_cfg1_against_committed_golden(gpu_handle):
+    """BASELINE.json configs[0] (512^2 vs 1024^2, 11 x 11 CRVAL lags): GPU sweeps against the committed oracle
+    output tests/golden/cfg1_corr.npz (made by tests/golden/make_golden_cfg1.py) -- serial semantics (full large
+    grid, quirk Q1), parallel semantics (sub-map) and the Carrington frame."""
+    import os
+    from tests.conftest import GOLDEN
+    from tests.golden import make_golden_cfg1 as G
+    g = np.load(os.path.join(GOLDEN, "cfg1_corr.npz"))
+    small, hs, large, hl, truth = G.scene()
+    # same seeded inputs as when the fixture was made
+    assert abs(np.nansum(small) - float(g["small_sum"])) <= 1e-6 * abs(float(g["small_sum"]))
+    assert abs(np.nansum(large) - float(g["large_sum"])) <= 1e-6 * abs(float(g["large_sum"]))
+    lags = G.lags(truth)
+    assert np.array_equal(lags[0], g["lag_crval1"])
+    got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, serial_semantics=True)
+    H.assert_corr_close(got, g["serial"], 1e-7, "cfg1 serial semantics vs golden")
+    got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags)
+    H.assert_corr_close(got, g["parallel"], 1e-7, "cfg1 parallel semantics vs golden")
+    got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, (512, 512), (228.0, 262.0), (-12.0, 22.0))
+    H.assert_corr_close(got, g["carrington"], 1e-10, "cfg1 carrington vs golden")
+    am = np.unravel_index(np.nanargmax(got), got.shape)
+    assert (lags[0][am[0]], lags[1][am[1]]) == (truth["lag_crval1"], truth["lag_crval2"])

@@ -142,3 +142,21 @@ def test_oracle_parallel_fanout_equals_serial():
     a = H.oracle_helio(small, hs, large, hl, lags)
     b = H.oracle_helio(small, hs, large, hl, lags, counts=2)
     assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_cfg1_golden_fixture_is_reproducible():
+    """The committed cfg1 fixture regenerates from its seed: same scene checksums and the oracle reproduces three of its
+    lag-points (a full regeneration takes ~40 s: tests/golden/make_golden_cfg1.py)."""
+    import os
+    from tests.conftest import GOLDEN
+    from tests.golden import make_golden_cfg1 as G
+    from tests import helpers as H
+    g = np.load(os.path.join(GOLDEN, "cfg1_corr.npz"))
+    small, hs, large, hl, truth = G.scene()
+    assert abs(np.nansum(small) - float(g["small_sum"])) <= 1e-9 * abs(float(g["small_sum"]))
+    lags = G.lags(truth)
+    sub = (lags[0][4:6], lags[1][5:6], None, None, None)
+    got = H.oracle_helio(small, hs, large, hl, sub, parallelism=True)
+    assert np.abs(got[:, 0, 0, 0, 0, 0] - g["parallel"][4:6, 5, 0, 0, 0, 0]).max() <= 1e-12
+    am = np.unravel_index(np.nanargmax(g["serial"]), g["serial"].shape)
+    assert (lags[0][am[0]], lags[1][am[1]]) == (truth["lag_crval1"], truth["lag_crval2"])
