@@ -313,6 +313,35 @@ class CoregHandle:
         return {f: getattr(s, f) for f, _ in Stats._fields_}
 
 
+_SHARED = {}
+
+
+def shared_handle(device=-1) -> CoregHandle:
+    """One long-lived handle per device for callers that run many sweeps back to back (jitter correction runs one sweep
+    per image pair, hdrshift caller jitter_correction/jitter_correction.py:101-138): device buffers, pinned staging and
+    the stream are allocated once and re-used.  Closed at interpreter exit."""
+    key = int(device)
+    h = _SHARED.get(key)
+    if h is None or getattr(h, "_h", None) is None:
+        h = CoregHandle(device)
+        _SHARED[key] = h
+    return h
+
+
+def _close_shared():
+    for h in list(_SHARED.values()):
+        try:
+            h.close()
+        except Exception:
+            pass
+    _SHARED.clear()
+
+
+import atexit  # noqa: E402
+
+atexit.register(_close_shared)
+
+
 # host-only helpers (no GPU): used by CPU tests of the header logic
 def shift_header(hdr, d_crval1, d_crval2, d_cdelt1, d_cdelt2, d_crota, cdelt_semantics=CDELT_INTENDED):
     lib = load_library()

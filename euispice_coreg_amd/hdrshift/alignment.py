@@ -242,8 +242,7 @@ class Alignment:
         if remove_fov_limits is not None:
             self._set_remove_fov_limits_to_nan(remove_fov_limits)
         if fov_limits is not None:
-            with _lib.CoregHandle(device) as h0:
-                self._select_fov_in_small_data(fov_limits, h0)
+            self._select_fov_in_small_data(fov_limits, _lib.shared_handle(device))
         self._set_initial_header_values(ang2pipi)
         if np.isnan(self.data_small).all():
             raise ValueError("minimum or maximum value have set all small FOV to nan")  # alignment.py:655-656
@@ -255,7 +254,8 @@ class Alignment:
         solar_rs = np.atleast_1d(np.asarray(self.lag_solar_r, dtype=np.float64))
         lo, hi, chunk = parallel.shard_bounds(lags.size, world, rank)
         out = np.full(lags.shape + (len(solar_rs),), np.nan)
-        with _lib.CoregHandle(device) as h:
+        h = _lib.shared_handle(device)  # long-lived: buffers are re-used by the next Alignment on this device
+        if True:
             h.set_small(self.data_small)
             for kk, solar_r in enumerate(solar_rs):
                 if self.coordinate_frame == "final_carrington":
