@@ -255,26 +255,25 @@ class Alignment:
         lo, hi, chunk = parallel.shard_bounds(lags.size, world, rank)
         out = np.full(lags.shape + (len(solar_rs),), np.nan)
         h = _lib.shared_handle(device)  # long-lived: buffers are re-used by the next Alignment on this device
-        if True:
-            h.set_small(self.data_small)
-            for kk, solar_r in enumerate(solar_rs):
-                if self.coordinate_frame == "final_carrington":
-                    grid = _lib.Grid(self.lonlims, self.latlims, self.shape, numpy_lat_trig=True)
-                    h.prepare_reference_carrington(self.data_large, self.hdr_large, grid, solar_r, self.order)
-                    part = h.sweep_carrington(self.hdr_small, grid, solar_r, lags, order=self.order, method=method,
-                                              cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
+        h.set_small(self.data_small)
+        for kk, solar_r in enumerate(solar_rs):
+            if self.coordinate_frame == "final_carrington":
+                grid = _lib.Grid(self.lonlims, self.latlims, self.shape, numpy_lat_trig=True)
+                h.prepare_reference_carrington(self.data_large, self.hdr_large, grid, solar_r, self.order)
+                part = h.sweep_carrington(self.hdr_small, grid, solar_r, lags, order=self.order, method=method,
+                                          cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
+            else:
+                if self.parallelism:
+                    h.prepare_reference_helioprojective(self.data_large, self.hdr_large, self.hdr_small,
+                                                        self.order)
+                    target = self.hdr_small
                 else:
-                    if self.parallelism:
-                        h.prepare_reference_helioprojective(self.data_large, self.hdr_large, self.hdr_small,
-                                                            self.order)
-                        target = self.hdr_small
-                    else:
-                        h.set_reference_on_grid(self.data_large)  # quirk Q1: full large grid, float64
-                        target = self.hdr_large
-                    part = h.sweep_helioprojective(target, self.hdr_small, lags, order=self.order, method=method,
-                                                   cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
-                if world > 1:
-                    part = parallel.allgather_lag_slices(part, lags.size).cpu().numpy()
-                out[..., kk] = np.asarray(part).reshape(lags.shape)
-            self.last_stats = h.last_stats()
+                    h.set_reference_on_grid(self.data_large)  # quirk Q1: full large grid, float64
+                    target = self.hdr_large
+                part = h.sweep_helioprojective(target, self.hdr_small, lags, order=self.order, method=method,
+                                               cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
+            if world > 1:
+                part = parallel.allgather_lag_slices(part, lags.size).cpu().numpy()
+            out[..., kk] = np.asarray(part).reshape(lags.shape)
+        self.last_stats = h.last_stats()
         return out
