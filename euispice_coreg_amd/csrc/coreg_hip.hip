@@ -103,7 +103,7 @@ struct coreg_handle {
     DevBuf lane_params, out_index, partials, out_dev, tmp_img;
 
     // options
-    int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0;
+    int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1;
 
     coreg_stats stats;
     bool stats_pending = false;   // a device-output sweep is in flight: timings are collected on demand
@@ -519,10 +519,13 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
         if (h->small_f32) SW_Q(M, O, float, R); \
         else SW_Q(M, O, double, R);             \
     } while (0)
-    // TRANSLATE = Carrington (float64 samples); HOMOGRAPHY = helioprojective (samples rounded to float32)
+    // TRANSLATE = Carrington (float64 samples); HOMOGRAPHY[_SERIES] = helioprojective (samples rounded to float32)
     if (mode == MODE_TRANSLATE) {
         if (order == 2) SW_T(MODE_TRANSLATE, 2, false);
         else SW_T(MODE_TRANSLATE, 1, false);
+    } else if (mode == MODE_HOMOGRAPHY_SERIES) {
+        if (order == 2) SW_T(MODE_HOMOGRAPHY_SERIES, 2, true);
+        else SW_T(MODE_HOMOGRAPHY_SERIES, 1, true);
     } else {
         if (order == 2) SW_T(MODE_HOMOGRAPHY, 2, true);
         else SW_T(MODE_HOMOGRAPHY, 1, true);
@@ -735,6 +738,8 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         h->opt_n_groups = value;
     } else if (n == "skew") {
         (void)value;  // accepted for compatibility: the LDS row skew was measured to lose and is gone
+    } else if (n == "h_series") {
+        h->opt_h_series = value ? 1 : 0;
     } else if (n == "patch_w") {
         if (value < 0 || value > kBlock) return fail(h, COREG_EINVAL, "patch_w must be in [0, 256]");
         h->opt_patch_w = value;
@@ -1164,8 +1169,14 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     if (n_batches == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
     const size_t ns = outidx.size();
     std::vector<double> params(9 * ns);
-    for (size_t s = 0; s < ns; ++s)
+    double eps_max = 0.0;  // largest |h6 x + h7 y| over the target grid and all lags
+    for (size_t s = 0; s < ns; ++s) {
         for (int k = 0; k < 9; ++k) params[(size_t)k * ns + s] = hs[s * 9 + k];
+        const double e = std::fabs(hs[s * 9 + 6]) * (double)h->gW + std::fabs(hs[s * 9 + 7]) * (double)h->gH;
+        if (e == e) eps_max = std::max(eps_max, e);
+    }
+    // 1/(1 + eps) = 1 - eps + eps^2 is exact to float64 below ~4e-6 (eps^3 < 1e-16); wider fields divide exactly
+    const int sweep_mode = (h->opt_h_series && eps_max < 4.0e-6) ? MODE_HOMOGRAPHY_SERIES : MODE_HOMOGRAPHY;
     RETCHK(upload_plan(h, params, outidx));
 
     PrecomputeArgs pa;
@@ -1183,7 +1194,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     pa.f1lo = std::floor(fy0) - 3.0;
     pa.f1hi = std::ceil(fy1) + 3.0;
     RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles, pick_groups(h, n_batches, n_tiles)));
-    RETCHK(launch_sweep(h, MODE_HOMOGRAPHY, order, method, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
+    RETCHK(launch_sweep(h, sweep_mode, order, method, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
                         n_tiles, lag_begin, out_dev));
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }

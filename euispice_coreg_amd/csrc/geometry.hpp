@@ -183,6 +183,7 @@ struct HomographyFamily {
         const double s = 1.0 / m.m[2][2];
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) h[3 * i + j] = m.m[i][j] * s;
+        h[8] = 1.0;  // exactly (the series form of the device map relies on it)
     }
 };
 

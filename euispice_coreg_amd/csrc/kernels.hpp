@@ -41,7 +41,9 @@ struct __attribute__((aligned(32))) Pt {
     double b0, b1, a, pad;
 };
 
-enum { MODE_TRANSLATE = 0, MODE_HOMOGRAPHY = 1 };
+// MODE_HOMOGRAPHY_SERIES: same map, denominator 1 + eps inverted as 1 - eps + eps^2 (host guarantees |eps| < 4e-6, i.e.
+// a truncation error below 1e-16 relative); MODE_HOMOGRAPHY divides exactly (any field of view)
+enum { MODE_TRANSLATE = 0, MODE_HOMOGRAPHY = 1, MODE_HOMOGRAPHY_SERIES = 2 };
 
 struct CarrDev {
     const double* sin_lon;  // [n_lon] sin(lon')
@@ -84,6 +86,21 @@ __device__ __forceinline__ void apply_h(const H9& m, double x, double y, double&
     r = fma(r, fma(-w, r, 1.0), r);
     ox = fma(m.h[0], x, fma(m.h[1], y, m.h[2])) * r;
     oy = fma(m.h[3], x, fma(m.h[4], y, m.h[5])) * r;
+}
+
+// h[8] == 1 exactly (host normalisation): w = 1 + eps with eps = h6 x + h7 y
+__device__ __forceinline__ void apply_h_series(const H9& m, double x, double y, double& ox, double& oy) {
+    const double eps = fma(m.h[6], x, m.h[7] * y);
+    const double q = fma(eps, eps, -eps);  // 1/(1 + eps) - 1 up to eps^3
+    const double xn = fma(m.h[0], x, fma(m.h[1], y, m.h[2]));
+    const double yn = fma(m.h[3], x, fma(m.h[4], y, m.h[5]));
+    ox = fma(xn, q, xn);
+    oy = fma(yn, q, yn);
+}
+template <int MODE>
+__device__ __forceinline__ void apply_map(const H9& m, double x, double y, double& ox, double& oy) {
+    if (MODE == MODE_HOMOGRAPHY_SERIES) apply_h_series(m, x, y, ox, oy);
+    else apply_h(m, x, y, ox, oy);
 }
 
 // ---- spline weights of scipy's get_spline_interpolation_weights (ni_splines.c), orders 1 and 2 -----------------
@@ -544,7 +561,7 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
         nx = px0 + b0;  // self.x + term, utils/rectify.py:362
         ny = py0 + b1;
     } else {
-        apply_h(hm, b0, b1, nx, ny);
+        apply_map<MODE>(hm, b0, b1, nx, ny);
     }
     if (INTERIOR || ((nx >= 0.0) & (nx <= wmax) & (ny >= 0.0) & (ny <= hmax))) {
         int sx, sy;
@@ -718,7 +735,7 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 double cx, cy;
-                apply_h(hm, (c & 1) ? bx1 : bx0, (c & 2) ? by1 : by0, cx, cy);
+                apply_map<MODE>(hm, (c & 1) ? bx1 : bx0, (c & 2) ? by1 : by0, cx, cy);
                 mnx = fmin(mnx, cx);
                 mxx = fmax(mxx, cx);
                 mny = fmin(mny, cy);

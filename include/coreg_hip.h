@@ -161,6 +161,8 @@ int coreg_last_stats(coreg_handle* h, coreg_stats* out);
  *   "tile_w"       0 (default, auto) or a power of two in [4, 256]: grid-tile width in points (tile = 1024 pts)
  *   "n_groups"     0 (default, auto): tile groups (partial-sum slabs) per lag batch
  *   "lds_bytes"    dynamic LDS per workgroup for the float64 gather window (default and max 159 KiB)
+ *   "h_series"     1 (default) helioprojective maps with |projective term| < 4e-6 invert 1 + eps as 1 - eps + eps^2
+ *                  (exact to float64 there) instead of dividing; 0 always divide
  *   "patch_w"      0 (default, auto) or the maximum width, in CRVAL1 lags, of a workgroup's lag patch
  * Returns COREG_EINVAL for unknown names. */
 int coreg_set_option(coreg_handle* h, const char* name, int64_t value);
