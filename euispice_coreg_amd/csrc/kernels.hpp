@@ -122,6 +122,21 @@ struct Spline<2> {
         start = (int)f - 1;
     }
 };
+template <int ORDER>
+__device__ __forceinline__ void spline_weights_t(double t, double* w);
+template <>
+__device__ __forceinline__ void spline_weights_t<2>(double t, double* w) {  // t in [-0.5, 0.5)
+    const double u = t * t;
+    w[1] = 0.75 - u;
+    w[0] = fma(0.5, u, fma(-0.5, t, 0.125));
+    w[2] = w[0] + t;
+}
+template <>
+__device__ __forceinline__ void spline_weights_t<1>(double t, double* w) {  // t in [0, 1)
+    w[0] = 1.0 - t;
+    w[1] = t;
+}
+
 template <>
 struct Spline<1> {
     static constexpr int N = 2;
@@ -551,11 +566,72 @@ struct Taps<2> {
 // bounds rule cannot trigger and is not evaluated (padding lanes never get here).
 // RESID (method 'residus', alignment.py:544-547): d = (a - b) / sqrt(a) summed instead of the Pearson moments;
 // `isa` = 1/sqrt(a).  No NaN mask exists in that method: k_finalize returns NaN unless EVERY grid point contributed.
+// pxw, pyw (interior LDS visits): TRANSLATE: lane origin + (0.5 for order 2) - (first tap's offset + window origin), so
+// that trunc(pxw + b0) is the window column of the first tap and fract() gives the spline argument; other modes: the
+// same constant to add to the mapped coordinate.
 template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false>
 __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                           int ox, int oy, int W, int H, double wmax, double hmax, double px0, double py0,
-                                          const H9& hm, double b0, double b1, double av, double isa, double pivot_b) {
+                                          double pxw, double pyw, const H9& hm, double b0, double b1, double av,
+                                          double isa, double pivot_b) {
     constexpr int N = Spline<ORDER>::N;
+    if (INTERIOR && LDS) {
+        // Every sample is inside the image: no bounds rule.  Window-relative coordinate u = coordinate + 0.5 - 1 -
+        // origin (order 2) / coordinate - origin (order 1): trunc(u) = window index of the first tap, fract(u) -> t.
+        // (For TRANSLATE the constant is folded into the lane's origin, which moves the float64 rounding of the sum by
+        // at most one ulp of the coordinate, ~2e-13 px.)
+        double ux, uy;
+        if (MODE == MODE_TRANSLATE) {
+            ux = pxw + b0;
+            uy = pyw + b1;
+        } else {
+            double mx, my;
+            apply_map<MODE>(hm, b0, b1, mx, my);
+            ux = mx + pxw;
+            uy = my + pyw;
+        }
+        const int c0 = (int)ux, r0 = (int)uy;
+        const unsigned a0 = win + 8u * (unsigned)(__mul24(r0, pitch) + c0);
+        const unsigned a1 = a0 + 8u * (unsigned)pitch;
+        const unsigned a2 = a1 + 8u * (unsigned)pitch;
+        Taps<N> tp;
+        tp.issue(a0, a1, a2);
+        double wx[N], wy[N];
+        spline_weights_t<ORDER>(__builtin_amdgcn_fract(ux) - (ORDER == 2 ? 0.5 : 0.0), wx);
+        spline_weights_t<ORDER>(__builtin_amdgcn_fract(uy) - (ORDER == 2 ? 0.5 : 0.0), wy);
+        tp.wait();
+        double v = 0.0;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            double row = 0.0;
+#pragma unroll
+            for (int c = 0; c < N; ++c) row = fma(tp.t[r * N + c], wx[c], row);
+            v = fma(row, wy[r], v);
+        }
+        double bm;
+        if (ROUND) {
+            v = (double)(float)v;  // float32 dst of alignment.py:1024
+            bm = v - pivot_b;
+        } else {
+            bm = v;  // the window holds (pixel - pivot)
+        }
+        if (RESID) {
+            const double d = (av - (ROUND ? v : v + pivot_b)) * isa;
+            if (isfinite(d)) {
+                acc.n += 1;
+                acc.b += d;
+                acc.bb = fma(d, d, acc.bb);
+            }
+        } else if (isfinite(v)) {
+            acc.n += 1;
+            acc.a += av;
+            acc.b += bm;
+            acc.aa = fma(av, av, acc.aa);
+            acc.bb = fma(bm, bm, acc.bb);
+            acc.ab = fma(av, bm, acc.ab);
+        }
+        return;
+    }
     double nx, ny;
     if (MODE == MODE_TRANSLATE) {
         nx = px0 + b0;  // self.x + term, utils/rectify.py:362
@@ -636,8 +712,8 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
 // point-group (c % kPointGroups).  Point data are wave-uniform: the loads below use uniform addresses (scalar loads).
 template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false>
 __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
-                                            int ox, int oy, int W, int H, double px0, double py0,
-                                            const H9& hm, const Pt* __restrict__ pts, int p_begin, int p_end,
+                                            int ox, int oy, int W, int H, double px0, double py0, double pxw,
+                                            double pyw, const H9& hm, const Pt* __restrict__ pts, int p_begin, int p_end,
                                             double pivot_b, int pg) {
     // points [p_begin, p_end) of the tile: p_begin is a multiple of kChunk * kPointGroups, p_end is one too or the
     // tile's point count
@@ -651,15 +727,16 @@ __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __
 #pragma unroll
         for (int k = 0; k < kChunk; ++k)
             point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0,
-                                                                    py0, hm, pt[k].b0, pt[k].b1, pt[k].a, pt[k].pad,
-                                                                    pivot_b);
+                                                                    py0, pxw, pyw, hm, pt[k].b0, pt[k].b1, pt[k].a,
+                                                                    pt[k].pad, pivot_b);
     }
     // ragged tail (< kChunk points): owned by the point-group next in the rotation
     if (pg == n_full % kPointGroups) {
         for (int p = n_full * kChunk; p < p_end; ++p) {
             const Pt pt = pts[p];
             point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0,
-                                                                    py0, hm, pt.b0, pt.b1, pt.a, pt.pad, pivot_b);
+                                                                    py0, pxw, pyw, hm, pt.b0, pt.b1, pt.a, pt.pad,
+                                                                    pivot_b);
         }
     }
 }
@@ -789,16 +866,23 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
             }
             __syncthreads();
             if (interior) {
-                if (!pad_lane)
+                if (!pad_lane) {
+                    // window-relative lane constants (exact: a small integer is subtracted)
+                    const double offx = (ORDER == 2 ? 0.5 : 0.0) - (double)((ORDER == 2 ? 1 : 0) + ox);
+                    const double offy = (ORDER == 2 ? 0.5 : 0.0) - (double)((ORDER == 2 ? 1 : 0) + oy);
+                    const double pxw = MODE == MODE_TRANSLATE ? px0 + offx : offx;
+                    const double pyw = MODE == MODE_TRANSLATE ? py0 + offy : offy;
                     tile_points<MODE, ORDER, TS, true, ROUND, RESID, true>(acc, win, img, pitch, ox, oy, W, H, px0, py0,
-                                                                           hm, pts, p_begin, p_end, pivot_b, pg);
+                                                                           pxw, pyw, hm, pts, p_begin, p_end, pivot_b,
+                                                                           pg);
+                }
             } else {
-                tile_points<MODE, ORDER, TS, true, ROUND, RESID>(acc, win, img, pitch, ox, oy, W, H, px0, py0, hm, pts,
-                                                                 p_begin, p_end, pivot_b, pg);
+                tile_points<MODE, ORDER, TS, true, ROUND, RESID>(acc, win, img, pitch, ox, oy, W, H, px0, py0, 0.0, 0.0, hm,
+                                                                 pts, p_begin, p_end, pivot_b, pg);
             }
         } else {
-            tile_points<MODE, ORDER, TS, false, ROUND, RESID>(acc, win, img, 0, 0, 0, W, H, px0, py0, hm, pts, p_begin,
-                                                              p_end, pivot_b, pg);
+            tile_points<MODE, ORDER, TS, false, ROUND, RESID>(acc, win, img, 0, 0, 0, W, H, px0, py0, 0.0, 0.0, hm, pts,
+                                                              p_begin, p_end, pivot_b, pg);
         }
     }
 
