@@ -116,8 +116,14 @@ def main():
     backend = os.environ.get("COREG_BENCH_BACKEND", "nccl")
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # COREG_BENCH_FORCE_DIST=1: initialise the process group (and run the all-gather) even with one rank, to exercise
+    # the RCCL code path on a one-GPU box
+    use_dist = world > 1 or os.environ.get("COREG_BENCH_FORCE_DIST", "0") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -147,14 +153,14 @@ def main():
     my_lags = _lib.LagSet(lag1[lo1:hi1], lag2[lo2:hi2], None, None, None) if (hi1 > lo1 and hi2 > lo2) else None
     perm_np, chunk = parallel.block_gather_index((lag1.size, lag2.size, 1, 1, 1), world)
     mine = torch.full((chunk,), float("nan"), dtype=torch.float64, device="cuda")
-    gathered = torch.empty((chunk * world,), dtype=torch.float64, device="cuda") if world > 1 else mine
+    gathered = torch.empty((chunk * world,), dtype=torch.float64, device="cuda") if use_dist else mine
     perm = torch.from_numpy(perm_np).to("cuda")
     result = [None]
 
     def step():
         if my_lags is not None:
             h.sweep_carrington(hs, grid, SOLAR_R, my_lags, order=ORDER, out_dev_ptr=mine.data_ptr())
-        if world > 1:
+        if use_dist:
             if backend == "nccl":
                 dist.all_gather_into_tensor(gathered, mine)  # the ONE collective of the path
                 result[0] = gathered[perm]
@@ -168,17 +174,17 @@ def main():
     for _ in range(args.warmup):
         step()
     kernel_ms, pre_ms = [], []
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()  # asynchronous: the host plans step k+1 while the GPU runs step k; nothing is read back in here
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -194,7 +200,7 @@ def main():
             st = h.last_stats()
             kernel_ms.append(st["sweep_kernel_ms"])
             pre_ms.append(st["precompute_ms"])
-    if world > 1:
+    if use_dist:
         dist.barrier()
     corr = result[0].cpu().numpy()
     corr = corr.reshape(lag1.size, lag2.size)
@@ -237,7 +243,7 @@ def main():
             "argmax_lag_arcsec": [float(lag1[am[0]]), float(lag2[am[1]])],
             "injected_shift_arcsec": [truth["lag_crval1"], truth["lag_crval2"]],
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
             # the GPU box gives one GPU's job a 16-core share whatever os.cpu_count() says
             try:
                 avail = len(os.sched_getaffinity(0))
@@ -256,7 +262,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     h.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

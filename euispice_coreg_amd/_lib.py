@@ -69,6 +69,8 @@ SYMBOLS = [
     ("coreg_set_stream", C.c_int, [_P, _P]),
     ("coreg_synchronize", C.c_int, [_P]),
     ("coreg_set_small", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    ("coreg_set_small_f32", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    ("coreg_threshold_small", C.c_int, [_P, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_longlong)]),
     ("coreg_set_reference_on_grid", C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32]),
     ("coreg_prepare_reference_carrington", C.c_int,
      [_P, _P, C.c_int32, C.c_int32, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
@@ -196,6 +198,9 @@ class CoregHandle:
         if rc != COREG_OK:
             self._h = None
             raise CoregError(rc, "coreg_create failed (no HIP device visible?)")
+        # caller-defined identity of the prepared reference now resident on the device (None = unknown): lets a session
+        # that aligns many images to one reference skip decoding and re-preparing it
+        self.reference_tag = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -230,21 +235,37 @@ class CoregHandle:
 
     # -- images
     def set_small(self, img):
-        img = np.ascontiguousarray(img, dtype=np.float64)
+        """Image to align.  float32 arrays (FITS BITPIX=-32 pixels) go up as they are; anything else as float64."""
+        img = np.asarray(img)
         if img.ndim != 2:
             raise ValueError("small image must be 2-D")
-        self._chk(self._lib.coreg_set_small(self._h, img.ctypes.data, img.shape[0], img.shape[1]))
+        if img.dtype == np.float32:
+            img = np.ascontiguousarray(img)
+            self._chk(self._lib.coreg_set_small_f32(self._h, img.ctypes.data, img.shape[0], img.shape[1]))
+        else:
+            img = np.ascontiguousarray(img, dtype=np.float64)
+            self._chk(self._lib.coreg_set_small(self._h, img.ctypes.data, img.shape[0], img.shape[1]))
+
+    def threshold_small(self, vmin=None, vmax=None) -> int:
+        """|v| < vmin or |v| > vmax -> NaN on the resident image to align (alignment.py:876-887); returns the number of
+        finite pixels left."""
+        n = C.c_longlong(0)
+        self._chk(self._lib.coreg_threshold_small(self._h, int(vmin is not None), float(vmin or 0.0),
+                                                  int(vmax is not None), float(vmax or 0.0), C.byref(n)))
+        return int(n.value)
 
     def set_reference_on_grid(self, ref):
         ref = np.ascontiguousarray(ref)
         if ref.ndim != 2 or ref.dtype not in (np.float32, np.float64):
             raise ValueError("reference on grid must be a 2-D float32/float64 array")
         dt = COREG_F32 if ref.dtype == np.float32 else COREG_F64
+        self.reference_tag = None
         self._chk(self._lib.coreg_set_reference_on_grid(self._h, ref.ctypes.data, dt, ref.shape[0], ref.shape[1]))
 
     def prepare_reference_carrington(self, large, hdr_large, grid: Grid, solar_r, order=2):
         large = np.ascontiguousarray(large, dtype=np.float64)
         w = wcs_from_header(hdr_large, carrington=True)
+        self.reference_tag = None
         self._chk(self._lib.coreg_prepare_reference_carrington(self._h, large.ctypes.data, large.shape[0],
                                                                large.shape[1], C.byref(w), C.byref(grid.c),
                                                                float(solar_r), int(order)))
@@ -252,6 +273,7 @@ class CoregHandle:
     def prepare_reference_helioprojective(self, large, hdr_large, hdr_small, order=2):
         large = np.ascontiguousarray(large, dtype=np.float64)
         wl, ws = wcs_from_header(hdr_large), wcs_from_header(hdr_small)
+        self.reference_tag = None
         self._chk(self._lib.coreg_prepare_reference_helioprojective(self._h, large.ctypes.data, large.shape[0],
                                                                     large.shape[1], C.byref(wl), C.byref(ws),
                                                                     int(order)))
@@ -316,11 +338,12 @@ class CoregHandle:
 _SHARED = {}
 
 
-def shared_handle(device=-1) -> CoregHandle:
+def shared_handle(device=-1, slot=0) -> CoregHandle:
     """One long-lived handle per device for callers that run many sweeps back to back (jitter correction runs one sweep
     per image pair, hdrshift caller jitter_correction/jitter_correction.py:101-138): device buffers, pinned staging and
-    the stream are allocated once and re-used.  Closed at interpreter exit."""
-    key = int(device)
+    the stream are allocated once and re-used.  Closed at interpreter exit.  `slot`: independent contexts on the same
+    device (own stream and buffers), one per host thread that drives sweeps concurrently."""
+    key = (int(device), int(slot))
     h = _SHARED.get(key)
     if h is None or getattr(h, "_h", None) is None:
         h = CoregHandle(device)

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -70,6 +71,9 @@ struct PinBuf {  // page-locked host staging (async H2D without a host sync)
     }
 };
 
+constexpr int kMaxDevices = 64;
+std::mutex g_attr_mutex;
+
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
 };
@@ -96,7 +100,7 @@ struct coreg_handle {
     DevBuf t_sin_lon, t_cos_lon, t_cos_lat, t_sin_lat;
     CarrTables tabs;
     std::vector<double> tabs_key;
-    PinBuf pin_params, pin_outidx;
+    PinBuf pin_params, pin_outidx, pin_img;
     // precompute outputs
     DevBuf pts, tile_count, tile_list, tile_cum, group_first, tile_info, tile_bbox;
     // sweep
@@ -498,11 +502,15 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
 #define SW(M, O, TS, R, Q)                                                                                          \
     do {                                                                                                              \
         {                                                                                                             \
-            static size_t attr_bytes = 0; /* per instantiation: raise the dynamic-LDS limit once, not per launch */   \
-            if (lds_bytes > 48 * 1024 && lds_bytes > attr_bytes) {                                                    \
+            /* per instantiation and device: raise the dynamic-LDS limit once, not per launch (handles of several  */ \
+            /* threads share the function attribute, hence the lock)                                                */ \
+            static size_t attr_bytes[kMaxDevices] = {0};                                                              \
+            std::lock_guard<std::mutex> lock(g_attr_mutex);                                                           \
+            size_t& ab = attr_bytes[h->device % kMaxDevices];                                                         \
+            if (lds_bytes > 48 * 1024 && lds_bytes > ab) {                                                            \
                 HIPCHK(hipFuncSetAttribute((const void*)(k_sweep<M, O, TS, R, Q>),                                    \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));              \
-                attr_bytes = lds_bytes;                                                                               \
+                ab = lds_bytes;                                                                                       \
             }                                                                                                         \
         }                                                                                                             \
         HIPCHK(hipEventRecord(ev->a, h->stream));                                                                     \
@@ -688,6 +696,7 @@ void coreg_destroy(coreg_handle* h) {
     for (DevBuf* b : bufs) b->release();
     h->pin_params.release();
     h->pin_outidx.release();
+    h->pin_img.release();
     for (auto& e : h->ev_sweep) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -765,6 +774,54 @@ int coreg_set_small(coreg_handle* h, const double* img, int32_t ny, int32_t nx) 
         RETCHK(device_mean<float>(h, h->small.as<float>(), (long long)n, h->pivots.as<double>() + 1));
     else
         RETCHK(device_mean<double>(h, h->small.as<double>(), (long long)n, h->pivots.as<double>() + 1));
+    return COREG_OK;
+}
+
+int coreg_set_small_f32(coreg_handle* h, const float* img, int32_t ny, int32_t nx) {
+    if (!h) return COREG_EINVAL;
+    if (!img || ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "set_small_f32: bad image");
+    RETCHK(bind_device(h));
+    const size_t n = (size_t)ny * nx;
+    HIPCHK(h->small.reserve(n * sizeof(float)));
+    // through pinned staging: the caller's buffer is free again on return, the copy itself is asynchronous
+    HIPCHK(hipStreamSynchronize(h->stream));  // an earlier upload may still be reading the staging buffer
+    HIPCHK(h->pin_img.reserve(n * sizeof(float)));
+    std::memcpy(h->pin_img.p, img, n * sizeof(float));
+    HIPCHK(hipMemcpyAsync(h->small.p, h->pin_img.p, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    h->small_f32 = true;
+    h->sW = nx;
+    h->sH = ny;
+    return device_mean<float>(h, h->small.as<float>(), (long long)n, h->pivots.as<double>() + 1);
+}
+
+int coreg_threshold_small(coreg_handle* h, int has_min, double vmin, int has_max, double vmax, long long* n_finite) {
+    if (!h) return COREG_EINVAL;
+    if (!h->small.p) return fail(h, COREG_ESTATE, "coreg_set_small has not been called");
+    RETCHK(bind_device(h));
+    const long long n = (long long)h->sW * h->sH;
+    if (has_min || has_max) {
+        const int nb = (int)std::min<long long>((n + 255) / 256, 2048);
+        if (h->small_f32)
+            hipLaunchKernelGGL((k_threshold<float>), dim3(nb), dim3(256), 0, h->stream, h->small.as<float>(), n, has_min,
+                               vmin, has_max, vmax);
+        else
+            hipLaunchKernelGGL((k_threshold<double>), dim3(nb), dim3(256), 0, h->stream, h->small.as<double>(), n, has_min,
+                               vmin, has_max, vmax);
+        HIPCHK(hipGetLastError());
+    }
+    // pivot = mean of what is left (same value as uploading a host-thresholded image)
+    if (h->small_f32)
+        RETCHK(device_mean<float>(h, h->small.as<float>(), n, h->pivots.as<double>() + 1));
+    else
+        RETCHK(device_mean<double>(h, h->small.as<double>(), n, h->pivots.as<double>() + 1));
+    if (n_finite) {
+        long long cnt[256];
+        HIPCHK(hipMemcpyAsync(cnt, h->red_cnt.p, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        long long c = 0;
+        for (int i = 0; i < 256; ++i) c += cnt[i];
+        *n_finite = c;
+    }
     return COREG_OK;
 }
 

@@ -250,6 +250,16 @@ __global__ void k_mean_final(const double* part_sum, const long long* part_cnt, 
     }
 }
 
+// alignment.py:876-887 in place: |v| < vmin or |v| > vmax -> NaN (comparisons with NaN are false, NaN stays NaN)
+template <typename T>
+__global__ void __launch_bounds__(256) k_threshold(T* __restrict__ v, long long n, int has_min, double vmin, int has_max,
+                                                   double vmax) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double x = fabs((double)v[i]);
+        if ((has_min && x < vmin) || (has_max && x > vmax)) v[i] = (T)__builtin_nan("");
+    }
+}
+
 __global__ void k_fill(double* p, long long n, double v) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

@@ -68,6 +68,10 @@ class Alignment:
         self.cdelt_semantics = cdelt_semantics
         self.device = device
         self.last_stats = None
+        # set by the jitter-correction session (jitter_correction/jitter_correction.py):
+        self.shard_lags = True          # False: every rank runs whole sweeps (images, not lags, are spread over GPUs)
+        self._preloaded_small = None    # (data, header) already decoded by the session's prefetch thread
+        self._handle_slot = 0           # which of the device's library contexts this sweep runs in
         # alignment.py:137-140
         for name in ("lag_crval1", "lag_crval2", "lag_crota", "lag_cdelt1", "lag_cdelt2"):
             if getattr(self, name) is None:
@@ -75,14 +79,36 @@ class Alignment:
 
     # ------------------------------------------------------------------------------------------------------------
     def _load(self):
-        dl, hl = fits_io.read_image(self.large_fov_known_pointing, self.large_fov_window)
-        ds, hs = fits_io.read_image(self.small_fov_to_correct, self.small_fov_window)
-        self.data_large = np.array(dl, dtype=np.float64)  # alignment.py:191 / :301
-        self.data_small = np.array(ds, dtype=np.float64)  # alignment.py:198 / :314
-        self.hdr_large = fits_io.Header(hl)
+        """Headers of both files and the pixels of the image to align.  The reference image's pixels are decoded only
+        when `_large_pixels()` is called: a sweep whose prepared reference is still resident on the GPU never does."""
+        self.data_large = None
+        self.hdr_large = fits_io.Header(fits_io.read_header(self.large_fov_known_pointing, self.large_fov_window))
+        if self._preloaded_small is not None:
+            ds, hs = self._preloaded_small
+            self.data_small = np.asarray(ds)  # float32 (BITPIX=-32) pixels stay float32: the float64 cast is exact
+        else:
+            ds, hs = fits_io.read_image(self.small_fov_to_correct, self.small_fov_window)
+            self.data_small = np.array(ds, dtype=np.float64)  # alignment.py:198 / :314
         self.hdr_small = fits_io.Header(hs)
         hdrutil.check_and_create_pcij_matrix(self.hdr_small, self.force_crota_0)  # alignment.py:232 / :310
         hdrutil.check_and_create_pcij_matrix(self.hdr_large, self.force_crota_0)
+
+    def _large_pixels(self):
+        if self.data_large is None:
+            dl, _ = fits_io.read_image(self.large_fov_known_pointing, self.large_fov_window)
+            self.data_large = np.array(dl, dtype=np.float64)  # alignment.py:191 / :301
+        return self.data_large
+
+    def _reference_tag(self, frame, *what):
+        """Identity of a prepared reference: (file identity of the reference image, preparation parameters), or None
+        when the reference image is an in-memory array."""
+        ident = fits_io.file_identity(self.large_fov_known_pointing, self.large_fov_window)
+        if ident is None:
+            return None
+
+        def flat(v):
+            return tuple(np.asarray(v, dtype=np.float64).ravel().tolist())
+        return (ident, frame, bool(self.force_crota_0), int(self.order)) + tuple(flat(w) for w in what)
 
     def _set_initial_header_values(self, ang2pipi=True):
         """alignment.py:799-842."""
@@ -232,19 +258,31 @@ class Alignment:
             raise NotImplementedError  # alignment.py:549
         device = self.device
         rank, world = parallel.world_info()
+        if not self.shard_lags:
+            rank, world = 0, 1
         if device is None:
             device = -1
-            if world > 1:
+            if parallel.world_info()[1] > 1:
                 import torch
                 device = torch.cuda.current_device()
+        h = _lib.shared_handle(device, self._handle_slot)  # long-lived: buffers are re-used by the next Alignment
         # alignment.py:844-861: thresholds, then the box to remove, then the sub-FOV re-grid
-        hdrutil.set_threshold_minmax_to_nan(self.data_small, self.small_fov_value_min, self.small_fov_value_max)
-        if remove_fov_limits is not None:
-            self._set_remove_fov_limits_to_nan(remove_fov_limits)
-        if fov_limits is not None:
-            self._select_fov_in_small_data(fov_limits, _lib.shared_handle(device))
+        on_device = (remove_fov_limits is None) and (fov_limits is None)
+        if on_device:
+            # thresholds applied to the resident copy (self.data_small is left as loaded)
+            h.set_small(self.data_small)
+            n_finite = h.threshold_small(self.small_fov_value_min, self.small_fov_value_max)
+        else:
+            self.data_small = np.array(self.data_small, dtype=np.float64)
+            hdrutil.set_threshold_minmax_to_nan(self.data_small, self.small_fov_value_min, self.small_fov_value_max)
+            if remove_fov_limits is not None:
+                self._set_remove_fov_limits_to_nan(remove_fov_limits)
+            if fov_limits is not None:
+                self._select_fov_in_small_data(fov_limits, h)
+            n_finite = int(np.isfinite(self.data_small).sum())
+            h.set_small(self.data_small)
         self._set_initial_header_values(ang2pipi)
-        if np.isnan(self.data_small).all():
+        if n_finite == 0:
             raise ValueError("minimum or maximum value have set all small FOV to nan")  # alignment.py:655-656
         if self.unit_lag != self.hdr_small["CUNIT1"]:
             raise ValueError("lag.unit and cUNIT are not the same")  # alignment.py:406
@@ -254,21 +292,22 @@ class Alignment:
         solar_rs = np.atleast_1d(np.asarray(self.lag_solar_r, dtype=np.float64))
         lo, hi, chunk = parallel.shard_bounds(lags.size, world, rank)
         out = np.full(lags.shape + (len(solar_rs),), np.nan)
-        h = _lib.shared_handle(device)  # long-lived: buffers are re-used by the next Alignment on this device
-        h.set_small(self.data_small)
         for kk, solar_r in enumerate(solar_rs):
             if self.coordinate_frame == "final_carrington":
                 grid = _lib.Grid(self.lonlims, self.latlims, self.shape, numpy_lat_trig=True)
-                h.prepare_reference_carrington(self.data_large, self.hdr_large, grid, solar_r, self.order)
+                tag = self._reference_tag("carrington", self.lonlims, self.latlims, self.shape, solar_r)
+                if tag is None or tag != h.reference_tag:
+                    h.prepare_reference_carrington(self._large_pixels(), self.hdr_large, grid, solar_r, self.order)
+                    h.reference_tag = tag
                 part = h.sweep_carrington(self.hdr_small, grid, solar_r, lags, order=self.order, method=method,
                                           cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
             else:
                 if self.parallelism:
-                    h.prepare_reference_helioprojective(self.data_large, self.hdr_large, self.hdr_small,
+                    h.prepare_reference_helioprojective(self._large_pixels(), self.hdr_large, self.hdr_small,
                                                         self.order)
                     target = self.hdr_small
                 else:
-                    h.set_reference_on_grid(self.data_large)  # quirk Q1: full large grid, float64
+                    h.set_reference_on_grid(self._large_pixels())  # quirk Q1: full large grid, float64
                     target = self.hdr_large
                 part = h.sweep_helioprojective(target, self.hdr_small, lags, order=self.order, method=method,
                                                cdelt_semantics=sem, lag_begin=lo, lag_end=hi)

@@ -112,3 +112,36 @@ def make_scene(small_n=2048, large_n=3072, seed=20220317, n_blobs=400, pointing_
     truth = {"lag_crval1": pointing_error[0], "lag_crval2": pointing_error[1], "lag_crota": pointing_error[2],
              "blobs": blobs}
     return small, hdr_small, large, hdr_large, truth
+
+
+def make_series(n_frames=5, n=256, seed=7, n_blobs=200, jitter_sigma=1.5, cadence_s=5.0, nan_frac=0.002,
+                jitters=None):
+    """Jittering time series of one HRIEUV-like field (the input of jitter_correction_imagers): every frame is rendered
+    through its TRUE header (nominal CRVAL + jitter_k) and handed out, as float32 pixels, with the NOMINAL header.
+    Frame 0 has no jitter.  Returns ([(data_f32, header), ...], jitters[n_frames, 2] in arcsec)."""
+    rng = np.random.default_rng(seed)
+    fov = 2048 * 0.492
+    cd = fov / n
+    crval = (-310.0, 420.0)
+    if jitters is None:
+        jitters = np.round(rng.normal(0.0, jitter_sigma, size=(n_frames, 2)), 2)
+        jitters[0] = 0.0
+    jitters = np.asarray(jitters, dtype=np.float64)
+    half = 0.5 * fov + 100.0
+    blobs = np.empty((n_blobs, 4))
+    blobs[:, 0] = crval[0] + rng.uniform(-half, half, n_blobs)
+    blobs[:, 1] = crval[1] + rng.uniform(-half, half, n_blobs)
+    blobs[:, 2] = rng.uniform(3.0, 40.0, n_blobs) * 0.492
+    blobs[:, 3] = np.exp(rng.uniform(np.log(50.0), np.log(3000.0), n_blobs))
+    frames = []
+    for k in range(n_frames):
+        sec = 45.277 + cadence_s * k
+        date = "2022-03-17T09:%02d:%06.3f" % (50 + int(sec // 60), sec % 60.0)
+        true = _header(n, n, (n + 1) / 2.0, (n + 1) / 2.0, crval[0] + jitters[k, 0], crval[1] + jitters[k, 1], cd, cd,
+                       3.0, date=date)
+        nominal = _header(n, n, (n + 1) / 2.0, (n + 1) / 2.0, crval[0], crval[1], cd, cd, 3.0, date=date)
+        img = _render(true, blobs, 100.0, rng).astype(np.float32)
+        if nan_frac > 0:
+            img[rng.random(img.shape) < nan_frac] = np.nan
+        frames.append((img, nominal))
+    return frames, jitters

@@ -86,7 +86,7 @@ def _data_size(hdr):
     return n, shape
 
 
-def _read_all(path):
+def _read_all(path, with_data=True):
     hdus = []
     with open(path, "rb") as f:
         while True:
@@ -95,7 +95,9 @@ def _read_all(path):
                 break
             nbytes, shape = _data_size(hdr)
             data = None
-            if nbytes:
+            if nbytes and not with_data:
+                f.seek(((nbytes + BLOCK - 1) // BLOCK) * BLOCK, os.SEEK_CUR)
+            elif nbytes:
                 buf = f.read(((nbytes + BLOCK - 1) // BLOCK) * BLOCK)
                 is_image = hdr.get("SIMPLE") is not None or str(hdr.get("XTENSION", "")).strip() == "IMAGE"
                 if is_image and shape:
@@ -146,6 +148,32 @@ def read_image(path, window=-1):
             raise NotImplementedError("tile-compressed FITS images need astropy.io.fits (not installed)")
         raise ValueError(f"HDU {window!r} of {path} holds no image")
     return data, hdr
+
+
+def read_header(path, window=-1):
+    """Header of one HDU without decoding any pixel data."""
+    if isinstance(path, (tuple, list)) and len(path) == 2:
+        return Header(path[1])
+    try:
+        import astropy.io.fits as afits
+    except ImportError:
+        afits = None
+    if afits is not None:
+        with afits.open(path) as hl:
+            hdu = hl[window]
+            return Header({k: hdu.header[k] for k in hdu.header.keys() if k})
+    if not os.path.exists(str(path)):
+        raise FileNotFoundError(path)
+    hdus = _read_all(path, with_data=False)
+    return hdus[_select(hdus, window)][0]
+
+
+def file_identity(path, window=-1):
+    """Hashable identity of (file contents as far as the OS tells, HDU): None for in-memory (data, header) pairs."""
+    if not isinstance(path, (str, os.PathLike)):
+        return None
+    st = os.stat(path)
+    return (os.path.abspath(os.fspath(path)), st.st_mtime_ns, st.st_size, window)
 
 
 def _card(key, value):

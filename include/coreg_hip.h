@@ -109,6 +109,16 @@ int coreg_synchronize(coreg_handle* h);
  * BITPIX=-32 / integer FITS data cast to float64), else as float64: arithmetic is float64 either way. */
 int coreg_set_small(coreg_handle* h, const double* img, int32_t ny, int32_t nx);
 
+/* Same, for callers that still hold the FITS BITPIX=-32 pixels as float32 (the float64 cast of alignment.py:314 is
+ * exact, so the results are identical): no float64 copy, no exactness scan, pinned staging.  Used by the
+ * jitter-correction session (jitter_correction/jitter_correction.py:101-138), which uploads one image per sweep. */
+int coreg_set_small_f32(coreg_handle* h, const float* img, int32_t ny, int32_t nx);
+
+/* Alignment._set_threshold_minmax_to_nan (alignment.py:876-887) on the resident image to align:
+ * |v| < vmin -> NaN when has_min, |v| > vmax -> NaN when has_max.  *n_finite (optional) receives the number of finite
+ * pixels left: 0 is the reference's "minimum or maximum value have set all small FOV to nan" error (alignment.py:655). */
+int coreg_threshold_small(coreg_handle* h, int has_min, double vmin, int has_max, double vmax, long long* n_finite);
+
 /* Reference image already resampled on the target grid (what alignment.py:646-651 leaves in data_large),
  * [gy][gx], dtype COREG_F32 (helioprojective sub-map, alignment.py:995) or COREG_F64 (Carrington). */
 int coreg_set_reference_on_grid(coreg_handle* h, const void* ref, int dtype, int32_t gy, int32_t gx);

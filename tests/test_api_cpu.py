@@ -140,3 +140,35 @@ def test_allgather_lag_slices_gloo_world2(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_jitter_sublists_follow_reference_formula():
+    """jitter_correction.py:91-98."""
+    from euispice_coreg_amd.jitter_correction.jitter_correction import build_sublists, _time_tag
+    after, before = build_sublists(25, 10, 1)
+    assert [a.tolist() for a in after] == [list(range(0, 11)), list(range(10, 21)), list(range(20, 25))]
+    assert [b.tolist() for b in before] == [[0]]
+    after, _ = build_sublists(7, 3, 2)
+    assert [a.tolist() for a in after] == [[0, 1, 2, 3, 4], [3, 4, 5, 6], [6]]
+    assert _time_tag("2022-03-17T09:50:45.277") == "09_50_45"
+
+
+def test_jitter_rejects_zero_overlap(tmp_path):
+    from euispice_coreg_amd.jitter_correction import jitter_correction_imagers
+    with pytest.raises(ValueError):
+        jitter_correction_imagers([], str(tmp_path), overlap=0)
+
+
+def test_fits_header_only_read_and_identity(tmp_path):
+    from euispice_coreg_amd.utils import fits_io
+    p = str(tmp_path / "a.fits")
+    img = np.arange(12, dtype=np.float32).reshape(3, 4)
+    fits_io.write_images(p, [(None, {"ORIGIN": "x"}), (img, {"CRVAL1": 1.5, "EXTNAME": "IMG", "DATE-AVG": "2022-03-17T09:50:45.277"})])
+    h = fits_io.read_header(p, -1)
+    assert h["CRVAL1"] == 1.5 and h["NAXIS1"] == 4 and h["DATE-AVG"].startswith("2022-03-17T09:50:45")
+    assert fits_io.read_header(p, "IMG")["NAXIS2"] == 3
+    d, h2 = fits_io.read_image(p, -1)
+    assert d.dtype == np.float32 and np.array_equal(d, img) and h2 == h
+    ident = fits_io.file_identity(p, -1)
+    assert ident == fits_io.file_identity(p, -1) and ident[0] == p
+    assert fits_io.file_identity((img, {}), -1) is None

@@ -1,0 +1,127 @@
+"""GPU tests of the jitter-correction session (euispice_coreg_amd.jitter_correction, reference:
+jitter_correction/jitter_correction.py:14-174) on a synthetic jittering series written as FITS files."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+LON, LAT, SHAPE = (236.0, 256.0), (-4.0, 16.0), (200, 200)
+
+
+@pytest.fixture(scope="module")
+def series(tmp_path_factory):
+    from euispice_coreg_amd import synthetic
+    from euispice_coreg_amd.utils import fits_io
+    d = tmp_path_factory.mktemp("series")
+    frames, jit = synthetic.make_series(n_frames=5, n=256, seed=7, jitter_sigma=4.0)
+    paths = []
+    for k, (img, hdr) in enumerate(frames):
+        p = str(d / f"solo_L2_eui-hrieuv174-image_{k:03d}.fits")
+        fits_io.write_images(p, [(None, {}), (img, hdr)])
+        paths.append(p)
+    return paths, frames, jit, d
+
+
+def test_jitter_series_matches_oracle_chain(series, tmp_path):
+    """Every output header = input header + the shift the ORACLE's sweep finds against the same (corrected) reference,
+    following the sublist chain of the reference implementation; and the recovered pointing is the injected jitter."""
+    from euispice_coreg_amd.jitter_correction import jitter_correction_imagers
+    from euispice_coreg_amd.hdrshift import AlignmentResults
+    from euispice_coreg_amd.utils import fits_io
+    paths, frames, jit, _ = series
+    out = str(tmp_path / "out")
+    lag = np.arange(-12.0, 12.5, 1.0)
+    done = jitter_correction_imagers(paths, out, lonlims=LON, latlims=LAT, shape=SHAPE, lag_crval1=lag, lag_crval2=lag,
+                                     sublist_length=2, overlap=1, small_fov_value_max=2800.0)
+    assert [(a, r) for a, r, _ in done] == [(1, 0), (2, 0), (3, 2), (4, 2)]
+    outs = [os.path.join(out, os.path.basename(p)) for p in paths]
+    assert all(os.path.isfile(p) for p in outs)
+    # frame 0 is copied untouched
+    assert open(outs[0], "rb").read() == open(paths[0], "rb").read()
+
+    corrected = {0: dict(frames[0][1])}
+    for idx, ref, res in done:
+        img = frames[idx][0].astype(np.float64)
+        from oracle import coreg_oracle as O
+        O.set_threshold_minmax_to_nan(img, None, 2800.0)
+        ref_img = frames[ref][0].astype(np.float64)
+        want = H.oracle_carrington(img, frames[idx][1], ref_img, corrected[ref], (lag, lag, [0], [0], [0]), SHAPE, LON,
+                                   LAT)
+        H.assert_corr_close(res.corr, want, 1e-10, f"jitter frame {idx} vs {ref}")
+        r = AlignmentResults(want, lag, lag, [0], [0], [0], "arcsec")
+        hdr_out = fits_io.read_header(outs[idx], -1)
+        # the Gaussian sub-lag fit amplifies the 1e-10 differences of the maps: SURVEY 8d gate, 1e-3 arcsec
+        assert abs(hdr_out["CRVAL1"] - (frames[idx][1]["CRVAL1"] + r.shift_arcsec[0])) < 1e-3
+        assert abs(hdr_out["CRVAL2"] - (frames[idx][1]["CRVAL2"] + r.shift_arcsec[1])) < 1e-3
+        corrected[idx] = dict(frames[idx][1], CRVAL1=hdr_out["CRVAL1"], CRVAL2=hdr_out["CRVAL2"])
+        # pixels are carried over unchanged
+        d_out, _ = fits_io.read_image(outs[idx], -1)
+        assert np.array_equal(d_out, frames[idx][0], equal_nan=True)
+        # the injected jitter is recovered (pixel scale 3.9 arcsec, lag step 1 arcsec)
+        assert abs(hdr_out["CRVAL1"] - (frames[idx][1]["CRVAL1"] + jit[idx, 0])) < 1.0
+        assert abs(hdr_out["CRVAL2"] - (frames[idx][1]["CRVAL2"] + jit[idx, 1])) < 1.0
+
+
+def test_reference_stays_resident_within_a_sublist(series, tmp_path, monkeypatch):
+    """One reference preparation per sublist, not per image."""
+    from euispice_coreg_amd import _lib
+    from euispice_coreg_amd.jitter_correction import jitter_correction_imagers
+    paths = series[0]
+    calls = []
+    orig = _lib.CoregHandle.prepare_reference_carrington
+
+    def spy(self, *a, **k):
+        calls.append(1)
+        return orig(self, *a, **k)
+    monkeypatch.setattr(_lib.CoregHandle, "prepare_reference_carrington", spy)
+    lag = np.arange(-2.0, 2.5, 1.0)
+    jitter_correction_imagers(paths, str(tmp_path / "o"), lonlims=LON, latlims=LAT, shape=SHAPE, lag_crval1=lag,
+                              lag_crval2=lag, sublist_length=4, overlap=1, pipeline_depth=1)
+    assert len(calls) == 1  # sublists [0..4] and [4]: four sweeps, one preparation
+    del calls[:]
+    a = jitter_correction_imagers(paths, str(tmp_path / "o2"), lonlims=LON, latlims=LAT, shape=SHAPE, lag_crval1=lag,
+                                  lag_crval2=lag, sublist_length=4, overlap=1, pipeline_depth=2)
+    assert len(calls) <= 2  # one per library context
+    b = jitter_correction_imagers(paths, str(tmp_path / "o3"), lonlims=LON, latlims=LAT, shape=SHAPE, lag_crval1=lag,
+                                  lag_crval2=lag, sublist_length=4, overlap=1, pipeline_depth=1)
+    # the schedule does not change the numbers
+    assert [i for i, _, _ in a] == [i for i, _, _ in b]
+    assert all(np.array_equal(x[2].corr, y[2].corr, equal_nan=True) for x, y in zip(a, b))
+
+
+def test_device_thresholds_equal_host_thresholds(series):
+    """coreg_set_small_f32 + coreg_threshold_small == host-side masking + coreg_set_small, bit for bit."""
+    from euispice_coreg_amd import _lib
+    from oracle import coreg_oracle as O
+    frames = series[1]
+    img32, hdr = frames[1]
+    ref = frames[0][0].astype(np.float64)
+    lag = np.arange(-3.0, 3.5, 1.5)
+    lags = (lag, lag, None, None, None)
+    h = _lib.shared_handle(-1)
+    host = img32.astype(np.float64)
+    O.set_threshold_minmax_to_nan(host, 150.0, 2500.0)
+    a = H.gpu_carrington(h, host, hdr, ref, frames[0][1], lags, SHAPE, LON, LAT)
+    grid = _lib.Grid(LON, LAT, SHAPE)
+    h.set_small(img32)
+    n = h.threshold_small(150.0, 2500.0)
+    assert n == int(np.isfinite(host).sum())
+    b = h.sweep_carrington(hdr, grid, 1.004, _lib.LagSet(*lags)).reshape(a.shape)
+    assert np.array_equal(a, b, equal_nan=True)
+    # float64 storage path (values not representable in float32)
+    img64 = img32.astype(np.float64) * (1.0 + 1e-12)
+    host = img64.copy()
+    O.set_threshold_minmax_to_nan(host, 150.0, 2500.0)
+    a = H.gpu_carrington(h, host, hdr, ref, frames[0][1], lags, SHAPE, LON, LAT)
+    h.set_small(img64)
+    assert h.threshold_small(150.0, 2500.0) == int(np.isfinite(host).sum())
+    b = h.sweep_carrington(hdr, grid, 1.004, _lib.LagSet(*lags)).reshape(a.shape)
+    assert np.array_equal(a, b, equal_nan=True)
+    with pytest.raises(ValueError):
+        from euispice_coreg_amd.hdrshift import Alignment
+        Alignment((ref, frames[0][1]), (img32, hdr), lag, lag, None, None, None,
+                  small_fov_value_min=1e9).align_using_carrington(lonlims=LON, latlims=LAT, shape=SHAPE)
