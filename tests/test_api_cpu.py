@@ -172,3 +172,57 @@ def test_fits_header_only_read_and_identity(tmp_path):
     ident = fits_io.file_identity(p, -1)
     assert ident == fits_io.file_identity(p, -1) and ident[0] == p
     assert fits_io.file_identity((img, {}), -1) is None
+
+
+def test_jitter_session_spreads_images_over_ranks_gloo_world2(tmp_path):
+    """N > 1 schedule of the jitter session on CPU (gloo, 2 ranks): images of a sublist are dealt round-robin, ranks
+    meet between sublists, every corrected file is written exactly once.  The GPU sweep is replaced by a stand-in
+    that returns a correlation map peaked at a lag derived from the image index."""
+    from euispice_coreg_amd.utils import fits_io
+    paths = []
+    for k in range(7):
+        p = str(tmp_path / f"f{k}.fits")
+        hdr = {"CRVAL1": 10.0, "CRVAL2": -5.0, "CDELT1": 1.0, "CDELT2": 1.0, "CUNIT1": "arcsec", "CUNIT2": "arcsec",
+               "CROTA": 0.0, "CRPIX1": 2.0, "CRPIX2": 2.0, "DATE-AVG": "2022-03-17T09:50:%02d.000" % (10 + k)}
+        fits_io.write_images(p, [(None, {}), (np.full((3, 4), float(k), dtype=np.float32), hdr)])
+        paths.append(p)
+    out = str(tmp_path / "out")
+    script = tmp_path / "worker.py"
+    script.write_text(
+        "import os, sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch.distributed as dist\n"
+        "from euispice_coreg_amd.jitter_correction import jitter_correction as J\n"
+        "from euispice_coreg_amd.hdrshift import AlignmentResults\n"
+        "dist.init_process_group('gloo')\n"
+        "rank = dist.get_rank()\n"
+        "lag = np.arange(-4.0, 4.5, 0.5)\n"
+        "class FakeA:\n"
+        "    def __init__(self, path): self.path = path\n"
+        "    def _wrap(self, corr, rt, restore_units):\n"
+        "        return AlignmentResults(corr, lag, lag, None, None, None, 'arcsec', image_to_align_path=self.path,\n"
+        "                                image_to_align_window=-1)\n"
+        "def fake(small_fov_path=None, large_fov_fits_path=None, _preloaded_small=None, **kw):\n"
+        "    assert os.path.isfile(large_fov_fits_path), large_fov_fits_path  # the sublist's reference is on disk\n"
+        "    k = float(_preloaded_small[0][0, 0])\n"
+        "    x, y = np.meshgrid(lag, lag, indexing='ij')\n"
+        "    corr = 0.9 * np.exp(-((x - 0.5 * k) ** 2 + (y + 0.25 * k) ** 2) / 4.0)\n"
+        "    return FakeA(small_fov_path), corr.reshape(len(lag), len(lag), 1, 1, 1, 1)\n"
+        "J._align_hrieuv_with_hrieuv = fake\n"
+        f"done = J.jitter_correction_imagers({paths!r}, {out!r}, lag_crval1=lag, lag_crval2=lag, sublist_length=3,\n"
+        "                                    overlap=1)\n"
+        f"open(os.path.join({str(tmp_path)!r}, 'rank%d.txt' % rank), 'w').write(str(sorted(i for i, _, _ in done)))\n"
+        "dist.barrier(); dist.destroy_process_group()\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29563", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # sublists [0,1,2,3] [3,4,5,6] [6]: rank 0 gets positions 0, 2 of each, rank 1 position 1
+    assert (tmp_path / "rank0.txt").read_text() == "[1, 3, 4, 6]"
+    assert (tmp_path / "rank1.txt").read_text() == "[2, 5]"
+    for k in range(7):
+        h = fits_io.read_header(os.path.join(out, f"f{k}.fits"), -1)
+        want = 10.0 + (0.5 * k if k else 0.0)
+        assert abs(h["CRVAL1"] - want) < 0.05, (k, h["CRVAL1"])
+        assert abs(h["CRVAL2"] - (-5.0 - (0.25 * k if k else 0.0))) < 0.05
