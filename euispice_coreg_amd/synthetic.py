@@ -71,7 +71,8 @@ def _render(hdr, blobs, floor, rng, noise=True):
 
 
 def make_scene(small_n=2048, large_n=3072, seed=20220317, n_blobs=400, pointing_error=(17.0, -9.0, 0.3),
-               nan_frac=0.005, float32_exact=True, small_shape=None, small_cdelt=None, small_unit="arcsec"):
+               nan_frac=0.005, float32_exact=True, small_shape=None, small_cdelt=None, small_unit="arcsec",
+               large_cdelt=None, large_crval=(12.5, -7.25)):
     """Returns (data_small, hdr_small, data_large, hdr_large, truth).
 
     The small image is rendered through the TRUE header (CRVAL = (-310, 420) arcsec, CROTA 3.3 deg for the
@@ -85,7 +86,7 @@ def make_scene(small_n=2048, large_n=3072, seed=20220317, n_blobs=400, pointing_
     sny, snx = small_shape
     if small_cdelt is None:
         small_cdelt = (fov / snx, fov / sny)
-    lcd = 3072 * 4.44 / large_n
+    lcd = 3072 * 4.44 / large_n if large_cdelt is None else float(large_cdelt)
     true_crval = (-310.0, 420.0)
     true_crota = 3.0 + pointing_error[2]
     u = {"arcsec": 1.0, "deg": 1.0 / 3600.0}[small_unit]
@@ -94,7 +95,7 @@ def make_scene(small_n=2048, large_n=3072, seed=20220317, n_blobs=400, pointing_
     hdr_small = _header(snx, sny, (snx + 1) / 2.0, (sny + 1) / 2.0, (true_crval[0] - pointing_error[0]) * u,
                         (true_crval[1] - pointing_error[1]) * u, small_cdelt[0] * u, small_cdelt[1] * u, 3.0,
                         unit=small_unit)
-    hdr_large = _header(large_n, large_n, (large_n + 1) / 2.0, (large_n + 1) / 2.0, 12.5, -7.25, lcd, lcd, 0.0,
+    hdr_large = _header(large_n, large_n, (large_n + 1) / 2.0, (large_n + 1) / 2.0, large_crval[0], large_crval[1], lcd, lcd, 0.0,
                         wavelnth=174, date="2022-03-17T09:50:45.281")
     half = 0.5 * max(small_cdelt[0] * snx, small_cdelt[1] * sny) + 150.0
     blobs = np.empty((n_blobs, 4))
@@ -145,3 +146,24 @@ def make_series(n_frames=5, n=256, seed=7, n_blobs=200, jitter_sigma=1.5, cadenc
             img[rng.random(img.shape) < nan_frac] = np.nan
         frames.append((img, nominal))
     return frames, jitters
+
+
+def make_spice_l2(nx=48, ny=160, nw=16, large_n=192, seed=21, pointing_error=(-23.0, 36.0, 0.0), n_blobs=150):
+    """SPICE-L2-like raster window: 4-D cube [1, nw, ny, nx] (float32) whose sum over wavelength is a helioprojective
+    image with CDELT (4.0, 1.098) arcsec and a known pointing error, plus the FSI-like reference image.
+    Returns (cube, hdr4d, data_large, hdr_large, truth); truth also holds the 2-D image and its (wrong) header."""
+    small, hs, large, hl, truth = make_scene(small_n=ny, large_n=large_n, seed=seed, n_blobs=n_blobs,
+                                             pointing_error=pointing_error, nan_frac=0.0, small_shape=(ny, nx),
+                                             small_cdelt=(4.0, 1.098), float32_exact=False, large_cdelt=4.44,
+                                             large_crval=(-300.0, 400.0))
+    k = np.arange(nw) - (nw - 1) / 2.0
+    prof = np.exp(-0.5 * (k / 2.0) ** 2)
+    prof /= prof.sum()
+    cube = (small[None, :, :] * prof[:, None, None])[None].astype(np.float32)
+    h = dict(hs)
+    h.update({"NAXIS": 4, "NAXIS1": nx, "NAXIS2": ny, "NAXIS3": nw, "NAXIS4": 1, "CTYPE3": "WAVE", "CTYPE4": "TIME",
+              "CUNIT3": "nm", "CUNIT4": "s", "CRPIX3": (nw + 1) / 2.0, "CRPIX4": 1.0, "CRVAL3": 97.7031,
+              "CRVAL4": 600.0, "CDELT3": 0.00973, "CDELT4": 1.0, "PC3_3": 1.0, "PC4_4": 1.0, "PC4_1": -25.2,
+              "NBIN2": 4, "DETECTOR": "SW", "PXBEG2": 200, "SOLAR_B0": -3.0, "RSUN_REF": 695700000.0})
+    truth = dict(truth, image=small, header2d=hs, profile=prof)
+    return cube, h, large, hl, truth

@@ -93,3 +93,33 @@ def test_alignment_refuses_unimplemented_paths(fits_pair):
     with pytest.raises(NotImplementedError):
         A.align_using_carrington(lonlims=(228, 262), latlims=(-12, 22), shape=(32, 32),
                                  method_carrington_reprojection="sunpy")
+
+
+def test_alignment_spice_l2_dropin():
+    """AlignmentSpice on a synthetic L2 raster cube (SURVEY cfg 4 shape: CDELT1 != CDELT2, 2-D header in degrees after
+    flattening, lags in arcsec) against the oracle run on the same prepared image / header."""
+    from euispice_coreg_amd import synthetic
+    from euispice_coreg_amd.hdrshift import AlignmentSpice, AlignmentResults
+    cube, h4, large, hl, truth = synthetic.make_spice_l2()
+    lag1, lag2 = np.arange(-31.0, -14.0, 2.0), np.arange(28.0, 45.0, 2.0)
+    wave_lo, wave_hi = 976.6, 977.5
+    A = AlignmentSpice((large, hl), (cube, h4), lag_crval1=lag1, lag_crval2=lag2, lag_crota=np.array([0.0]),
+                       lag_cdelt1=np.array([0.0]), lag_cdelt2=np.array([0.0]), parallelism=True, level=2,
+                       wavelength_interval_to_sum=[wave_lo, wave_hi])
+    with pytest.warns(UserWarning):  # "Units of headers in deg: modifying inputs units"
+        res = A.align_using_helioprojective(method="correlation")
+    assert isinstance(res, AlignmentResults) and res.corr.shape == (9, 9, 1, 1, 1, 1) and res.unit_lag == "arcsec"
+    want = H.oracle_helio(A.data_small, A.hdr_small, large, hl, (lag1, lag2, [0.0], [0.0], [0.0]), parallelism=True,
+                          unit_lag="arcsec")
+    H.assert_corr_close(res.corr, want, 1e-7, "AlignmentSpice.align_using_helioprojective")
+    am = res.max_index
+    assert (lag1[am[0]], lag2[am[1]]) == (truth["lag_crval1"], truth["lag_crval2"])
+    assert abs(res.shift_arcsec[0] - truth["lag_crval1"]) < 1.0 and abs(res.shift_arcsec[1] - truth["lag_crval2"]) < 1.0
+    # Carrington frame on the same raster (2-D header converted to arcsec, alignment_spice.py:159-168)
+    B = AlignmentSpice((large, hl), (cube, h4), lag_crval1=lag1, lag_crval2=lag2, parallelism=True, level=2)
+    kw = dict(lonlims=(241.0, 247.0), latlims=(3.5, 9.0), shape=(60, 110))
+    resc = B.align_using_carrington(**kw)
+    assert B.hdr_small["CUNIT1"] == "arcsec"
+    wantc = H.oracle_carrington(B.data_small, B.hdr_small, large, hl, (lag1, lag2, None, None, None), kw["shape"],
+                                kw["lonlims"], kw["latlims"])
+    H.assert_corr_close(resc.corr, wantc, 1e-10, "AlignmentSpice.align_using_carrington")

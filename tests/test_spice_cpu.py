@@ -1,0 +1,106 @@
+"""CPU tests of the SPICE data preparation either side of the sweep: 4-D -> 2-D header flattening
+against astropy / wcslib golden vectors, slit geometry, cube collapse (hdrshift/alignment_spice.py:250-323)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(GOLDEN, "spice_header_golden.json")) as f:
+        return json.load(f)
+
+
+def test_celestial_header_equals_astropy_to_header(golden):
+    """Every card WCS(hdr).dropaxis().dropaxis().to_header() writes (astropy 4.3.1 / wcslib 7.6), same values."""
+    from euispice_coreg_amd.utils import spice_header as S
+    assert len(golden["cases"]) >= 4
+    for c in golden["cases"]:
+        flat = S.celestial_header(c["input"])
+        assert set(flat) == set(c["flat"]), c["name"]
+        for k, v in c["flat"].items():
+            assert flat[k] == v, (c["name"], k, flat[k], v)
+        if c["level"] == 2:
+            w = S.wavelengths_angstrom(c["input"]) * 1e-10
+            assert np.max(np.abs(w - np.array(c["wave"])) / np.array(c["wave"])) < 1e-15
+
+
+def test_slit_geometry():
+    """utils/Util.py:431-455."""
+    from euispice_coreg_amd.utils import spice_header as S
+    h = {"NBIN2": 1, "DETECTOR": "SW", "PXBEG2": 101}
+    assert S.slit_pxl(h) == (112, 712)
+    assert S.vertical_edges_limits(h) == (132, 692)
+    h = {"NBIN2": 2, "DETECTOR": "LW", "PXBEG2": 51}
+    assert S.slit_pxl(h) == (75, 388)       # (512-313)/2 = 99.5 -> 99.5 - 25.5 + 1 = 75 ; 412.5 - 24.5 = 388
+    assert S.vertical_edges_limits(h) == (85, 378)
+    with pytest.raises(ValueError):
+        S.slit_pxl({"NBIN2": 1, "DETECTOR": "XX", "PXBEG2": 1})
+
+
+def test_prepare_spice_from_l2_collapses_cube():
+    from euispice_coreg_amd import synthetic
+    from euispice_coreg_amd.hdrshift import AlignmentSpice
+    from euispice_coreg_amd.utils import spice_header as S
+    cube, h4, large, hl, truth = synthetic.make_spice_l2()
+    ymin, ymax = S.vertical_edges_limits(h4)
+    assert (ymin, ymax) == (9, 149)
+    A = AlignmentSpice((large, hl), (cube, h4), lag_crval1=[0.0], lag_crval2=[0.0], level=2)
+    A._extract_spice_data_header(level=2)
+    img = truth["image"]
+    assert A.data_small.shape == img.shape and A.data_small.dtype == np.float64
+    assert np.isnan(A.data_small[:ymin]).all() and np.isnan(A.data_small[ymax:]).all()
+    assert np.allclose(A.data_small[ymin:ymax], img[ymin:ymax], rtol=1e-6)
+    hs = A.hdr_small
+    assert hs["CUNIT1"] == "deg" and hs["NAXIS1"] == img.shape[1] and hs["NAXIS2"] == img.shape[0]
+    assert hs["CROTA"] == h4["CROTA"] and hs["DSUN_OBS"] == h4["DSUN_OBS"] and hs["SOLAR_B0"] == -3.0
+    assert abs(hs["CDELT2"] * 3600 - 1.098) < 1e-12 and abs(hs["CRVAL1"] * 3600 - h4["CRVAL1"]) < 1e-9
+    # wavelength interval: only the pixels inside contribute
+    wave = S.wavelengths_angstrom(h4)
+    lo, hi = wave[5] - 1e-6, wave[9] + 1e-6
+    B = AlignmentSpice((large, hl), (cube, h4), lag_crval1=[0.0], lag_crval2=[0.0], level=2,
+                       wavelength_interval_to_sum=[lo, hi])
+    B._extract_spice_data_header(level=2)
+    frac = truth["profile"][5:10].sum()
+    assert np.allclose(B.data_small[ymin:ymax], frac * img[ymin:ymax], rtol=1e-6)
+    # cut_from_center and sub_fov_window masks
+    C = AlignmentSpice((large, hl), (cube, h4), lag_crval1=[0.0], lag_crval2=[0.0], level=2)
+    C.cut_from_center = 20
+    C._extract_spice_data_header(level=2)
+    xmid = img.shape[1] // 2
+    assert np.isnan(C.data_small[:, :xmid - 11]).all() and np.isnan(C.data_small[:, xmid + 10:]).all()
+    assert np.isfinite(C.data_small[ymin:ymax, xmid - 11:xmid + 10]).all()
+    lon0, lat0 = h4["CRVAL1"], h4["CRVAL2"]
+    D = AlignmentSpice((large, hl), (cube, h4), lag_crval1=[0.0], lag_crval2=[0.0], level=2,
+                       sub_fov_window=[lon0 - 40.0, lon0 + 40.0, lat0 - 50.0, lat0 + 50.0])
+    D._extract_spice_data_header(level=2)
+    n = int(np.isfinite(D.data_small).sum())
+    assert 0 < n < int(np.isfinite(A.data_small).sum())
+    assert abs(n - (80 / 4.0) * (100 / 1.098)) < 0.15 * (80 / 4.0) * (100 / 1.098)
+    with pytest.raises(ValueError):
+        AlignmentSpice((large, hl), (cube, h4), level=None)._extract_spice_data_header(level=None)
+
+
+def test_correct_solar_rotation_shrinks_cdelt1():
+    """alignment_spice.py:223-248 (extend_pixel_size=True)."""
+    from euispice_coreg_amd import synthetic
+    from euispice_coreg_amd.hdrshift import AlignmentSpice
+    cube, h4, large, hl, _ = synthetic.make_spice_l2()
+    A = AlignmentSpice((large, hl), (cube, h4), lag_crval1=[0.0], lag_crval2=[0.0], level=2)
+    A.hdr_large = dict(hl)
+    A.extend_pixel_size = True
+    A._extract_spice_data_header(level=2)
+    # independent evaluation of the same formula
+    B0 = np.deg2rad(-3.0)
+    omega = np.deg2rad(360 / 25.38 / 86400) + np.deg2rad((14.56 - 360 / 25.38 - 2.65 * np.sin(B0) ** 2
+                                                           + 0.96 * np.sin(B0) ** 4) / 86400)
+    R, D = 695700000.0, h4["DSUN_OBS"]
+    rate = np.rad2deg(1.004 * omega * R / (D - 1.004 * R)) * 3600
+    phi = np.arcsin(((D - 1.004 * R) / (1.004 * R)) * np.sin(np.deg2rad(A.hdr_small["CRVAL1"])))
+    want = 4.0 - (-25.2) * rate * np.cos(phi)
+    assert abs(A.hdr_small["CDELT1"] * 3600 - want) < 1e-9
+    assert want > 4.0  # PC4_1 < 0: the raster runs against the rotation
