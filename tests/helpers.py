@@ -81,4 +81,7 @@ def assert_corr_close(got, want, atol, what=""):
     if np.isfinite(want).any():
         d = np.nanmax(np.abs(got - want))
         assert d <= atol, f"{what}: max|dcorr| = {d:.3e} > {atol:.1e}"
-        assert np.nanargmax(got) == np.nanargmax(want), f"{what}: argmax differs"
+        # same argmax -- or, when several lag-points tie to within the tolerance (e.g. CDELT1 lags under the reference's
+        # semantics are no-ops, quirk Q2), an argmax inside the tie
+        if np.nanargmax(got) != np.nanargmax(want):
+            assert want.ravel()[np.nanargmax(got)] >= np.nanmax(want) - atol, f"{what}: argmax differs"

@@ -9,15 +9,15 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def _random_case(seed):
+def _random_case(seed, scale=1):
     rng = np.random.default_rng(seed)
-    ny, nx = int(rng.integers(40, 110)), int(rng.integers(40, 110))
+    ny, nx = int(rng.integers(40, 110)) * scale, int(rng.integers(40, 110)) * scale
     fov = 1008.0
     cd1 = fov / nx * rng.choice([1.0, -1.0]) * rng.uniform(0.8, 1.2)
     cd2 = fov / ny * rng.uniform(0.8, 1.2)
     from euispice_coreg_amd import synthetic
     small, hs, large, hl, truth = synthetic.make_scene(small_shape=(ny, nx), small_cdelt=(abs(cd1), abs(cd2)),
-                                                       large_n=int(rng.integers(96, 160)), seed=seed, n_blobs=150,
+                                                       large_n=int(rng.integers(96, 160)) * scale, seed=seed, n_blobs=150,
                                                        nan_frac=float(rng.choice([0.0, 0.01])),
                                                        float32_exact=bool(rng.integers(0, 2)))
     # scramble the header: sign of CDELT1, rotation, reference pixel off-centre
