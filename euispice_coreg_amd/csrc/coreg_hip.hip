@@ -11,6 +11,7 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "geometry.hpp"
@@ -105,6 +106,7 @@ struct coreg_handle {
     DevBuf pts, tile_count, tile_list, tile_cum, group_first, tile_info, tile_bbox;
     // sweep
     DevBuf lane_params, out_index, partials, out_dev, tmp_img;
+    DevBuf up_f64, up_flag;  // upload staging on the device (float64 copy, exactness flag)
 
     // options
     int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1;
@@ -165,29 +167,61 @@ int device_mean(coreg_handle* h, const T* v, long long n, double* mean_dev) {
     return COREG_OK;
 }
 
-bool all_f32_exact(const double* v, size_t n) {
-    for (size_t i = 0; i < n; ++i) {
-        const double x = v[i];
-        if (x != x) continue;
-        if ((double)(float)x != x) return false;
+// host -> device through pinned staging: worker threads fill the staging buffer segment by segment while the DMA
+// engine drains the previous segment (a plain hipMemcpy from pageable memory runs at a fraction of the link rate)
+void parallel_memcpy(void* dst, const void* src, size_t bytes) {
+    const size_t min_per_thread = (size_t)2 << 20;
+    unsigned nt = (unsigned)std::min<size_t>(8, std::max<size_t>(1, bytes / min_per_thread));
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw > 0) nt = std::min(nt, hw);
+    if (nt <= 1) {
+        std::memcpy(dst, src, bytes);
+        return;
     }
-    return true;
+    std::vector<std::thread> th;
+    const size_t per = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t lo = std::min(bytes, (size_t)t * per), hi = std::min(bytes, lo + per);
+        if (hi > lo) th.emplace_back([=] { std::memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
+    }
+    for (auto& x : th) x.join();
 }
 
-// upload a float64 host image as float32 when exact, else float64
+int staged_upload(coreg_handle* h, void* dev, const void* host, size_t bytes) {
+    HIPCHK(hipStreamSynchronize(h->stream));  // an earlier upload may still be reading the staging buffer
+    HIPCHK(h->pin_img.reserve(bytes));
+    const size_t seg = (size_t)16 << 20;
+    for (size_t off = 0; off < bytes; off += seg) {
+        const size_t len = std::min(seg, bytes - off);
+        parallel_memcpy((char*)h->pin_img.p + off, (const char*)host + off, len);
+        HIPCHK(hipMemcpyAsync((char*)dev + off, (char*)h->pin_img.p + off, len, hipMemcpyHostToDevice, h->stream));
+    }
+    return COREG_OK;
+}
+
+// upload a float64 host image; it is kept as float32 on the device when every finite value is exactly representable
+// (FITS BITPIX=-32 / integer data cast to float64), else as float64.  The test and the conversion run on the GPU.
 int upload_image(coreg_handle* h, const double* img, size_t n, DevBuf& buf, bool* is_f32) {
-    const bool f32 = all_f32_exact(img, n);
-    *is_f32 = f32;
-    if (f32) {
-        std::vector<float> tmp(n);
-        for (size_t i = 0; i < n; ++i) tmp[i] = (float)img[i];
+    HIPCHK(h->up_f64.reserve(n * sizeof(double)));
+    HIPCHK(h->up_flag.reserve(sizeof(int)));
+    RETCHK(staged_upload(h, h->up_f64.p, img, n * sizeof(double)));
+    HIPCHK(hipMemsetAsync(h->up_flag.p, 0, sizeof(int), h->stream));
+    const int nb = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_f32_exact, dim3(nb), dim3(256), 0, h->stream, h->up_f64.as<double>(), (long long)n,
+                       h->up_flag.as<int>());
+    HIPCHK(hipGetLastError());
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, h->up_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *is_f32 = flag == 0;
+    if (*is_f32) {
         HIPCHK(buf.reserve(n * sizeof(float)));
-        HIPCHK(hipMemcpyAsync(buf.p, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));  // tmp goes out of scope
+        hipLaunchKernelGGL(k_f64_to_f32, dim3(nb), dim3(256), 0, h->stream, h->up_f64.as<double>(), (long long)n,
+                           buf.as<float>());
+        HIPCHK(hipGetLastError());
     } else {
-        HIPCHK(buf.reserve(n * sizeof(double)));
-        HIPCHK(hipMemcpyAsync(buf.p, img, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        std::swap(buf.p, h->up_f64.p);  // the float64 copy becomes the image
+        std::swap(buf.cap, h->up_f64.cap);
     }
     return COREG_OK;
 }
@@ -692,7 +726,7 @@ void coreg_destroy(coreg_handle* h) {
     DevBuf* bufs[] = {&h->small, &h->ref, &h->pivots, &h->red_sum, &h->red_cnt, &h->t_sin_lon, &h->t_cos_lon,
                       &h->t_cos_lat, &h->t_sin_lat, &h->pts, &h->tile_count, &h->tile_list, &h->tile_cum, &h->group_first,
                       &h->tile_info, &h->tile_bbox, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
-                      &h->tmp_img};
+                      &h->tmp_img, &h->up_f64, &h->up_flag};
     for (DevBuf* b : bufs) b->release();
     h->pin_params.release();
     h->pin_outidx.release();
@@ -784,10 +818,7 @@ int coreg_set_small_f32(coreg_handle* h, const float* img, int32_t ny, int32_t n
     const size_t n = (size_t)ny * nx;
     HIPCHK(h->small.reserve(n * sizeof(float)));
     // through pinned staging: the caller's buffer is free again on return, the copy itself is asynchronous
-    HIPCHK(hipStreamSynchronize(h->stream));  // an earlier upload may still be reading the staging buffer
-    HIPCHK(h->pin_img.reserve(n * sizeof(float)));
-    std::memcpy(h->pin_img.p, img, n * sizeof(float));
-    HIPCHK(hipMemcpyAsync(h->small.p, h->pin_img.p, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    RETCHK(staged_upload(h, h->small.p, img, n * sizeof(float)));
     h->small_f32 = true;
     h->sW = nx;
     h->sH = ny;
@@ -872,8 +903,7 @@ int coreg_prepare_reference_carrington(coreg_handle* h, const double* large, int
     h->ref_dtype = COREG_F64;
     RETCHK(ref_pivot(h));
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->tmp_img.release();
-    return COREG_OK;
+    return COREG_OK;  // tmp_img stays allocated: the next preparation re-uses it (hipFree would stall the device)
 }
 
 int coreg_prepare_reference_helioprojective(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
@@ -902,8 +932,7 @@ int coreg_prepare_reference_helioprojective(coreg_handle* h, const double* large
     h->ref_dtype = COREG_F32;
     RETCHK(ref_pivot(h));
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->tmp_img.release();
-    return COREG_OK;
+    return COREG_OK;  // tmp_img stays allocated: the next preparation re-uses it (hipFree would stall the device)
 }
 
 int coreg_get_reference_on_grid(coreg_handle* h, void* out, int dtype) {

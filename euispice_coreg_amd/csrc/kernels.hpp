@@ -250,6 +250,20 @@ __global__ void k_mean_final(const double* part_sum, const long long* part_cnt, 
     }
 }
 
+// upload helpers: is every finite value of a float64 image exactly representable in float32?  (flag |= 1 when not)
+__global__ void __launch_bounds__(256) k_f32_exact(const double* __restrict__ v, long long n, int* flag) {
+    int bad = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double x = v[i];
+        if (x == x && (double)(float)x != x) bad = 1;
+    }
+    if (bad) atomicOr(flag, 1);
+}
+__global__ void __launch_bounds__(256) k_f64_to_f32(const double* __restrict__ v, long long n, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = (float)v[i];
+}
+
 // alignment.py:876-887 in place: |v| < vmin or |v| > vmax -> NaN (comparisons with NaN are false, NaN stays NaN)
 template <typename T>
 __global__ void __launch_bounds__(256) k_threshold(T* __restrict__ v, long long n, int has_min, double vmin, int has_max,
