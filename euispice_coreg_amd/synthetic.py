@@ -164,6 +164,24 @@ def make_spice_l2(nx=48, ny=160, nw=16, large_n=192, seed=21, pointing_error=(-2
     h.update({"NAXIS": 4, "NAXIS1": nx, "NAXIS2": ny, "NAXIS3": nw, "NAXIS4": 1, "CTYPE3": "WAVE", "CTYPE4": "TIME",
               "CUNIT3": "nm", "CUNIT4": "s", "CRPIX3": (nw + 1) / 2.0, "CRPIX4": 1.0, "CRVAL3": 97.7031,
               "CRVAL4": 600.0, "CDELT3": 0.00973, "CDELT4": 1.0, "PC3_3": 1.0, "PC4_4": 1.0, "PC4_1": -25.2,
-              "NBIN2": 4, "DETECTOR": "SW", "PXBEG2": 200, "SOLAR_B0": -3.0, "RSUN_REF": 695700000.0})
+              "NBIN2": 4, "DETECTOR": "SW", "PXBEG2": 200, "SOLAR_B0": -3.0, "RSUN_REF": 695700000.0,
+              "DATE-BEG": "2022-03-17T09:40:45.277", "DATEREF": "2022-03-17T09:40:45.277", "TIMESYS": "UTC"})
     truth = dict(truth, image=small, header2d=hs, profile=prof)
     return cube, h, large, hl, truth
+
+
+def make_imager_sequence(large, hdr_large, start="2022-03-17T09:40:00.000", cadence_s=300.0, n_frames=6):
+    """Imager frames for the synthetic-raster builder: the same FSI-like image with a frame-dependent gain
+    (1 + 0.05 k), pointing drift (0.7 k, -0.4 k) arcsec and DATE-AVG = start + k * cadence.  float32 pixels."""
+    import datetime as dt
+    t0 = dt.datetime.strptime(start, "%Y-%m-%dT%H:%M:%S.%f")
+    frames = []
+    for k in range(n_frames):
+        h = dict(hdr_large)
+        h["CRVAL1"] = hdr_large["CRVAL1"] + 0.7 * k
+        h["CRVAL2"] = hdr_large["CRVAL2"] - 0.4 * k
+        t = t0 + dt.timedelta(seconds=cadence_s * k)
+        h["DATE-AVG"] = t.strftime("%Y-%m-%dT%H:%M:%S.%f")[:-3]
+        h["DETECTOR"] = "FSI"
+        frames.append(((large * (1.0 + 0.05 * k)).astype(np.float32), h))
+    return frames

@@ -36,11 +36,23 @@ def _axes(hdr):
     return lon, lat
 
 
-def _mjd(date: str) -> float:
+def parse_date(date: str) -> _dt.datetime:
     s = str(date).strip().rstrip("Z")
     fmt = "%Y-%m-%dT%H:%M:%S.%f" if "." in s else ("%Y-%m-%dT%H:%M:%S" if "T" in s else "%Y-%m-%d")
-    t = _dt.datetime.strptime(s, fmt)
-    return (t - _dt.datetime(1858, 11, 17)).total_seconds() / 86400.0
+    return _dt.datetime.strptime(s, fmt)
+
+
+def _mjd_parts(date: str):
+    """(integer MJD, day fraction), the fraction from the time of day itself (no cancellation)."""
+    t = parse_date(date)
+    days = (t.date() - _dt.date(1858, 11, 17)).days
+    frac = (t.hour * 3600 + t.minute * 60 + t.second + t.microsecond * 1e-6) / 86400.0
+    return days, frac
+
+
+def _mjd(date: str) -> float:
+    days, frac = _mjd_parts(date)
+    return days + frac
 
 
 def celestial_header(hdr) -> Header:
@@ -70,13 +82,18 @@ def celestial_header(hdr) -> Header:
     out["LONPOLE"] = float(hdr.get("LONPOLE", 180.0))
     out["LATPOLE"] = out["CRVAL2"]
     dates = [k for k in ("DATE-OBS", "DATE-BEG", "DATE-AVG", "DATE-END") if k in hdr]
-    if dates:
+    if "DATEREF" in hdr:
+        if "TIMESYS" in hdr:
+            out["TIMESYS"] = str(hdr["TIMESYS"]).strip()
+        out["DATEREF"] = hdr["DATEREF"]
+        days, frac = _mjd_parts(hdr["DATEREF"])
+        out["MJDREFI"] = float(days)
+        out["MJDREFF"] = _p14(frac)
+    elif dates or any(k in hdr for k in ("RSUN_REF", "DSUN_OBS")):
         out["MJDREF"] = 0.0
     for k in dates:
         out[k] = hdr[k]
         out["MJD-" + k[5:]] = _p14(_mjd(hdr[k]))
-    if not dates and any(k in hdr for k in ("RSUN_REF", "DSUN_OBS")):
-        out["MJDREF"] = 0.0
     for k in ("RSUN_REF", "DSUN_OBS", "CRLN_OBS", "CRLT_OBS", "HGLN_OBS", "HGLT_OBS"):
         if k in hdr:
             out[k] = float(hdr[k])
@@ -94,6 +111,39 @@ def wavelengths_angstrom(hdr) -> np.ndarray:
             pc = float(hdr.get("PC%d_%d" % (i, i), 1.0))
             return (float(hdr["CRVAL%d" % i]) + float(hdr["CDELT%d" % i]) * pc * (z + 1.0 - float(hdr["CRPIX%d" % i]))) * to_a
     raise ValueError("no WAVE axis in the SPICE header")
+
+
+def column_times(hdr):
+    """Time of every raster column [s after the reference epoch] and that epoch: the TIME axis of the (x, y, t) WCS
+    the synthetic-raster builder evaluates (synras/map_builder.py:247-288), averaged over the slit as
+    `_return_mean_time` does (:237-243).  world_t = CRVAL4 + CDELT4 * sum_j PC4_j (p_j - CRPIX_j)."""
+    naxis = int(hdr.get("NAXIS", 0))
+    lon, lat = _axes(hdr)
+    tax = None
+    for i in range(1, naxis + 1):
+        if str(hdr.get("CTYPE%d" % i, "")).strip() in ("TIME", "UTC"):
+            tax = i
+    if tax is None:
+        raise ValueError("no TIME axis in the SPICE header")
+    nx, ny = int(hdr["NAXIS%d" % lon]), int(hdr["NAXIS%d" % lat])
+    x = np.arange(nx, dtype=np.float64) + 1.0 - float(hdr.get("CRPIX%d" % lon, 0.0))
+    y = np.arange(ny, dtype=np.float64) + 1.0 - float(hdr.get("CRPIX%d" % lat, 0.0))
+    pc_x = float(hdr.get("PC%d_%d" % (tax, lon), 0.0))
+    pc_y = float(hdr.get("PC%d_%d" % (tax, lat), 0.0))
+    pc_t = float(hdr.get("PC%d_%d" % (tax, tax), 1.0))
+    t0 = 1.0 - float(hdr.get("CRPIX%d" % tax, 0.0))  # first (only) time pixel
+    cd = float(hdr.get("CDELT%d" % tax, 1.0))
+    unit = str(hdr.get("CUNIT%d" % tax, "s")).strip() or "s"
+    to_s = {"s": 1.0, "min": 60.0, "h": 3600.0, "d": 86400.0}[unit]
+    t = float(hdr.get("CRVAL%d" % tax, 0.0)) + cd * (pc_x * x[None, :] + pc_y * y[:, None] + pc_t * t0)
+    ref = None
+    for k in ("DATEREF", "DATE-REF", "DATE-BEG", "DATE-OBS"):
+        if k in hdr:
+            ref = parse_date(hdr[k])
+            break
+    if ref is None:
+        raise ValueError("the SPICE header has no DATEREF / DATE-BEG to anchor its TIME axis")
+    return t.mean(axis=0) * to_s, ref
 
 
 def slit_pxl(header):

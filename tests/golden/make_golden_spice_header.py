@@ -22,7 +22,7 @@ from astropy.io import fits  # noqa: E402
 from astropy.wcs import WCS  # noqa: E402
 
 
-def l2_header(crval1, crval2, crota, cdelt1=4.0, cdelt2=1.098, nx=64, ny=96, nw=20, pc4_1=-60.3):
+def l2_header(crval1, crval2, crota, cdelt1=4.0, cdelt2=1.098, nx=64, ny=96, nw=20, pc4_1=-60.3, dateref=True):
     rho = np.deg2rad(crota)
     lam = cdelt2 / cdelt1
     h = fits.Header()
@@ -40,6 +40,8 @@ def l2_header(crval1, crval2, crota, cdelt1=4.0, cdelt2=1.098, nx=64, ny=96, nw=
         ("CRLT_OBS", -3.1), ("HGLN_OBS", 20.0), ("HGLT_OBS", -3.1), ("DATE-AVG", "2022-03-17T00:20:32.100"),
         ("DATE-OBS", "2022-03-17T00:00:32.100"), ("DATE-BEG", "2022-03-17T00:00:32.100"),
     ]
+    if dateref:
+        cards += [("DATEREF", "2022-03-17T00:00:32.100"), ("TIMESYS", "UTC")]
     for k, v in cards:
         h[k] = v
     return h
@@ -86,7 +88,17 @@ def flatten_l2(h):
     w_xy = w_xyt.dropaxis(2)
     z = np.arange(h["NAXIS3"])
     wave_m = np.asarray(w_wave.wcs_pix2world(z, 0)[0], dtype=np.float64)  # pixel_to_world(z): SpectralCoord in m
-    return w_xy.to_header().copy(), wave_m, str(w_wave.wcs.cunit[0])
+    # synras/map_builder.py:247-288: time of every raster column through the (x, y, t) WCS
+    w3 = w_spice.dropaxis(2)
+    if "DATEREF" not in h:
+        return w_xy.to_header().copy(), wave_m, str(w_wave.wcs.cunit[0]), None, None
+    x, y, t = np.meshgrid(np.arange(h["NAXIS1"]), np.arange(h["NAXIS2"]), np.arange(h["NAXIS4"]))
+    lon, lat, utc = w3.pixel_to_world(x, y, t)
+    from astropy.time import Time
+    ref = Time(h["DATEREF"])
+    col_seconds = np.array([((utc[:, ii, 0] - ref).to("s").value).mean() for ii in range(h["NAXIS1"])])
+    col_iso = [utc[0, ii, 0].isot for ii in (0, h["NAXIS1"] - 1)]
+    return w_xy.to_header().copy(), wave_m, str(w_wave.wcs.cunit[0]), col_seconds, col_iso
 
 
 def flatten_l3(h):
@@ -102,10 +114,12 @@ def main():
     out = {"astropy": __import__("astropy").__version__, "cases": []}
     for name, args in [("l2_a", (-86.1, 416.6, -2.4)), ("l2_b", (512.25, -300.125, 0.0)),
                        ("l2_c", (-1033.0, 12.0, 12.5))]:
-        h = l2_header(*args)
-        flat, wave_m, wunit = flatten_l2(h)
+        h = l2_header(*args, dateref=(name != "l2_b"))
+        flat, wave_m, wunit, col_s, col_iso = flatten_l2(h)
         out["cases"].append({"name": name, "level": 2, "input": cards_of(h), "flat": cards_of(flat),
-                             "wave": wave_m.tolist(), "wave_unit": wunit})
+                             "wave": wave_m.tolist(), "wave_unit": wunit,
+                             "column_seconds": None if col_s is None else col_s.tolist(),
+                             "column_isot_first_last": col_iso})
     for name, args in [("l3_a", (-86.1, 416.6, -2.4))]:
         h = l3_header(*args)
         out["cases"].append({"name": name, "level": 3, "input": cards_of(h), "flat": cards_of(flatten_l3(h))})

@@ -27,6 +27,12 @@ def test_celestial_header_equals_astropy_to_header(golden):
         if c["level"] == 2:
             w = S.wavelengths_angstrom(c["input"]) * 1e-10
             assert np.max(np.abs(w - np.array(c["wave"])) / np.array(c["wave"])) < 1e-15
+        if c.get("column_seconds"):
+            # TIME axis of the (x, y, t) WCS: synras/map_builder.py:247-288
+            t, ref = S.column_times(c["input"])
+            assert np.abs(t - np.array(c["column_seconds"])).max() < 1e-9
+            first = ref + __import__("datetime").timedelta(seconds=float(t[0]))
+            assert first.strftime("%Y-%m-%dT%H:%M:%S.%f")[:-3] == c["column_isot_first_last"][0]
 
 
 def test_slit_geometry():
