@@ -140,6 +140,9 @@ def main():
 
     h = _lib.CoregHandle(local_rank)
     h.set_option("use_lds", args.use_lds)
+    for kv in filter(None, os.environ.get("COREG_BENCH_OPTS", "").split(",")):  # tuning experiments: "opt=val,opt=val"
+        k, v = kv.split("=")
+        h.set_option(k, int(v))
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     grid = _lib.Grid(LONLIMS, LATLIMS, GRID_SHAPE, numpy_lat_trig=True)
     lagset = _lib.LagSet(*lags)

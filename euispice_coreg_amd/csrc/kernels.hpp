@@ -560,6 +560,23 @@ struct Taps<3> {
               "=&v"(t[8])
             : "v"(a0), "v"(a1), "v"(a2));
     }
+    // the wait, placed after everything (w0..w5) depends on has been computed
+    __device__ __forceinline__ void wait_after(double& w0, double& w1, double& w2, double& w3, double& w4, double& w5) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
+                       "+v"(t[8]), "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5));
+    }
+    // same, and pins (fx, fy) to the issue point: arithmetic that starts from them (the spline weights) is scheduled
+    // AFTER the reads have been issued and overlaps their latency
+    __device__ __forceinline__ void issue_before(unsigned a0, unsigned a1, unsigned a2, double& fx, double& fy) {
+        asm volatile(
+            "ds_read_b64 %0, %11\n\tds_read_b64 %1, %11 offset:8\n\tds_read_b64 %2, %11 offset:16\n\t"
+            "ds_read_b64 %3, %12\n\tds_read_b64 %4, %12 offset:8\n\tds_read_b64 %5, %12 offset:16\n\t"
+            "ds_read_b64 %6, %13\n\tds_read_b64 %7, %13 offset:8\n\tds_read_b64 %8, %13 offset:16"
+            : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+              "=&v"(t[8]), "+v"(fx), "+v"(fy)
+            : "v"(a0), "v"(a1), "v"(a2));
+    }
     __device__ __forceinline__ void wait() {
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
@@ -576,6 +593,11 @@ struct Taps<2> {
             : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
             : "v"(a0), "v"(a1));
     }
+    // (only instantiated, never reached: the bilinear path calls issue() / wait())
+    __device__ __forceinline__ void issue_before(unsigned a0, unsigned a1, unsigned a2, double&, double&) {
+        issue(a0, a1, a2);
+    }
+    __device__ __forceinline__ void wait_after(double&, double&, double&, double&, double&, double&) { wait(); }
     __device__ __forceinline__ void wait() {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
     }
@@ -619,11 +641,28 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
         const unsigned a1 = a0 + 8u * (unsigned)pitch;
         const unsigned a2 = a1 + 8u * (unsigned)pitch;
         Taps<N> tp;
-        tp.issue(a0, a1, a2);
         double wx[N], wy[N];
-        spline_weights_t<ORDER>(__builtin_amdgcn_fract(ux) - (ORDER == 2 ? 0.5 : 0.0), wx);
-        spline_weights_t<ORDER>(__builtin_amdgcn_fract(uy) - (ORDER == 2 ? 0.5 : 0.0), wy);
-        tp.wait();
+        if (ORDER == 2) {
+            // f = fract(u) = t + 1/2: the weights of scipy's quadratic B-spline, w0 = (1/2 - t)^2 / 2, w1 = 3/4 - t^2,
+            // w2 = (1/2 + t)^2 / 2, are g^2 / 2, 1/2 + f g, f^2 / 2 with g = 1 - f.  Evaluated DOUBLED (5 operations per
+            // axis instead of 6); the window of an interior visit holds the pixels times 1/4 (exact), which puts the
+            // factor 2 x 2 back.
+            double fx = __builtin_amdgcn_fract(ux), fy = __builtin_amdgcn_fract(uy);
+            tp.issue_before(a0, a1, a2, fx, fy);
+            const double gx = 1.0 - fx, gy = 1.0 - fy;
+            wx[0] = gx * gx;
+            wx[2] = fx * fx;
+            wx[1] = (2.0 - wx[0]) - wx[2];
+            wy[0] = gy * gy;
+            wy[2] = fy * fy;
+            wy[1] = (2.0 - wy[0]) - wy[2];
+            tp.wait_after(wx[0], wx[1], wx[2], wy[0], wy[1], wy[2]);
+        } else {
+            tp.issue(a0, a1, a2);
+            spline_weights_t<ORDER>(__builtin_amdgcn_fract(ux), wx);
+            spline_weights_t<ORDER>(__builtin_amdgcn_fract(uy), wy);
+            tp.wait();
+        }
         double v = 0.0;
 #pragma unroll
         for (int r = 0; r < N; ++r) {
@@ -872,20 +911,41 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
         const int ex = min((int)floor(fmin(mxx, (double)(W - 1))) + 2, W);
         const int ey = min((int)floor(fmin(mxy, (double)(H - 1))) + 2, H);
         const int ww = ex - ox + 1, wh = ey - oy + 1;
-        const int pitch = ww | 1;
+        const int pitch = ww | 1;  // odd pitch: measured best for the ~2-pixel lag lattice (rejected layouts)
         const long long need = (long long)pitch * wh;
         const bool in_lds = a.use_lds && (need <= (long long)a.lds_elems);
 
         const Pt* __restrict__ pts = a.pts + (size_t)tile * kTilePts;
 
         if (in_lds) {
-            for (int r = wave; r < wh; r += kWaves) {
-                const int gy = mirror_idx(oy + r, H);
-                const TS* __restrict__ src = img + (size_t)gy * W;
-                double* dst = lds + r * pitch;
-                for (int c = lane; c < ww; c += 64) {
-                    const double v = (double)src[mirror_idx(ox + c, W)];
-                    dst[c] = ROUND ? v : v - pivot_b;
+            // Stage the window.  The loads are L2 round trips: kStage rows per wave are in flight at a time (one wave
+            // would otherwise wait out ~20 dependent load -> store round trips per visit).
+            constexpr int kStage = 8;
+            // interior visits of the quadratic spline use doubled weights on both axes (see point_lag)
+            const double scale = (interior && ORDER == 2) ? 0.25 : 1.0;
+            // (the row index is wave-uniform: with it in an SGPR the row addresses are scalar arithmetic)
+            const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+            for (int r0 = wave_u; r0 < wh; r0 += kWaves * kStage) {
+                for (int c0 = 0; c0 < ww; c0 += 64) {
+                    const int c = c0 + lane;
+                    const int gx = mirror_idx(ox + min(c, ww - 1), W);
+                    TS v[kStage];
+#pragma unroll
+                    for (int k = 0; k < kStage; ++k) {
+                        const int r = min(r0 + k * kWaves, wh - 1);
+                        const TS* __restrict__ row = img + (size_t)mirror_idx(oy + r, H) * W;
+                        v[k] = row[gx];
+                    }
+                    if (c < ww) {
+#pragma unroll
+                        for (int k = 0; k < kStage; ++k) {
+                            const int r = r0 + k * kWaves;
+                            if (r < wh) {
+                                const double e = (ROUND ? (double)v[k] : (double)v[k] - pivot_b) * scale;
+                                lds[r * pitch + c] = e;
+                            }
+                        }
+                    }
                 }
             }
             __syncthreads();

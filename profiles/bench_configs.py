@@ -26,6 +26,9 @@ def timed(fn, reps=3):
 def main():
     which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4", "cfg5", "dense"]
     h = _lib.CoregHandle(0)
+    for kv in filter(None, os.environ.get("COREG_BENCH_OPTS", "").split(",")):  # tuning experiments: "opt=val,opt=val"
+        k, v = kv.split("=")
+        h.set_option(k, int(v))
     small, hs, large, hl, truth = synthetic.make_scene()
     res = {}
     if "cfg2" in which:  # helioprojective, sub-map semantics, 61 x 61
