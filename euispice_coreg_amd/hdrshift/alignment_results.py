@@ -1,8 +1,8 @@
 """
 `AlignmentResults` -- drop-in for euispice_coreg.hdrshift.AlignmentResults (hdrshift/AlignmentResults.py:23-354):
 argmax of the 6-D correlation array, 2-D Gaussian sub-lag refinement (scipy.optimize.curve_fit, CPU, a few dozen
-points), corrected-header / corrected-FITS output.  Plotting (hdrshift/AlignmentResults.py:93-147 -> plot/plot.py)
-is presentation code outside the accelerated path and raises NotImplementedError here.
+points), corrected-header / corrected-FITS output.  `plot_correlation` draws the correlation map (matplotlib, optional);
+`plot_co_alignment` (image overlays, plot/plot.py) is presentation code outside the path and raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -139,8 +139,48 @@ class AlignmentResults:
         if n_corrected == 0:
             raise ValueError("has not corrected any window.")
 
-    def plot_correlation(self, *a, **k):
-        raise NotImplementedError("plotting is outside the accelerated path (reference: plot/plot.py)")
+    def plot_correlation(self, path_save_figure=None, show=False, fig=None, ax=None):
+        """AlignmentResults.py:93-116 -> plot/plot.py:56-175: the (CRVAL1, CRVAL2) slice of the correlation array through
+        its maximum, with the fitted shift marked.  Needs matplotlib (optional dependency)."""
+        try:
+            import matplotlib
+            if not show:
+                matplotlib.use("Agg", force=False)
+            from matplotlib import pyplot as plt
+        except ImportError as e:  # pragma: no cover
+            raise NotImplementedError("plot_correlation needs matplotlib") from e
+        if self.unit_lag not in ("arcsec", "deg"):
+            raise NotImplementedError
+        unit = "''" if self.unit_lag == "arcsec" else "deg"
+        f = hdrutil.unit_to_deg("arcsec") / hdrutil.unit_to_deg(self.unit_lag)
+        mi = self.max_index
+        corr = np.asarray(self.corr)[:, :, mi[2], mi[3], mi[4]]
+        corr = corr.reshape(corr.shape[0], corr.shape[1], -1)[:, :, 0]
+        lag_dx = self.parameters_alignment_arcsec["lag_crval1"] * f
+        lag_dy = self.parameters_alignment_arcsec["lag_crval2"] * f
+        dx = lag_dx[1] - lag_dx[0] if len(lag_dx) > 1 else 1.0
+        dy = lag_dy[1] - lag_dy[0] if len(lag_dy) > 1 else 1.0
+        if fig is None:
+            fig = plt.figure()
+        if ax is None:
+            ax = fig.add_subplot()
+        finite = corr[np.isfinite(corr)]
+        vmin = np.percentile(finite, 30) if finite.size else None
+        im = ax.imshow(corr.T, origin="lower", interpolation="none", aspect="auto", vmin=vmin,
+                       extent=(lag_dx[0] - 0.5 * dx, lag_dx[-1] + 0.5 * dx, lag_dy[0] - 0.5 * dy, lag_dy[-1] + 0.5 * dy))
+        s = self.shift_arcsec
+        ax.plot(s[0] * f, s[1] * f, marker="+", color="r", markersize=12,
+                label=f"dx={s[0] * f:.2f}{unit}, dy={s[1] * f:.2f}{unit}, dcdelt=({s[2] * f:.3g}, {s[3] * f:.3g}){unit}, "
+                      f"drota={s[4]:.3g} deg")
+        ax.set_xlabel(f"CRVAL1 [{self.unit_lag}]")
+        ax.set_ylabel(f"CRVAL2 [{self.unit_lag}]")
+        ax.legend(loc="best", fontsize=7)
+        fig.colorbar(im, ax=ax, label="correlation")
+        if path_save_figure is not None:
+            fig.savefig(path_save_figure)
+        if show:
+            plt.show()
+        return fig, ax
 
     def plot_co_alignment(self, *a, **k):
         raise NotImplementedError("plotting is outside the accelerated path (reference: plot/plot.py)")

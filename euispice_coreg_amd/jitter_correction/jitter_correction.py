@@ -68,7 +68,9 @@ def jitter_correction_imagers(list_files_input, path_files_output, lonlims=None,
     sublists_after, _sublists_before = build_sublists(len(list_files_input), sublist_length, overlap)
     rank, world = parallel.world_info()
     if path_figures is not None:
-        warnings.warn("figures are not produced by this implementation (plotting is outside the accelerated path)")
+        os.makedirs(path_figures, exist_ok=True)
+        if plot_all_figures:
+            warnings.warn("plot_co_alignment figures are not produced by this implementation")
     os.makedirs(path_files_output, exist_ok=True)
 
     done = []
@@ -96,7 +98,11 @@ def jitter_correction_imagers(list_files_input, path_files_output, lonlims=None,
             _preloaded_small=fut_image.result(), _return_corr=True, _handle_slot=slots.id, **kwargs_carrington)
         out_path = os.path.join(path_files_output, os.path.basename(list_files_input[index_to_align]))
         # sub-lag Gaussian fit + corrected FITS in the writer thread: the GPU is already on the next image
-        return writer.submit(_finish, A, corr, window_files_input, out_path)
+        figure_path = None
+        if path_figures is not None:
+            figure_path = os.path.join(path_figures, f"correlation_{_time_tag(dates[index_to_align])}_"
+                                                     f"{_time_tag(dates[index_ref])}.pdf")
+        return writer.submit(_finish, A, corr, window_files_input, out_path, figure_path)
 
     try:
         for ii, list_ in enumerate(sublists_after):
@@ -125,9 +131,13 @@ def jitter_correction_imagers(list_files_input, path_files_output, lonlims=None,
     return done
 
 
-def _finish(A, corr, window, out_path):
+def _finish(A, corr, window, out_path, figure_path=None):
     results = A._wrap(corr, "AlignmentResults", restore_units=True)
     results.write_corrected_fits(window_list_to_apply_shift=[window], path_to_l3_output=out_path)
+    if figure_path is not None:  # jitter_correction.py:241-243
+        fig, _ = results.plot_correlation(path_save_figure=figure_path)
+        from matplotlib import pyplot as plt
+        plt.close(fig)
     return results
 
 

@@ -226,3 +226,16 @@ def test_jitter_session_spreads_images_over_ranks_gloo_world2(tmp_path):
         want = 10.0 + (0.5 * k if k else 0.0)
         assert abs(h["CRVAL1"] - want) < 0.05, (k, h["CRVAL1"])
         assert abs(h["CRVAL2"] - (-5.0 - (0.25 * k if k else 0.0))) < 0.05
+
+
+def test_plot_correlation_writes_a_figure(tmp_path):
+    """AlignmentResults.plot_correlation (reference: plot/plot.py:56-175) on the reference's own correlation fixture."""
+    pytest.importorskip("matplotlib")
+    from euispice_coreg_amd.hdrshift import AlignmentResults
+    R = AlignmentResults(corr=REF_CORR, lag_crval1=np.arange(15, 26, 1), lag_crval2=np.arange(5, 11, 1),
+                         lag_cdelt1=None, lag_cdelt2=[0], lag_crota=[0.75], unit_lag="arcsec")
+    out = tmp_path / "corr.png"
+    fig, ax = R.plot_correlation(path_save_figure=str(out))
+    assert out.stat().st_size > 1000
+    assert ax.get_xlabel() == "CRVAL1 [arcsec]" and len(ax.images) == 1
+    assert ax.images[0].get_array().shape == (6, 11)

@@ -35,8 +35,10 @@ def test_jitter_series_matches_oracle_chain(series, tmp_path):
     paths, frames, jit, _ = series
     out = str(tmp_path / "out")
     lag = np.arange(-12.0, 12.5, 1.0)
+    figs = str(tmp_path / "figs")
     done = jitter_correction_imagers(paths, out, lonlims=LON, latlims=LAT, shape=SHAPE, lag_crval1=lag, lag_crval2=lag,
-                                     sublist_length=2, overlap=1, small_fov_value_max=2800.0)
+                                     sublist_length=2, overlap=1, small_fov_value_max=2800.0, path_figures=figs)
+    assert len([f for f in os.listdir(figs) if f.startswith("correlation_") and f.endswith(".pdf")]) == 4
     assert [(a, r) for a, r, _ in done] == [(1, 0), (2, 0), (3, 2), (4, 2)]
     outs = [os.path.join(out, os.path.basename(p)) for p in paths]
     assert all(os.path.isfile(p) for p in outs)
