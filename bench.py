@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement after the timed region")
     ap.add_argument("--cpu-sample", type=int, default=0, help="lag-points in the CPU sample (0 = 48 per core)")
     ap.add_argument("--use-lds", type=int, default=1)
     ap.add_argument("--dense", action="store_true", help="extra line: grid tightened onto the small FOV (full overlap)")
@@ -211,7 +212,7 @@ def main():
     # the boundary hands over host buffers: the same step with both images uploaded (and the reference re-prepared) and
     # the map copied back to the host every call -- reported beside `value`, never as `value`
     pcie = None
-    if world == 1:
+    if world == 1 and not args.no_pcie:
         full_lags = _lib.LagSet(*lags)
         times = []
         for _ in range(4):
