@@ -91,8 +91,8 @@ def cpu_baseline(small, hs, large, hl, lags, n_sample, cores):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement after the timed region")
     ap.add_argument("--cpu-sample", type=int, default=0, help="lag-points in the CPU sample (0 = 48 per core)")
