@@ -710,7 +710,8 @@ int coreg_create(coreg_handle** out, int device) {
         hipEventCreate(&h->ev_upload) != hipSuccess || hipEventRecord(h->ev_upload, h->stream) != hipSuccess ||
         h->pivots.reserve(2 * sizeof(double)) != hipSuccess ||
         hipMemsetAsync(h->pivots.p, 0, 2 * sizeof(double), h->stream) != hipSuccess) {
-        delete h;
+        h->own_stream = h->stream != nullptr;
+        coreg_destroy(h);  // releases whatever was created
         return COREG_EHIP;
     }
     h->own_stream = true;

@@ -127,3 +127,35 @@ def test_device_thresholds_equal_host_thresholds(series):
         from euispice_coreg_amd.hdrshift import Alignment
         Alignment((ref, frames[0][1]), (img32, hdr), lag, lag, None, None, None,
                   small_fov_value_min=1e9).align_using_carrington(lonlims=LON, latlims=LAT, shape=SHAPE)
+
+
+def test_two_library_contexts_sweep_concurrently(series):
+    """Two host threads, each with its own handle (own stream and buffers) on the same GPU, run different sweeps at the
+    same time -- the jitter session's driver threads do -- and get the results of the sequential runs, bit for bit."""
+    import threading
+    from euispice_coreg_amd import _lib
+    frames = series[1]
+    ref = frames[0][0].astype(np.float64)
+    grid = _lib.Grid(LON, LAT, SHAPE)
+    lagsets = [_lib.LagSet(np.arange(-6.0, 6.5, 1.0) + 0.25 * k, np.arange(-5.0, 5.5, 1.0), None, None, [0.0, 0.2 * k])
+               for k in range(1, 5)]
+
+    def run(h, k, out):
+        h.set_small(frames[k][0])
+        h.threshold_small(None, 2800.0)
+        out[k] = h.sweep_carrington(frames[k][1], grid, 1.004, lagsets[k - 1])
+
+    hs = [_lib.shared_handle(-1, slot=0), _lib.shared_handle(-1, slot=1)]
+    for h in hs:
+        h.prepare_reference_carrington(ref, frames[0][1], grid, 1.004, 2)
+    seq, par = {}, {}
+    for k in range(1, 5):
+        run(hs[0], k, seq)
+    for rounds in range(3):  # several rounds: the interleaving differs every time
+        th = [threading.Thread(target=lambda i=i: [run(hs[i], k, par) for k in range(1 + i, 5, 2)]) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for k in range(1, 5):
+            assert np.array_equal(seq[k], par[k], equal_nan=True), (rounds, k)
