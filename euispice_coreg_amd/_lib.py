@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("COREG_HIP_LIB", os.path.join(_HERE, "libcoreg_hip.so"
 COREG_OK = 0
 COREG_EINVAL, COREG_EHIP, COREG_ESTATE, COREG_ENOTIMPL, COREG_ENOMEM = -1, -2, -3, -4, -5
 COREG_F32, COREG_F64 = 0, 1
+PROJ_TAN, PROJ_CAR = 0, 1
 METHOD_CORRELATION, METHOD_RESIDUS = 0, 1
 CDELT_INTENDED, CDELT_REFERENCE = 0, 1
 
@@ -35,7 +36,8 @@ class Wcs2d(C.Structure):
                 ("cdelt1", C.c_double), ("cdelt2", C.c_double),
                 ("pc1_1", C.c_double), ("pc1_2", C.c_double), ("pc2_1", C.c_double), ("pc2_2", C.c_double),
                 ("crota", C.c_double), ("unit_to_deg", C.c_double), ("lonpole", C.c_double),
-                ("dsun_obs", C.c_double), ("crln_obs", C.c_double), ("crlt_obs", C.c_double)]
+                ("dsun_obs", C.c_double), ("crln_obs", C.c_double), ("crlt_obs", C.c_double),
+                ("latpole", C.c_double), ("proj", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Lags(C.Structure):
@@ -92,6 +94,7 @@ SYMBOLS = [
     ("coreg_lag_homography", C.c_int,
      [_WP, _WP, C.POINTER(Lags), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
     ("coreg_carrington_origin", C.c_int, [_WP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("coreg_car_map", C.c_int, [_WP, _WP, C.c_int64, _P, _P, _P, _P]),
 ]
 
 _lib = None
@@ -143,7 +146,15 @@ def wcs_from_header(hdr, carrington=False) -> Wcs2d:
     if str(u1).strip() != str(hdr.get("CUNIT2", u1)).strip():
         raise ValueError("CUNIT1 and CUNIT2 must be equal")  # alignment.py:839-840
     w.unit_to_deg = unit_to_deg(u1)
-    w.lonpole = float(hdr.get("LONPOLE", 180.0))
+    # projection: gnomonic (HPLN-TAN / HPLT-TAN) unless the axes say plate carree (CRLN-CAR / CRLT-CAR maps,
+    # alignment.py:365-366); a CAR header without LONPOLE / LATPOLE gets the FITS defaults inside the library
+    if str(hdr.get("CTYPE1", "")).strip().upper().endswith("-CAR"):
+        w.proj = PROJ_CAR
+        w.lonpole = float(hdr["LONPOLE"]) if "LONPOLE" in hdr else float("nan")
+    else:
+        w.proj = PROJ_TAN
+        w.lonpole = float(hdr.get("LONPOLE", 180.0))
+    w.latpole = float(hdr["LATPOLE"]) if "LATPOLE" in hdr else float("nan")
     if carrington:
         w.dsun_obs = float(hdr["DSUN_OBS"])
         w.crln_obs = float(hdr["CRLN_OBS"])
@@ -396,6 +407,22 @@ def lag_homography(hdr_target, hdr_small, lags: "LagSet", idx, cdelt_semantics=C
     if rc < 0:
         raise CoregError(rc, "coreg_lag_homography")
     return rc, np.array(h[:]).reshape(3, 3)
+
+
+def car_map(hdr_from, hdr_to, px, py):
+    """Pixels of a CAR header -> pixels of another CAR header (host, no GPU).  None when a header has no valid pole."""
+    lib = load_library()
+    px = np.ascontiguousarray(px, dtype=np.float64).ravel()
+    py = np.ascontiguousarray(py, dtype=np.float64).ravel()
+    ox, oy = np.empty_like(px), np.empty_like(py)
+    wf, wt = wcs_from_header(hdr_from), wcs_from_header(hdr_to)
+    rc = lib.coreg_car_map(C.byref(wf), C.byref(wt), px.size, px.ctypes.data, py.ctypes.data, ox.ctypes.data,
+                           oy.ctypes.data)
+    if rc == 1:
+        return None
+    if rc != COREG_OK:
+        raise CoregError(rc, "coreg_car_map: bad arguments")
+    return ox, oy
 
 
 def carrington_origin(hdr):

@@ -502,7 +502,8 @@ void fill_precompute_common(coreg_handle* h, PrecomputeArgs* a, int tile_w) {
 // one sweep-kernel launch + finalize over n_batches * 256 slots whose parameters (SoA [np][n_slots]) and output
 // indices are already on the device
 int launch_sweep(coreg_handle* h, int mode, int order, int method, const double* params_dev,
-                 const long long* outidx_dev, int n_batches, int n_tiles, long long lag_begin, double* out_dev) {
+                 const long long* outidx_dev, int n_batches, int n_tiles, long long lag_begin, double* out_dev,
+                 const Aff6* car_inv = nullptr) {
     const long long n_slots = (long long)n_batches * kBlock;
     const int n_groups = pick_groups(h, n_batches, n_tiles);
     HIPCHK(h->partials.reserve((size_t)n_groups * kNumSums * n_slots * sizeof(double)));
@@ -529,6 +530,8 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     const size_t lds_min = (size_t)(kPointGroups - 1) * kNumSums * kBlock * sizeof(double);
     const size_t lds_bytes = std::max(lds_min, a.use_lds ? (size_t)h->opt_lds_bytes : 0);
     a.lds_elems = (int)(lds_bytes / sizeof(double));
+    std::memset(&a.car_inv, 0, sizeof(a.car_inv));
+    if (car_inv) a.car_inv = *car_inv;
 
     const dim3 grid((unsigned)((long long)n_groups * n_batches)), block(kSweepThreads);
     EventPair* ev = next_event(h, h->ev_sweep, h->ev_sweep_used);
@@ -565,6 +568,9 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     if (mode == MODE_TRANSLATE) {
         if (order == 2) SW_T(MODE_TRANSLATE, 2, false);
         else SW_T(MODE_TRANSLATE, 1, false);
+    } else if (mode == MODE_CAR) {
+        if (order == 2) SW_T(MODE_CAR, 2, true);
+        else SW_T(MODE_CAR, 1, true);
     } else if (mode == MODE_HOMOGRAPHY_SERIES) {
         if (order == 2) SW_T(MODE_HOMOGRAPHY_SERIES, 2, true);
         else SW_T(MODE_HOMOGRAPHY_SERIES, 1, true);
@@ -913,6 +919,8 @@ int coreg_prepare_reference_helioprojective(coreg_handle* h, const double* large
     if (!large || !hdr_large || !hdr_small || ny < 1 || nx < 1)
         return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
     if (hdr_small->naxis1 < 1 || hdr_small->naxis2 < 1) return fail(h, COREG_EINVAL, "hdr_small: NAXIS1/2 missing");
+    if (hdr_large->proj != COREG_PROJ_TAN || hdr_small->proj != COREG_PROJ_TAN)
+        return fail(h, COREG_ENOTIMPL, "prepare_reference_helioprojective: TAN headers only");
     RETCHK(check_order(h, order));
     RETCHK(bind_device(h));
     bool f32;
@@ -983,6 +991,8 @@ static int resample_helio(coreg_handle* h, const coreg_wcs2d* hdr_target, const 
     RETCHK(bind_device(h));
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
+    if (hdr_target->proj != COREG_PROJ_TAN || hdr->proj != COREG_PROJ_TAN)
+        return fail(h, COREG_ENOTIMPL, "resample_helioprojective: TAN headers only");
     homography(*hdr_target, *hdr, a.hom.h);  // alignment.py:1022
     a.img = h->small.p;
     a.W = h->sW;
@@ -1147,11 +1157,145 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }
 
+// Plate-carree maps on both sides (Alignment.align_using_initial_carrington, alignment.py:344-399 ->
+// _interpolate_on_large_data_grid :1018-1029 with WCS(CRLN-CAR)): the per-lag map is a rotation of the sphere between
+// the native frames of the two maps (a CRVAL2 lag makes the shifted map oblique).  One precompute (native angles of
+// the target pixels), one sweep launch per (cdelt1, cdelt2, crota) combination (its native -> pixel affine map is a
+// launch constant).  Lags whose header has no valid native pole get NaN (astropy raises for them).
+static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_small, const coreg_lags* lags,
+                     const LagDims& d, int order, int method, int cdelt_semantics, int64_t lag_begin, int64_t lag_end,
+                     double* corr_out, int out_on_device, double* out_dev) {
+    const long long n_out = lag_end - lag_begin;
+    Mat3 r_target;
+    if (car_native_to_celestial(*hdr_target, &r_target))
+        return fail(h, COREG_EINVAL, "hdr_target: no valid native pole for this CRVAL2 / LONPOLE (CAR)");
+    auto shifted = [&](const coreg_wcs2d& base, int i1, int i2) {
+        coreg_wcs2d hl = base;
+        hl.crval1 = hdr_small->crval1 + lags->crval1[i1];  // alignment.py:404
+        hl.crval2 = hdr_small->crval2 + lags->crval2[i2];  // alignment.py:412
+        return hl;
+    };
+    // ---- plan: local geometry from the maps of the central lag and of its two neighbours
+    Geometry geo;
+    {
+        const int c1 = d.n1 / 2, c2 = d.n2 / 2;
+        CarMapHost m0, m1h, m2h;
+        if (m0.init(*hdr_target, shifted(*hdr_small, c1, c2)) ||
+            m1h.init(*hdr_target, shifted(*hdr_small, std::min(c1 + 1, d.n1 - 1), c2)) ||
+            m2h.init(*hdr_target, shifted(*hdr_small, c1, std::min(c2 + 1, d.n2 - 1)))) {
+            geo.dx_di = geo.dy_dj = 1.0;  // central lag invalid: any plan will do, its lanes are NaN
+            geo.dy_di = geo.dx_dj = geo.ax = geo.ay = geo.bx = geo.by = 0.0;
+        } else {
+            const double u = hdr_target->naxis1 * 0.5, v = hdr_target->naxis2 * 0.5;
+            double x0, y0, x1, y1;
+            m0.apply(u, v, &x0, &y0);
+            m0.apply(u + 1, v, &x1, &y1);
+            geo.dx_di = x1 - x0;
+            geo.dy_di = y1 - y0;
+            m0.apply(u, v + 1, &x1, &y1);
+            geo.dx_dj = x1 - x0;
+            geo.dy_dj = y1 - y0;
+            m1h.apply(u, v, &x1, &y1);
+            geo.ax = x1 - x0;
+            geo.ay = y1 - y0;
+            m2h.apply(u, v, &x1, &y1);
+            geo.bx = x1 - x0;
+            geo.by = y1 - y0;
+        }
+    }
+    const long long row = (long long)d.n2 * d.nc;
+    const int m1 = (int)((lag_end - 1) / row) - (int)(lag_begin / row) + 1;
+    const Plan plan = choose_plan(h, geo, m1, d.n2, h->opt_use_lds ? lds_window_elems(h) : (1LL << 40));
+
+    // rotation of every (CRVAL1, CRVAL2) lag: R = R_small(lag)^T * R_target  (PC / CDELT do not enter it)
+    const int i1_lo = (int)(lag_begin / row), i1_hi = (int)((lag_end - 1) / row);
+    std::vector<double> rot((size_t)(i1_hi - i1_lo + 1) * d.n2 * 9);
+    const double nanv = std::numeric_limits<double>::quiet_NaN();
+    for (int i1 = i1_lo; i1 <= i1_hi; ++i1)
+        for (int i2 = 0; i2 < d.n2; ++i2) {
+            double* r = &rot[((size_t)(i1 - i1_lo) * d.n2 + i2) * 9];
+            Mat3 rs;
+            if (car_native_to_celestial(shifted(*hdr_small, i1, i2), &rs)) {
+                for (int k = 0; k < 9; ++k) r[k] = nanv;
+                continue;
+            }
+            const Mat3 m = mat_mul(mat_T(rs), r_target);
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) r[3 * a + b] = (double)m.m[a][b];
+        }
+
+    struct Launch {
+        size_t slot_off;
+        int n_batches;
+        Aff6 inv;
+    };
+    std::vector<Launch> launches;
+    std::vector<double> params;  // per launch: SoA [9][slots of the launch]
+    std::vector<long long> outidx;
+    SlotList slots;
+    for (long long c = 0; c < d.nc; ++c) {
+        const long long first = (lag_begin - c + d.nc - 1) / d.nc;
+        if (first * d.nc + c >= lag_end) continue;
+        const int i5 = (int)(c % d.n5), i4 = (int)((c / d.n5) % d.n4), i3 = (int)(c / ((long long)d.n5 * d.n4));
+        coreg_wcs2d hc;
+        if (shift_header(*hdr_small, 0.0, 0.0, lags->cdelt1[i3], lags->cdelt2[i4], lags->crota[i5], cdelt_semantics,
+                         &hc))
+            continue;  // reference semantics: this lag kills the worker -> NaN (already filled)
+        build_slots(d, c, lag_begin, lag_end, plan.sw, plan.sh, &slots);
+        if (slots.n_batches == 0) continue;
+        const size_t ns = slots.i1.size();
+        Launch L;
+        L.slot_off = outidx.size();
+        L.n_batches = slots.n_batches;
+        const Affine2 inv = car_native_to_pix(hc);
+        L.inv = {inv.m00, inv.m01, inv.m10, inv.m11, inv.b0, inv.b1};
+        const size_t pbase = params.size();
+        params.resize(pbase + 9 * ns);
+        for (size_t s = 0; s < ns; ++s) {
+            const bool pad = slots.outidx[s] < 0;
+            const double* r = &rot[((size_t)(slots.i1[s] - i1_lo) * d.n2 + slots.i2[s]) * 9];
+            for (int k = 0; k < 9; ++k) params[pbase + (size_t)k * ns + s] = pad ? nanv : r[k];
+        }
+        outidx.insert(outidx.end(), slots.outidx.begin(), slots.outidx.end());
+        launches.push_back(L);
+    }
+    if (launches.empty()) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+    RETCHK(upload_plan(h, params, outidx));
+
+    PrecomputeArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    {
+        const int th = kTilePts / plan.tile_w;
+        RETCHK(reserve_tiles(h, ((h->gW + plan.tile_w - 1) / plan.tile_w) * ((h->gH + th - 1) / th)));
+    }
+    fill_precompute_common(h, &pa, plan.tile_w);
+    pa.residus = method == COREG_METHOD_RESIDUS ? 1 : 0;
+    const int n_tiles = pa.tiles_x * pa.tiles_y;
+    const Affine2 fwd = car_pix_to_native(*hdr_target);
+    pa.car_fwd = {fwd.m00, fwd.m01, fwd.m10, fwd.m11, fwd.b0, fwd.b1};
+    const double inf = std::numeric_limits<double>::infinity();
+    pa.f0lo = pa.f1lo = -inf;  // no culling by position: only non-finite reference values drop out
+    pa.f0hi = pa.f1hi = inf;
+    int last_groups = -1;
+    for (const Launch& L : launches) {
+        // the work partition (k_tile_list) depends on the group count of the launch: redo it only when that changes
+        const int ng = pick_groups(h, L.n_batches, n_tiles);
+        if (ng != last_groups) RETCHK(launch_precompute<MODE_CAR>(h, pa, n_tiles, ng));
+        last_groups = ng;
+        RETCHK(launch_sweep(h, MODE_CAR, order, method, h->lane_params.as<double>() + 9 * L.slot_off,
+                            h->out_index.as<long long>() + L.slot_off, L.n_batches, n_tiles, lag_begin, out_dev,
+                            &L.inv));
+    }
+    return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+}
+
 int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_small,
                                 const coreg_lags* lags, int order, int method, int cdelt_semantics, int64_t lag_begin,
                                 int64_t lag_end, double* corr_out, int out_on_device) {
     if (!h) return COREG_EINVAL;
     if (!hdr_target || !hdr_small) return fail(h, COREG_EINVAL, "sweep_helioprojective: null header");
+    if (hdr_target->proj != hdr_small->proj || (hdr_small->proj != COREG_PROJ_TAN && hdr_small->proj != COREG_PROJ_CAR))
+        return fail(h, COREG_ENOTIMPL, "both headers must be TAN (helioprojective) or both CAR (Carrington maps)");
     if (method != COREG_METHOD_CORRELATION && method != COREG_METHOD_RESIDUS)
         return fail(h, COREG_ENOTIMPL, "method must be COREG_METHOD_CORRELATION or COREG_METHOD_RESIDUS");
     RETCHK(check_order(h, order));
@@ -1164,6 +1308,9 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     double* out_dev = nullptr;
     RETCHK(begin_sweep(h, n_out, corr_out, out_on_device, &out_dev));
     if (n_out == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+    if (hdr_small->proj == COREG_PROJ_CAR)
+        return sweep_car(h, hdr_target, hdr_small, lags, d, order, method, cdelt_semantics, lag_begin, lag_end, corr_out,
+                         out_on_device, out_dev);
 
     // ---- plan: local geometry from the maps of the central lag and of its two neighbours
     Geometry geo;
@@ -1301,8 +1448,19 @@ int coreg_shift_header(const coreg_wcs2d* ref, double d_crval1, double d_crval2,
     return shift_header(*ref, d_crval1, d_crval2, d_cdelt1, d_cdelt2, d_crota, cdelt_semantics, out);
 }
 
+int coreg_car_map(const coreg_wcs2d* from, const coreg_wcs2d* to, int64_t n, const double* px, const double* py,
+                  double* ox, double* oy) {
+    if (!from || !to || n < 0 || (n > 0 && (!px || !py || !ox || !oy))) return COREG_EINVAL;
+    if (from->proj != COREG_PROJ_CAR || to->proj != COREG_PROJ_CAR) return COREG_EINVAL;
+    CarMapHost m;
+    if (m.init(*from, *to)) return 1;
+    for (int64_t i = 0; i < n; ++i) m.apply(px[i], py[i], &ox[i], &oy[i]);
+    return COREG_OK;
+}
+
 int coreg_homography(const coreg_wcs2d* from, const coreg_wcs2d* to, double* h9) {
     if (!from || !to || !h9) return COREG_EINVAL;
+    if (from->proj != COREG_PROJ_TAN || to->proj != COREG_PROJ_TAN) return COREG_ENOTIMPL;
     homography(*from, *to, h9);
     return COREG_OK;
 }
@@ -1310,6 +1468,7 @@ int coreg_homography(const coreg_wcs2d* from, const coreg_wcs2d* to, double* h9)
 int coreg_lag_homography(const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_small, const coreg_lags* lags,
                          const int32_t idx[5], int cdelt_semantics, double* h9) {
     if (!hdr_target || !hdr_small || !lags || !idx || !h9) return COREG_EINVAL;
+    if (hdr_target->proj != COREG_PROJ_TAN || hdr_small->proj != COREG_PROJ_TAN) return COREG_ENOTIMPL;
     if (idx[0] < 0 || idx[0] >= lags->n_crval1 || idx[1] < 0 || idx[1] >= lags->n_crval2 || idx[2] < 0 ||
         idx[2] >= lags->n_cdelt1 || idx[3] < 0 || idx[3] >= lags->n_cdelt2 || idx[4] < 0 || idx[4] >= lags->n_crota)
         return COREG_EINVAL;

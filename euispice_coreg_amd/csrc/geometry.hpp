@@ -193,6 +193,114 @@ inline void apply_h(const double h[9], double x, double y, double* ox, double* o
     *oy = (h[3] * x + h[4] * y + h[5]) / w;
 }
 
+// ---- plate carree (CAR) inputs: align_using_initial_carrington, alignment.py:344-399 --------------------
+// wcslib celset (cel.c) for a cylindrical projection, fiducial native point (phi0, theta0) = (0, 0): celestial
+// longitude / latitude of the native pole and LONPOLE, in degrees.  A CRVAL2 lag makes the projection oblique; an
+// explicit LONPOLE on the wrong side of the equator leaves no valid pole (astropy raises InvalidTransformError, the
+// reference's worker dies): returns 1, the caller reports NaN for that lag-point.
+inline int car_euler(const coreg_wcs2d& w, ld* lngp_out, ld* latp_out, ld* phip_out) {
+    const ld d2r = (ld)kPi / 180.0L, r2d = 180.0L / (ld)kPi;
+    const ld lng0 = (ld)w.crval1 * (ld)w.unit_to_deg, lat0 = (ld)w.crval2 * (ld)w.unit_to_deg;
+    const ld phi0 = 0, theta0 = 0;
+    const ld phip = (w.lonpole == w.lonpole) ? (ld)w.lonpole : (lat0 >= theta0 ? 0.0L : 180.0L);
+    const ld latpreq = (w.latpole == w.latpole) ? (ld)w.latpole : 90.0L;
+    const ld tol = 1.0e-10L;
+    const ld slat0 = sinl(lat0 * d2r), clat0 = cosl(lat0 * d2r);
+    const ld cthe0 = 1.0L, sthe0 = 0.0L;
+    ld sphip = 0, cphip = 1;
+    if (phip != phi0) {
+        sphip = sinl((phip - phi0) * d2r);
+        cphip = cosl((phip - phi0) * d2r);
+    }
+    ld x = cthe0 * cphip, y = sthe0;
+    ld z = hypotl(x, y), latp;
+    if (z == 0) {
+        if (slat0 != 0) return 1;
+        latp = latpreq;
+    } else {
+        ld slz = slat0 / z;
+        if (fabsl(slz) > 1) {
+            if (fabsl(slz) - 1 < tol) slz = slz > 0 ? 1 : -1;
+            else return 1;
+        }
+        const ld u = atan2l(y, x) * r2d, v = acosl(slz) * r2d;
+        ld latp1 = u + v, latp2 = u - v;
+        if (latp1 > 180) latp1 -= 360; else if (latp1 < -180) latp1 += 360;
+        if (latp2 > 180) latp2 -= 360; else if (latp2 < -180) latp2 += 360;
+        if (fabsl(latpreq - latp1) < fabsl(latpreq - latp2)) latp = fabsl(latp1) < 90 + tol ? latp1 : latp2;
+        else latp = fabsl(latp2) < 90 + tol ? latp2 : latp1;
+        if (!(fabsl(latp) < 90 + tol)) return 1;  // "No valid solution for latp"
+        if (latp > 90) latp = 90; else if (latp < -90) latp = -90;
+    }
+    ld lngp;
+    z = cosl(latp * d2r) * clat0;
+    if (fabsl(z) < tol) {
+        if (fabsl(clat0) < tol) lngp = lng0;
+        else if (latp > 0) lngp = lng0 + phip - phi0 - 180;
+        else lngp = lng0 - phip + phi0;
+    } else {
+        const ld xx = (sthe0 - sinl(latp * d2r) * slat0) / z, yy = sphip * cthe0 / clat0;
+        if (xx == 0 && yy == 0) return 1;
+        lngp = lng0 - atan2l(yy, xx) * r2d;
+    }
+    *lngp_out = lngp;
+    *latp_out = latp;
+    *phip_out = phip;
+    return 0;
+}
+// native -> celestial rotation of a CAR header (same form as the zenithal one, with the pole from car_euler)
+inline int car_native_to_celestial(const coreg_wcs2d& w, Mat3* out) {
+    ld lngp, latp, phip;
+    if (car_euler(w, &lngp, &latp, &phip)) return 1;
+    const ld d2r = (ld)kPi / 180.0L;
+    const ld ap = lngp * d2r, dp = latp * d2r, pp = phip * d2r;
+    Mat3 rz1 = {{{cosl(ap), -sinl(ap), 0}, {sinl(ap), cosl(ap), 0}, {0, 0, 1}}};
+    Mat3 t = {{{-sinl(dp), 0, cosl(dp)}, {0, -1, 0}, {cosl(dp), 0, sinl(dp)}}};
+    Mat3 rz2 = {{{cosl(pp), sinl(pp), 0}, {-sinl(pp), cosl(pp), 0}, {0, 0, 1}}};
+    *out = mat_mul(rz1, mat_mul(t, rz2));
+    return 0;
+}
+// 0-based pixel -> native (phi, theta) [radians] of a CAR header: phi = x, theta = y (the intermediate world
+// coordinates themselves), affine: (phi, theta) = A (i, j) + b.  And its inverse.
+struct Affine2 {
+    double m00, m01, m10, m11, b0, b1;
+};
+inline Affine2 car_pix_to_native(const coreg_wcs2d& w) {
+    const Mat3 a = pix_to_iwc(w);
+    return {(double)a.m[0][0], (double)a.m[0][1], (double)a.m[1][0], (double)a.m[1][1], (double)a.m[0][2],
+            (double)a.m[1][2]};
+}
+inline Affine2 car_native_to_pix(const coreg_wcs2d& w) {
+    const Mat3 a = iwc_to_pix(w);
+    return {(double)a.m[0][0], (double)a.m[0][1], (double)a.m[1][0], (double)a.m[1][1], (double)a.m[0][2],
+            (double)a.m[1][2]};
+}
+// The whole CAR -> CAR map of one lag-point, host version (planning, tests): pixel of `from` -> pixel of `to`.
+//   n = unit vector of native (phi, theta) of `from`;  m = R n with R = R_to^T R_from;  (phi', theta') = (atan2, asin)
+struct CarMapHost {
+    Affine2 fwd, inv;
+    double r[9];
+    int init(const coreg_wcs2d& from, const coreg_wcs2d& to) {
+        Mat3 rf, rt;
+        if (car_native_to_celestial(from, &rf) || car_native_to_celestial(to, &rt)) return 1;
+        const Mat3 m = mat_mul(mat_T(rt), rf);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) r[3 * i + j] = (double)m.m[i][j];
+        fwd = car_pix_to_native(from);
+        inv = car_native_to_pix(to);
+        return 0;
+    }
+    void apply(double x, double y, double* ox, double* oy) const {
+        const double phi = fwd.m00 * x + fwd.m01 * y + fwd.b0, th = fwd.m10 * x + fwd.m11 * y + fwd.b1;
+        const double ct = std::cos(th), n0 = ct * std::cos(phi), n1 = ct * std::sin(phi), n2 = std::sin(th);
+        const double m0 = r[0] * n0 + r[1] * n1 + r[2] * n2, m1 = r[3] * n0 + r[4] * n1 + r[5] * n2,
+                     m2 = r[6] * n0 + r[7] * n1 + r[8] * n2;
+        const double p = std::atan2(m1, m0), t = std::asin(std::fmax(-1.0, std::fmin(1.0, m2)));
+        *ox = inv.m00 * p + inv.m01 * t + inv.b0;
+        *oy = inv.m10 * p + inv.m11 * t + inv.b1;
+    }
+};
+
 // ---- Carrington ---------------------------------------------------------------------------------------
 // Lag-independent-per-(roll, cdelt) part of utils/rectify.py:387-415 + :340-363.
 struct CarrCommon {

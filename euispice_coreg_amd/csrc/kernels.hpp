@@ -43,7 +43,13 @@ struct __attribute__((aligned(32))) Pt {
 
 // MODE_HOMOGRAPHY_SERIES: same map, denominator 1 + eps inverted as 1 - eps + eps^2 (host guarantees |eps| < 4e-6, i.e.
 // a truncation error below 1e-16 relative); MODE_HOMOGRAPHY divides exactly (any field of view)
-enum { MODE_TRANSLATE = 0, MODE_HOMOGRAPHY = 1, MODE_HOMOGRAPHY_SERIES = 2 };
+// MODE_CAR: plate-carree maps on both sides (align_using_initial_carrington): base coordinates = native (phi, theta) of
+// the target pixel [radians], per lag a rotation of the sphere (h[0..8]) between the two native frames, then
+// (atan2, asin) and the affine native -> pixel map of the shifted header (uniform per launch, Aff6)
+enum { MODE_TRANSLATE = 0, MODE_HOMOGRAPHY = 1, MODE_HOMOGRAPHY_SERIES = 2, MODE_CAR = 3 };
+struct Aff6 {
+    double m00, m01, m10, m11, b0, b1;
+};
 
 struct CarrDev {
     const double* sin_lon;  // [n_lon] sin(lon')
@@ -97,9 +103,25 @@ __device__ __forceinline__ void apply_h_series(const H9& m, double x, double y, 
     ox = fma(xn, q, xn);
     oy = fma(yn, q, yn);
 }
+// wcslib sphx2s / sphs2x + cars2x for one point: native angles of the target -> unit vector -> rotated -> native angles
+// of the shifted map -> its pixel
+__device__ __forceinline__ void apply_car(const H9& m, const Aff6& u, double phi, double theta, double& ox, double& oy) {
+    double sp, cp, st, ct;
+    sincos(phi, &sp, &cp);
+    sincos(theta, &st, &ct);
+    const double n0 = ct * cp, n1 = ct * sp, n2 = st;
+    const double q0 = fma(m.h[0], n0, fma(m.h[1], n1, m.h[2] * n2));
+    const double q1 = fma(m.h[3], n0, fma(m.h[4], n1, m.h[5] * n2));
+    const double q2 = fma(m.h[6], n0, fma(m.h[7], n1, m.h[8] * n2));
+    const double p = atan2(q1, q0);
+    const double t = atan2(q2, sqrt(fma(q0, q0, q1 * q1)));
+    ox = fma(u.m00, p, fma(u.m01, t, u.b0));
+    oy = fma(u.m10, p, fma(u.m11, t, u.b1));
+}
 template <int MODE>
-__device__ __forceinline__ void apply_map(const H9& m, double x, double y, double& ox, double& oy) {
-    if (MODE == MODE_HOMOGRAPHY_SERIES) apply_h_series(m, x, y, ox, oy);
+__device__ __forceinline__ void apply_map(const H9& m, const Aff6& u, double x, double y, double& ox, double& oy) {
+    if (MODE == MODE_CAR) apply_car(m, u, x, y, ox, oy);
+    else if (MODE == MODE_HOMOGRAPHY_SERIES) apply_h_series(m, x, y, ox, oy);
     else apply_h(m, x, y, ox, oy);
 }
 
@@ -318,6 +340,7 @@ struct PrecomputeArgs {
     int tile_w, tile_h;  // tile_w * tile_h == kTilePts
     int tiles_x, tiles_y;
     CarrDev carr;             // MODE_TRANSLATE
+    Aff6 car_fwd;             // MODE_CAR: 0-based target pixel -> its native (phi, theta) [rad]
     double f0lo, f0hi, f1lo, f1hi;  // cull box on the base coordinates (inclusive)
     int residus;              // 1: method 'residus' -> pts hold the raw reference value and 1/sqrt(value)
     const double* pivot_a;    // device scalar: mean of the finite reference values
@@ -380,6 +403,9 @@ __global__ void __launch_bounds__(256) k_precompute(const PrecomputeArgs a) {
             av = (double)((const TA*)a.ref)[(size_t)gj * a.gw + gi];
             if (MODE == MODE_TRANSLATE) {
                 valid = carr_term(a.carr, gi, gj, b0, b1);
+            } else if (MODE == MODE_CAR) {
+                b0 = fma(a.car_fwd.m00, (double)gi, fma(a.car_fwd.m01, (double)gj, a.car_fwd.b0));
+                b1 = fma(a.car_fwd.m10, (double)gi, fma(a.car_fwd.m11, (double)gj, a.car_fwd.b1));
             } else {
                 b0 = (double)gi;
                 b1 = (double)gj;
@@ -535,6 +561,7 @@ struct SweepArgs {
     const double* pivots;  // device: [0] mean(reference) (already subtracted in aval), [1] mean(small image)
     int use_lds;
     int lds_elems;     // capacity of the dynamic LDS window in float64 elements
+    Aff6 car_inv;      // MODE_CAR: native (phi, theta) [rad] -> 0-based pixel of the shifted map of this launch
 };
 
 struct Acc {
@@ -618,7 +645,7 @@ struct Taps<2> {
 template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false>
 __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                           int ox, int oy, int W, int H, double wmax, double hmax, double px0, double py0,
-                                          double pxw, double pyw, const H9& hm, double b0, double b1, double av,
+                                          double pxw, double pyw, const H9& hm, const Aff6& cu, double b0, double b1, double av,
                                           double isa, double pivot_b) {
     constexpr int N = Spline<ORDER>::N;
     if (INTERIOR && LDS) {
@@ -632,7 +659,7 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
             uy = pyw + b1;
         } else {
             double mx, my;
-            apply_map<MODE>(hm, b0, b1, mx, my);
+            apply_map<MODE>(hm, cu, b0, b1, mx, my);
             ux = mx + pxw;
             uy = my + pyw;
         }
@@ -700,7 +727,7 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
         nx = px0 + b0;  // self.x + term, utils/rectify.py:362
         ny = py0 + b1;
     } else {
-        apply_map<MODE>(hm, b0, b1, nx, ny);
+        apply_map<MODE>(hm, cu, b0, b1, nx, ny);
     }
     if (INTERIOR || ((nx >= 0.0) & (nx <= wmax) & (ny >= 0.0) & (ny <= hmax))) {
         int sx, sy;
@@ -776,7 +803,7 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
 template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false>
 __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                             int ox, int oy, int W, int H, double px0, double py0, double pxw,
-                                            double pyw, const H9& hm, const Pt* __restrict__ pts, int p_begin, int p_end,
+                                            double pyw, const H9& hm, const Aff6& cu, const Pt* __restrict__ pts, int p_begin, int p_end,
                                             double pivot_b, int pg) {
     // points [p_begin, p_end) of the tile: p_begin is a multiple of kChunk * kPointGroups, p_end is one too or the
     // tile's point count
@@ -790,7 +817,7 @@ __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __
 #pragma unroll
         for (int k = 0; k < kChunk; ++k)
             point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0,
-                                                                    py0, pxw, pyw, hm, pt[k].b0, pt[k].b1, pt[k].a,
+                                                                    py0, pxw, pyw, hm, cu, pt[k].b0, pt[k].b1, pt[k].a,
                                                                     pt[k].pad, pivot_b);
     }
     // ragged tail (< kChunk points): owned by the point-group next in the rotation
@@ -798,7 +825,7 @@ __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __
         for (int p = n_full * kChunk; p < p_end; ++p) {
             const Pt pt = pts[p];
             point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0,
-                                                                    py0, pxw, pyw, hm, pt.b0, pt.b1, pt.a, pt.pad,
+                                                                    py0, pxw, pyw, hm, cu, pt.b0, pt.b1, pt.a, pt.pad,
                                                                     pivot_b);
         }
     }
@@ -875,7 +902,7 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 double cx, cy;
-                apply_map<MODE>(hm, (c & 1) ? bx1 : bx0, (c & 2) ? by1 : by0, cx, cy);
+                apply_map<MODE>(hm, a.car_inv, (c & 1) ? bx1 : bx0, (c & 2) ? by1 : by0, cx, cy);
                 mnx = fmin(mnx, cx);
                 mxx = fmax(mxx, cx);
                 mny = fmin(mny, cy);
@@ -957,15 +984,15 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
                     const double pxw = MODE == MODE_TRANSLATE ? px0 + offx : offx;
                     const double pyw = MODE == MODE_TRANSLATE ? py0 + offy : offy;
                     tile_points<MODE, ORDER, TS, true, ROUND, RESID, true>(acc, win, img, pitch, ox, oy, W, H, px0, py0,
-                                                                           pxw, pyw, hm, pts, p_begin, p_end, pivot_b,
+                                                                           pxw, pyw, hm, a.car_inv, pts, p_begin, p_end, pivot_b,
                                                                            pg);
                 }
             } else {
                 tile_points<MODE, ORDER, TS, true, ROUND, RESID>(acc, win, img, pitch, ox, oy, W, H, px0, py0, 0.0, 0.0, hm,
-                                                                 pts, p_begin, p_end, pivot_b, pg);
+                                                                 a.car_inv, pts, p_begin, p_end, pivot_b, pg);
             }
         } else {
-            tile_points<MODE, ORDER, TS, false, ROUND, RESID>(acc, win, img, 0, 0, 0, W, H, px0, py0, 0.0, 0.0, hm, pts,
+            tile_points<MODE, ORDER, TS, false, ROUND, RESID>(acc, win, img, 0, 0, 0, W, H, px0, py0, 0.0, 0.0, hm, a.car_inv, pts,
                                                               p_begin, p_end, pivot_b, pg);
         }
     }

@@ -186,8 +186,26 @@ class Alignment:
         return self._wrap(results, return_type, restore_units=True)
 
     def align_using_initial_carrington(self, method="correlation", return_type="AlignmentResults"):
-        raise NotImplementedError("align_using_initial_carrington (CRLN-CAR / CRLT-CAR input maps, "
-                                  "alignment.py:344-399) is outside the accelerated path")
+        """alignment.py:344-399: both inputs are already Carrington maps (CRLN-CAR / CRLT-CAR, plate carree).  The image
+        to align is resampled, per lag, on the reference map's own pixel grid (no sub-map, no Carrington transform);
+        both images are read as float32, lags are not wrapped (ang2pipi=False)."""
+        self.lonlims = self.latlims = self.shape = self.reference_date = None
+        self.method = method
+        self.coordinate_frame = "initial_carrington"
+        self._load()
+        for hdr, what in ((self.hdr_small, "image to align"), (self.hdr_large, "reference image")):
+            if not str(hdr.get("CTYPE1", "")).strip().upper().endswith("-CAR"):
+                raise ValueError(f"align_using_initial_carrington: the {what} is not a CRLN-CAR / CRLT-CAR map")
+        self.data_small = np.array(self.data_small, dtype=np.float32)  # alignment.py:384
+        results = self._find_best_header_parameters(ang2pipi=False)
+        if return_type == "corr":
+            return results
+        return AlignmentResults(corr=results, lag_crval1=self.lag_crval1, lag_crval2=self.lag_crval2,
+                                lag_cdelt1=self.lag_cdelt1, lag_cdelt2=self.lag_cdelt2, lag_crota=self.lag_crota,
+                                unit_lag=self.unit_lag, image_to_align_path=self.small_fov_to_correct,
+                                image_to_align_window=self.small_fov_window,
+                                reference_image_path=self.large_fov_known_pointing,
+                                reference_image_window=self.large_fov_window)
 
     def _wrap(self, results, return_type, restore_units):
         if return_type == "corr":
@@ -301,6 +319,12 @@ class Alignment:
                     h.reference_tag = tag
                 part = h.sweep_carrington(self.hdr_small, grid, solar_r, lags, order=self.order, method=method,
                                           cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
+            elif self.coordinate_frame == "initial_carrington":
+                # the reference map on its own grid, float32 (alignment.py:372); neither the parallel nor the serial
+                # branch of the reference builds a sub-map for this frame (:649, :765)
+                h.set_reference_on_grid(np.asarray(self._large_pixels(), dtype=np.float32))
+                part = h.sweep_helioprojective(self.hdr_large, self.hdr_small, lags, order=self.order, method=method,
+                                               cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
             else:
                 if self.parallelism:
                     h.prepare_reference_helioprojective(self._large_pixels(), self.hdr_large, self.hdr_small,

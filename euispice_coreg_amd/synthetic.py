@@ -185,3 +185,59 @@ def make_imager_sequence(large, hdr_large, start="2022-03-17T09:40:00.000", cade
         h["DETECTOR"] = "FSI"
         frames.append(((large * (1.0 + 0.05 * k)).astype(np.float32), h))
     return frames
+
+
+def make_car_scene(small_shape=(90, 120), large_shape=(150, 200), seed=31, n_blobs=160, pointing_error=(0.018, -0.011),
+                   small_cdelt=(0.0101, 0.0099), large_cdelt=(0.01637, 0.01613), crota=0.0, explicit_lonpole=False,
+                   nan_frac=0.004):
+    """Two Carrington maps (CRLN-CAR / CRLT-CAR, plate carree, degrees) of one blob field on the sphere: the map to
+    align is rendered through its TRUE header and handed out with CRVAL off by `pointing_error` (degrees), the reference
+    map is coarser and wider.  float32 pixels.  Returns (small, hdr_small, large, hdr_large, truth)."""
+    rng = np.random.default_rng(seed)
+
+    def header(shape, crval, cdelt, rot):
+        ny, nx = shape
+        rho, lam = np.deg2rad(rot), cdelt[1] / cdelt[0]
+        h = {"NAXIS": 2, "NAXIS1": int(nx), "NAXIS2": int(ny), "CTYPE1": "CRLN-CAR", "CTYPE2": "CRLT-CAR",
+             "CUNIT1": "deg", "CUNIT2": "deg", "CRPIX1": (nx + 1) / 2.0, "CRPIX2": (ny + 1) / 2.0,
+             "CRVAL1": float(crval[0]), "CRVAL2": float(crval[1]), "CDELT1": float(cdelt[0]), "CDELT2": float(cdelt[1]),
+             "PC1_1": float(np.cos(rho)), "PC1_2": float(-lam * np.sin(rho)), "PC2_1": float(np.sin(rho) / lam),
+             "PC2_2": float(np.cos(rho)), "CROTA": float(rot), "DATE-AVG": "2022-03-17T09:50:45.277", "WAVELNTH": 174}
+        if explicit_lonpole:
+            h["LONPOLE"] = 0.0
+            h["LATPOLE"] = 90.0
+        return h
+
+    centre = (250.0, 0.0)
+    half = 0.5 * max(large_shape[1] * large_cdelt[0], large_shape[0] * large_cdelt[1])
+    blobs = np.empty((n_blobs, 4))
+    blobs[:, 0] = centre[0] + rng.uniform(-half, half, n_blobs)
+    blobs[:, 1] = centre[1] + rng.uniform(-half, half, n_blobs)
+    blobs[:, 2] = rng.uniform(0.02, 0.25, n_blobs)  # sigma, degrees
+    blobs[:, 3] = np.exp(rng.uniform(np.log(50.0), np.log(3000.0), n_blobs))
+
+    def render(h):
+        # pixel -> (lon, lat): with |CRVAL2| << 1 deg the oblique terms are far below a pixel; the affine form is used
+        # for rendering only (the alignment itself uses the exact projection)
+        y, x = np.mgrid[0:h["NAXIS2"], 0:h["NAXIS1"]].astype(np.float64)
+        q1, q2 = x + 1.0 - h["CRPIX1"], y + 1.0 - h["CRPIX2"]
+        lon = h["CRVAL1"] + h["CDELT1"] * (h["PC1_1"] * q1 + h["PC1_2"] * q2)
+        lat = h["CRVAL2"] + h["CDELT2"] * (h["PC2_1"] * q1 + h["PC2_2"] * q2)
+        img = np.full(lon.shape, 100.0)
+        for k in range(n_blobs):
+            d2 = (lon - blobs[k, 0]) ** 2 + (lat - blobs[k, 1]) ** 2
+            m = d2 < (4.5 * blobs[k, 2]) ** 2
+            img[m] += blobs[k, 3] * np.exp(-d2[m] / (2.0 * blobs[k, 2] ** 2))
+        img = img + np.sqrt(img) * rng.standard_normal(img.shape)
+        return img.astype(np.float32)
+
+    true_crval = (centre[0] + 0.0713, centre[1] + 0.00037)
+    h_true = header(small_shape, true_crval, small_cdelt, crota)
+    h_small = header(small_shape, (true_crval[0] - pointing_error[0], true_crval[1] - pointing_error[1]), small_cdelt,
+                     crota)
+    h_large = header(large_shape, centre, large_cdelt, 0.0)
+    small, large = render(h_true), render(h_large)
+    if nan_frac > 0:
+        small[rng.random(small.shape) < nan_frac] = np.nan
+    truth = {"lag_crval1": pointing_error[0], "lag_crval2": pointing_error[1]}
+    return small, h_small, large, h_large, truth

@@ -31,6 +31,9 @@ extern "C" {
 #define COREG_F32 0
 #define COREG_F64 1
 
+#define COREG_PROJ_TAN 0
+#define COREG_PROJ_CAR 1
+
 #define COREG_METHOD_CORRELATION 0 /* alignment.py:522-542 */
 #define COREG_METHOD_RESIDUS 1     /* alignment.py:544-547 (no NaN mask, quirk Q8) */
 
@@ -56,6 +59,11 @@ typedef struct coreg_wcs2d {
     double dsun_obs;    /* metres          (Carrington only, utils/rectify.py:405)                           */
     double crln_obs;    /* degrees         (Carrington only, utils/rectify.py:406)                           */
     double crlt_obs;    /* degrees         (Carrington only, utils/rectify.py:407)                           */
+    double latpole;     /* degrees; NaN = FITS default (90).  Only the CAR projection reads it                   */
+    int32_t proj;       /* COREG_PROJ_TAN (HPLN-TAN / HPLT-TAN) or COREG_PROJ_CAR (CRLN-CAR / CRLT-CAR inputs of
+                           align_using_initial_carrington, alignment.py:344-399).  For CAR a NaN lonpole means the
+                           FITS default: 0 deg when CRVAL2 >= 0, else 180 deg                                    */
+    int32_t reserved;
 } coreg_wcs2d;
 
 /* The five lag axes of Alignment.__init__ (alignment.py:47-55), already in header units
@@ -193,6 +201,13 @@ int coreg_homography(const coreg_wcs2d* from, const coreg_wcs2d* to, double* h9)
 int coreg_lag_homography(const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_small, const coreg_lags* lags,
                          const int32_t idx[5], int cdelt_semantics, double* h9);
 int coreg_carrington_origin(const coreg_wcs2d* hdr, double* x0, double* y0);
+/* CAR -> CAR map of one lag-point on the host: 0-based pixels of `from` -> 0-based pixels of `to` through the common
+ * sphere, WCS(to).world_to_pixel(WCS(from).pixel_to_world(p)) for CRLN-CAR / CRLT-CAR headers (alignment.py:1038-1069
+ * on the align_using_initial_carrington path).  Returns 1 when either header has no valid native pole (astropy raises
+ * InvalidTransformError). */
+int coreg_car_map(const coreg_wcs2d* from, const coreg_wcs2d* to, int64_t n, const double* px, const double* py,
+                  double* ox, double* oy);
+
 
 #ifdef __cplusplus
 }

@@ -240,19 +240,183 @@ class TanWCS:
         return px, py
 
 
-def extract_EUI_coordinates(hdr):
-    """Longitude/latitude (degrees, ]-180,180]) of every pixel of `hdr`.  Util.py:282-312
-    (non-sunpy branch: list of Quantities, ang2pipi applied)."""
-    w = TanWCS(hdr)
+class InvalidTransformError(ValueError):
+    """wcslib celset: 'No valid solution for latp' (astropy.wcs raises InvalidTransformError)."""
+
+
+class CarWCS:
+    """2-D plate-carree (CAR) WCS the way `astropy.wcs.WCS(hdr)` / wcslib evaluates it (FITS WCS paper II, wcslib
+    cel.c celset + sph.c): native (phi, theta) = intermediate (x, y) in degrees, fiducial point (phi0, theta0) = (0, 0)
+    at (CRVAL1, CRVAL2); LONPOLE defaults to 0 deg when CRVAL2 >= 0, else 180 deg; LATPOLE to 90 deg.  With
+    CRVAL2 != 0 the projection is oblique: the native pole sits at celestial latitude 90 - |CRVAL2|."""
+
+    def __init__(self, hdr):
+        u1 = unit_to_deg(hdr.get("CUNIT1", "deg"))
+        u2 = unit_to_deg(hdr.get("CUNIT2", "deg"))
+        self.crpix = (float(hdr["CRPIX1"]), float(hdr["CRPIX2"]))
+        self.cdelt = (float(hdr["CDELT1"]) * u1, float(hdr["CDELT2"]) * u2)
+        self.crval = (float(hdr["CRVAL1"]) * u1, float(hdr["CRVAL2"]) * u2)
+        self.pc = np.array([[float(hdr.get("PC1_1", 1.0)), float(hdr.get("PC1_2", 0.0))],
+                            [float(hdr.get("PC2_1", 0.0)), float(hdr.get("PC2_2", 1.0))]])
+        self.naxis = (int(hdr["NAXIS1"]) if "NAXIS1" in hdr else None,
+                      int(hdr["NAXIS2"]) if "NAXIS2" in hdr else None)
+        if "ZNAXIS1" in hdr:
+            self.naxis = (int(hdr["ZNAXIS1"]), int(hdr["ZNAXIS2"]))
+        lng0, lat0 = self.crval
+        phi0, theta0 = 0.0, 0.0
+        phip = float(hdr["LONPOLE"]) if "LONPOLE" in hdr else (0.0 if lat0 >= theta0 else 180.0)
+        latpreq = float(hdr.get("LATPOLE", 90.0))
+        # celset (cel.c:230-440), non-zenithal branch
+        tol = 1.0e-10
+        slat0, clat0 = math.sin(math.radians(lat0)), math.cos(math.radians(lat0))
+        cthe0, sthe0 = math.cos(math.radians(theta0)), math.sin(math.radians(theta0))
+        if phip == phi0:
+            sphip, cphip = 0.0, 1.0
+        else:
+            sphip, cphip = math.sin(math.radians(phip - phi0)), math.cos(math.radians(phip - phi0))
+        x, y = cthe0 * cphip, sthe0
+        z = math.hypot(x, y)
+        if z == 0.0:
+            if slat0 != 0.0:
+                raise InvalidTransformError("celset: invalid coordinate transformation parameters")
+            latp = latpreq
+        else:
+            slz = slat0 / z
+            if abs(slz) > 1.0:
+                if abs(slz) - 1.0 < tol:
+                    slz = math.copysign(1.0, slz)
+                else:
+                    raise InvalidTransformError("celset: invalid coordinate transformation parameters")
+            uu = math.degrees(math.atan2(y, x))
+            vv = math.degrees(math.acos(slz))
+            latp1 = uu + vv
+            if latp1 > 180.0:
+                latp1 -= 360.0
+            elif latp1 < -180.0:
+                latp1 += 360.0
+            latp2 = uu - vv
+            if latp2 > 180.0:
+                latp2 -= 360.0
+            elif latp2 < -180.0:
+                latp2 += 360.0
+            if abs(latpreq - latp1) < abs(latpreq - latp2):
+                latp = latp1 if abs(latp1) < 90.0 + tol else latp2
+            else:
+                latp = latp2 if abs(latp2) < 90.0 + tol else latp1
+            if abs(latp) < 90.0 + tol:
+                if latp > 90.0:
+                    latp = 90.0
+                elif latp < -90.0:
+                    latp = -90.0
+            else:
+                raise InvalidTransformError("No valid solution for latp for these values of phip, phi0, and theta0")
+        z = math.cos(math.radians(latp)) * clat0
+        if abs(z) < tol:
+            if abs(clat0) < tol:
+                lngp = lng0
+            elif latp > 0.0:
+                lngp = lng0 + phip - phi0 - 180.0
+            else:
+                lngp = lng0 - phip + phi0
+        else:
+            xx = (sthe0 - math.sin(math.radians(latp)) * slat0) / z
+            yy = sphip * cthe0 / clat0
+            if xx == 0.0 and yy == 0.0:
+                raise InvalidTransformError("celset: invalid coordinate transformation parameters")
+            lngp = lng0 - math.degrees(math.atan2(yy, xx))
+        if lng0 >= 0.0:
+            if lngp < 0.0:
+                lngp += 360.0
+            elif lngp > 360.0:
+                lngp -= 360.0
+        else:
+            if lngp > 0.0:
+                lngp -= 360.0
+            elif lngp < -360.0:
+                lngp += 360.0
+        self.euler = (lngp, 90.0 - latp, phip)  # celestial longitude of the native pole, its co-latitude, LONPOLE
+        self.latp = latp
+
+    def _matrix(self):
+        return np.array([[self.cdelt[0] * self.pc[0, 0], self.cdelt[0] * self.pc[0, 1]],
+                         [self.cdelt[1] * self.pc[1, 0], self.cdelt[1] * self.pc[1, 1]]])
+
+    def pixel_to_world(self, px, py):
+        """0-based pixel -> (lon, lat) degrees; longitude normalised as wcslib's sphx2s does (sign of the pole's
+        celestial longitude decides [0, 360) or (-360, 0])."""
+        px = np.asarray(px, dtype=np.float64)
+        py = np.asarray(py, dtype=np.float64)
+        q1 = px + 1.0 - self.crpix[0]
+        q2 = py + 1.0 - self.crpix[1]
+        m = self._matrix()
+        phi = m[0, 0] * q1 + m[0, 1] * q2       # carx2s: phi = x, theta = y (degrees)
+        theta = m[1, 0] * q1 + m[1, 1] * q2
+        lngp, colat, phip = self.euler
+        dphi = np.radians(phi - phip)
+        th = np.radians(theta)
+        cl, sl = math.cos(math.radians(colat)), math.sin(math.radians(colat))  # = sin(latp), cos(latp)
+        sth, cth = np.sin(th), np.cos(th)
+        x = sth * sl - cth * cl * np.cos(dphi)
+        y = -cth * np.sin(dphi)
+        z = sth * cl + cth * sl * np.cos(dphi)
+        lng = lngp + np.degrees(np.arctan2(y, x))
+        lat_a = np.degrees(np.arcsin(np.clip(z, -1.0, 1.0)))
+        lat_b = np.copysign(np.degrees(np.arccos(np.clip(np.hypot(x, y), 0.0, 1.0))), z)
+        lat = np.where(np.abs(z) > 0.99, lat_b, lat_a)
+        if lngp >= 0.0:
+            lng = np.where(lng < 0.0, lng + 360.0, lng)
+        else:
+            lng = np.where(lng > 0.0, lng - 360.0, lng)
+        lng = np.where(lng > 360.0, lng - 360.0, lng)
+        lng = np.where(lng < -360.0, lng + 360.0, lng)
+        return lng, lat
+
+    def world_to_pixel(self, lon, lat):
+        """(lon, lat) degrees -> 0-based pixel (x, y)."""
+        lon = np.asarray(lon, dtype=np.float64)
+        lat = np.asarray(lat, dtype=np.float64)
+        lngp, colat, phip = self.euler
+        dl = np.radians(lon - lngp)
+        la = np.radians(lat)
+        cl, sl = math.cos(math.radians(colat)), math.sin(math.radians(colat))
+        sla, cla = np.sin(la), np.cos(la)
+        x = sla * sl - cla * cl * np.cos(dl)
+        y = -cla * np.sin(dl)
+        z = sla * cl + cla * sl * np.cos(dl)
+        dphi = np.degrees(np.arctan2(y, x))
+        phi = phip + dphi
+        phi = np.where(phi > 180.0, phi - 360.0, phi)
+        phi = np.where(phi < -180.0, phi + 360.0, phi)
+        th_a = np.degrees(np.arcsin(np.clip(z, -1.0, 1.0)))
+        th_b = np.copysign(np.degrees(np.arccos(np.clip(np.hypot(x, y), 0.0, 1.0))), z)
+        theta = np.where(np.abs(z) > 0.99, th_b, th_a)
+        mi = np.linalg.inv(self._matrix())
+        q1 = mi[0, 0] * phi + mi[0, 1] * theta   # cars2x: x = phi, y = theta
+        q2 = mi[1, 0] * phi + mi[1, 1] * theta
+        return q1 + self.crpix[0] - 1.0, q2 + self.crpix[1] - 1.0
+
+
+def make_wcs(hdr):
+    """TAN or CAR by CTYPE1 (the two projections the alignment paths meet)."""
+    ct = str(hdr.get("CTYPE1", "HPLN-TAN")).strip().upper()
+    return CarWCS(hdr) if ct.endswith("-CAR") else TanWCS(hdr)
+
+
+def extract_EUI_coordinates(hdr, wrap=True):
+    """Longitude/latitude (degrees) of every pixel of `hdr`.  Util.py:282-312 (non-sunpy branch: list of Quantities;
+    ang2pipi applied for HPLN-TAN, raw wcslib output for CRLN-CAR)."""
+    w = make_wcs(hdr)
     x, y = np.meshgrid(np.arange(w.naxis[0]), np.arange(w.naxis[1]))
     lon, lat = w.pixel_to_world(x, y)
-    return ang2pipi(lon), ang2pipi(lat)
+    if wrap and not isinstance(w, CarWCS):
+        return ang2pipi(lon), ang2pipi(lat)
+    return lon, lat
 
 
 def extract_coordinates_pixels(header_initial_to_project, header_target_projection):
     """Pixel coordinates, in `header_target_projection`, of every pixel of
     `header_initial_to_project`.  alignment.py:1038-1069 (non-sunpy branch)."""
-    w_to = TanWCS(header_target_projection)
+    w_to = make_wcs(header_target_projection)
     lon, lat = extract_EUI_coordinates(header_initial_to_project)
     return w_to.world_to_pixel(lon, lat)
 
@@ -566,7 +730,12 @@ def step(st: SweepState, frame, data_small, data_large, d_crval1, d_crval2, d_cd
     if frame == "carrington":
         interp = carrington_transform_fa(data_small, hdr, d_solar_r, st.shape, st.lonlims, st.latlims, st.order)
     else:
-        interp = interpolate_on_large_data_grid(st, data_small, hdr)
+        try:
+            interp = interpolate_on_large_data_grid(st, data_small, hdr)
+        except InvalidTransformError:
+            # CAR inputs: a CRVAL2 lag can leave no valid native pole for an explicit LONPOLE; astropy raises, the
+            # reference's worker dies and the slot keeps its initial value -- reported as NaN here (quirk Q9)
+            return np.nan
     if method == "correlation":
         return masked_pearson(data_large, interp)
     elif method == "residus":

@@ -49,3 +49,18 @@ def gpu_handle():
     h = _lib.CoregHandle(0)
     yield h
     h.close()
+
+
+@pytest.fixture(scope="session")
+def car_golden():
+    return np.load(os.path.join(GOLDEN, "car_golden.npz"))
+
+
+def car_header(g, name):
+    """CAR header dict of a case of car_golden.npz."""
+    h = dict(zip([str(k) for k in g[name + "/keys"]], [float(v) for v in g[name + "/vals"]]))
+    for k in ("NAXIS1", "NAXIS2"):
+        if k in h:
+            h[k] = int(h[k])
+    h.update(CTYPE1="CRLN-CAR", CTYPE2="CRLT-CAR", CUNIT1="deg", CUNIT2="deg")
+    return h

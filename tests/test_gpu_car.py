@@ -1,0 +1,93 @@
+"""GPU tests of the plate-carree path (Alignment.align_using_initial_carrington, reference alignment.py:344-399): inputs
+that are already Carrington maps, per-lag sphere rotation between the two maps (oblique CAR for CRVAL2 lags)."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _sweep(h, small, hs, large, hl, lags, order=2, method=0, **kw):
+    from euispice_coreg_amd import _lib
+    h.set_small(small)
+    h.set_reference_on_grid(np.asarray(large, dtype=np.float32))
+    ls = _lib.LagSet(*lags)
+    return h.sweep_helioprojective(hl, hs, ls, order=order, method=method, **kw).reshape(ls.shape + (1,))
+
+
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("use_lds", [1, 0])
+def test_sweep_car_vs_oracle(gpu_handle, order, use_lds):
+    from euispice_coreg_amd import synthetic
+    small, hs, large, hl, truth = synthetic.make_car_scene()
+    lags = (np.arange(-0.01, 0.045, 0.006), np.arange(-0.035, 0.02, 0.006), None, None, [0.0, 0.4])
+    gpu_handle.set_option("use_lds", use_lds)
+    try:
+        got = _sweep(gpu_handle, small, hs, large, hl, lags, order=order)
+    finally:
+        gpu_handle.set_option("use_lds", 1)
+    want = H.oracle_helio(small.astype(np.float64), hs, large.astype(np.float64), hl, lags, order=order,
+                          parallelism=False, unit_lag="deg")
+    H.assert_corr_close(got, want, 1e-7, f"CAR sweep order={order} lds={use_lds}")
+    am = np.unravel_index(np.nanargmax(got), got.shape)
+    assert abs(lags[0][am[0]] - truth["lag_crval1"]) <= 0.006 and abs(lags[1][am[1]] - truth["lag_crval2"]) <= 0.006
+
+
+def test_sweep_car_cdelt_crota_slices_and_residus(gpu_handle):
+    from euispice_coreg_amd import synthetic
+    small, hs, large, hl, _ = synthetic.make_car_scene(small_shape=(70, 96), large_shape=(110, 150), crota=0.3, seed=5,
+                                                       small_cdelt=(0.0111, 0.0093), nan_frac=0.0)
+    lags = (np.array([0.0, 0.012, 0.02]), np.array([-0.015, -0.004]), [0.0, 0.0002], [0.0, -0.0001], [-0.2, 0.0])
+    got = _sweep(gpu_handle, small, hs, large, hl, lags)
+    want = H.oracle_helio(small.astype(np.float64), hs, large.astype(np.float64), hl, lags, parallelism=False,
+                          unit_lag="deg")
+    H.assert_corr_close(got, want, 1e-7, "CAR 5-D sweep")
+    # contiguous slices of the raveled lag range concatenate to the full map
+    from euispice_coreg_amd import _lib
+    ls = _lib.LagSet(*lags)
+    parts = [gpu_handle.sweep_helioprojective(hl, hs, ls, lag_begin=a, lag_end=b) for a, b in ((0, 17), (17, 18), (18, 48))]
+    assert np.allclose(np.concatenate(parts), got.ravel(), rtol=0, atol=1e-12, equal_nan=True)
+
+
+def test_car_invalid_pole_lags_are_nan(gpu_handle):
+    """A header with an explicit LONPOLE = 0 (what astropy's to_header writes for an equatorial CAR map) has no valid
+    native pole once a lag makes CRVAL2 negative: astropy raises, the reference's worker dies; here those lag-points are
+    NaN and the others are unaffected."""
+    from euispice_coreg_amd import synthetic
+    small, hs, large, hl, _ = synthetic.make_car_scene(explicit_lonpole=True, pointing_error=(0.018, 0.011), seed=8)
+    lags = (np.array([0.0, 0.018]), np.array([-0.02, -0.0050, 0.011, 0.02]), None, None, None)
+    got = _sweep(gpu_handle, small, hs, large, hl, lags)
+    want = H.oracle_helio(small.astype(np.float64), hs, large.astype(np.float64), hl, lags, parallelism=False,
+                          unit_lag="deg")
+    # CRVAL2 of the handed-out header is 0.00037 - 0.011: lags below +0.01063 leave it negative
+    assert np.isnan(want[:, :2]).all() and np.isfinite(want[:, 2:]).all()
+    H.assert_corr_close(got, want, 1e-7, "CAR invalid-pole lags")
+
+
+def test_align_using_initial_carrington_dropin(tmp_path):
+    from euispice_coreg_amd import synthetic
+    from euispice_coreg_amd.hdrshift import Alignment, AlignmentResults
+    from euispice_coreg_amd.utils import fits_io
+    small, hs, large, hl, truth = synthetic.make_car_scene()
+    ps, pl = str(tmp_path / "small_car.fits"), str(tmp_path / "large_car.fits")
+    fits_io.write_images(ps, [(None, {}), (small, hs)])
+    fits_io.write_images(pl, [(None, {}), (large, hl)])
+    lag1, lag2 = np.arange(-20.0, 140.0, 20.0), np.arange(-120.0, 40.0, 20.0)  # arcsec; the maps are in degrees
+    A = Alignment(pl, ps, lag_crval1=lag1, lag_crval2=lag2, lag_cdelt1=None, lag_cdelt2=None, lag_crota=None,
+                  parallelism=True, small_fov_value_max=2900.0)
+    with pytest.warns(UserWarning):
+        res = A.align_using_initial_carrington()
+    assert isinstance(res, AlignmentResults) and res.corr.shape == (8, 8, 1, 1, 1, 1) and res.unit_lag == "deg"
+    sm = small.astype(np.float64)
+    from oracle import coreg_oracle as O
+    O.set_threshold_minmax_to_nan(sm, None, 2900.0)
+    want = H.oracle_helio(sm, hs, large.astype(np.float64), hl, (lag1 / 3600.0, lag2 / 3600.0, None, None, None),
+                          parallelism=False, unit_lag="deg")
+    H.assert_corr_close(res.corr, want, 1e-7, "Alignment.align_using_initial_carrington")
+    assert abs(res.shift_arcsec[0] - truth["lag_crval1"] * 3600) < 20 and abs(res.shift_arcsec[1] - truth["lag_crval2"] * 3600) < 20
+    # TAN inputs are refused
+    from tests import helpers
+    s2, h2, l2, hl2, _ = helpers.scene(small_n=32, large_n=48)
+    with pytest.raises(ValueError):
+        Alignment((l2, hl2), (s2, h2), [0.0], [0.0], None, None, None).align_using_initial_carrington()

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_struct_layouts_match_header(lib):
     import ctypes as C
-    assert C.sizeof(lib.Wcs2d) == 8 + 16 * 8
+    assert C.sizeof(lib.Wcs2d) == 8 + 17 * 8 + 8  # 2 x int32, 17 doubles, proj + reserved
     assert C.sizeof(lib.Lags) == 5 * 16
     assert C.sizeof(lib.CarrGrid) == 6 * 8 + 2 * 8
     assert C.sizeof(lib.Stats) == 3 * 8 + 4 * 8 + 2 * 4
@@ -144,3 +144,25 @@ def test_carrington_origin_matches_oracle(lib):
     p = O.carrington_params(hdr, 1.004)
     x0, y0 = lib.carrington_origin(hdr)
     assert x0 == pytest.approx(p["x0"], abs=1e-11) and y0 == pytest.approx(p["y0"], abs=1e-11)
+
+
+@pytest.mark.parametrize("tag", ["lag_ns", "lag_nn", "lag_roll", "lag_cdelt"])
+def test_car_map_host_matches_wcslib(car_golden, tag):
+    """geometry.hpp: celset for plate-carree headers + the sphere rotation between two CAR maps (host helper
+    coreg_car_map) against astropy / wcslib composites."""
+    from euispice_coreg_amd import _lib
+    from tests.conftest import car_header
+    g = car_golden
+    out = _lib.car_map(car_header(g, tag + "/A"), car_header(g, tag + "/B"), g[tag + "/gx"], g[tag + "/gy"])
+    assert out is not None
+    assert np.abs(out[0] - g[tag + "/x"]).max() <= 1e-9
+    assert np.abs(out[1] - g[tag + "/y"]).max() <= 1e-9
+
+
+def test_car_map_host_reports_invalid_pole(car_golden):
+    from euispice_coreg_amd import _lib
+    from tests.conftest import car_header
+    g = car_golden
+    assert _lib.car_map(car_header(g, "equator"), car_header(g, "lonpole_bad"), [1.0], [2.0]) is None
+    with pytest.raises(_lib.CoregError):  # TAN header where a CAR one is required
+        _lib.car_map(car_header(g, "equator"), dict(car_header(g, "equator"), CTYPE1="HPLN-TAN"), [1.0], [2.0])

@@ -160,3 +160,36 @@ def test_cfg1_golden_fixture_is_reproducible():
     assert np.abs(got[:, 0, 0, 0, 0, 0] - g["parallel"][4:6, 5, 0, 0, 0, 0]).max() <= 1e-12
     am = np.unravel_index(np.nanargmax(g["serial"]), g["serial"].shape)
     assert (lags[0][am[0]], lags[1][am[1]]) == (truth["lag_crval1"], truth["lag_crval2"])
+
+
+@pytest.mark.parametrize("name", ["equator", "north", "south", "rolled", "high", "lonpole_ok", "lonpole_180"])
+def test_car_wcs_matches_wcslib(car_golden, name):
+    """Plate-carree headers of the align_using_initial_carrington path, oblique cases included (CRVAL2 != 0)."""
+    from tests.conftest import car_header
+    g = car_golden
+    w = O.CarWCS(car_header(g, name))
+    lon, lat = w.pixel_to_world(g[name + "/px"], g[name + "/py"])
+    assert np.abs(lon - g[name + "/lon"]).max() <= 1e-11   # raw wcslib longitude branch included
+    assert np.abs(lat - g[name + "/lat"]).max() <= 1e-11
+    bx, by = w.world_to_pixel(g[name + "/lon"], g[name + "/lat"])
+    assert np.abs(bx - g[name + "/back_x"]).max() <= 1e-9
+    assert np.abs(by - g[name + "/back_y"]).max() <= 1e-9
+    assert abs(w.latp - float(g[name + "/latpole_used"])) <= 1e-12
+
+
+def test_car_wcs_invalid_pole_raises_like_wcslib(car_golden):
+    from tests.conftest import car_header
+    assert [str(n) for n in car_golden["invalid"]] == ["lonpole_bad"]
+    with pytest.raises(O.InvalidTransformError):
+        O.CarWCS(car_header(car_golden, "lonpole_bad"))
+
+
+@pytest.mark.parametrize("tag", ["lag_ns", "lag_nn", "lag_roll", "lag_cdelt"])
+def test_car_composite_matches_wcslib(car_golden, tag):
+    from tests.conftest import car_header
+    g = car_golden
+    wa, wb = O.CarWCS(car_header(g, tag + "/A")), O.CarWCS(car_header(g, tag + "/B"))
+    lon, lat = wa.pixel_to_world(g[tag + "/gx"], g[tag + "/gy"])
+    x, y = wb.world_to_pixel(lon, lat)
+    assert np.abs(x - g[tag + "/x"]).max() <= 1e-9
+    assert np.abs(y - g[tag + "/y"]).max() <= 1e-9
