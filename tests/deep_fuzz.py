@@ -1,10 +1,9 @@
 """Long randomised GPU-vs-oracle parity run (the generator of tests/test_gpu_fuzz.py over many more seeds, plus
-method='residus', CDELT2 lags, both CDELT semantics, degrees headers).  usage: python profiles/deep_fuzz.py [n] [seed0] [scale]"""
+method='residus', CDELT2 lags, both CDELT semantics, degrees headers).  usage: python tests/deep_fuzz.py [n] [seed0] [scale]"""
 import os
 import sys
 import time
 
-import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
