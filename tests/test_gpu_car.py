@@ -91,3 +91,47 @@ def test_align_using_initial_carrington_dropin(tmp_path):
     s2, h2, l2, hl2, _ = helpers.scene(small_n=32, large_n=48)
     with pytest.raises(ValueError):
         Alignment((l2, hl2), (s2, h2), [0.0], [0.0], None, None, None).align_using_initial_carrington()
+
+
+@pytest.mark.parametrize("seed", list(range(300, 312)))
+def test_fuzz_car(gpu_handle, seed):
+    """Random Carrington-map pairs: rolls, unequal / negative pixel sizes, reference latitudes on both sides of the
+    equator and far from it, lag sets that cross CRVAL2 = 0, both spline orders, both methods' NaN rules."""
+    from euispice_coreg_amd import synthetic
+    rng = np.random.default_rng(seed)
+    ny, nx = int(rng.integers(40, 100)), int(rng.integers(40, 100))
+    cd = (0.0101 * rng.uniform(0.8, 1.3) * rng.choice([1.0, -1.0]), 0.0099 * rng.uniform(0.8, 1.3))
+    small, hs, large, hl, _ = synthetic.make_car_scene(small_shape=(ny, nx), large_shape=(int(ny * 1.4), int(nx * 1.5)),
+                                                       seed=seed, small_cdelt=(abs(cd[0]), cd[1]),
+                                                       crota=float(rng.choice([0.0, 0.4, -2.5, 30.0])),
+                                                       nan_frac=float(rng.choice([0.0, 0.01])),
+                                                       explicit_lonpole=bool(rng.integers(0, 2)))
+    hs = dict(hs)
+    if cd[0] < 0:  # flip the longitude axis of the map to align (header only: the oracle and the GPU see the same data)
+        hs["CDELT1"] = cd[0]
+        lam = hs["CDELT2"] / hs["CDELT1"]
+        rho = np.deg2rad(hs["CROTA"])
+        hs["PC1_2"], hs["PC2_1"] = float(-lam * np.sin(rho)), float(np.sin(rho) / lam)
+    off = float(rng.choice([0.0, 0.0, 12.0, -33.0]))  # move both maps away from the equator
+    if "LONPOLE" in hl:
+        off = abs(off)  # an explicit LONPOLE = 0 is only valid north of the equator (the library refuses such a target)
+    hs["CRVAL2"] += off
+    hl = dict(hl, CRVAL2=hl["CRVAL2"] + off)
+    l1 = np.sort(rng.uniform(-0.05, 0.05, int(rng.integers(1, 6))))
+    l2 = rng.uniform(-0.04, 0.04, int(rng.integers(1, 6)))
+    crot = [0.0] if rng.integers(0, 2) else [-0.3, 0.0, 0.2]
+    cdl = None if rng.integers(0, 2) else [0.0, 0.0002]
+    lags = (l1, l2, cdl, None, crot)
+    order = int(rng.choice([1, 2]))
+    got = _sweep(gpu_handle, small, hs, large, hl, lags, order=order)
+    want = H.oracle_helio(small.astype(np.float64), hs, large.astype(np.float64), hl, lags, order=order,
+                          parallelism=False, unit_lag="deg")
+    H.assert_corr_close(got, want, 1e-7, f"fuzz CAR seed={seed}")
+
+
+def test_car_invalid_target_header_is_an_error(gpu_handle):
+    from euispice_coreg_amd import _lib, synthetic
+    small, hs, large, hl, _ = synthetic.make_car_scene(explicit_lonpole=True, small_shape=(40, 40), large_shape=(60, 60))
+    hl = dict(hl, CRVAL2=-20.0)  # LONPOLE = 0 south of the equator: astropy cannot build WCS(hdr_large) either
+    with pytest.raises(_lib.CoregError):
+        _sweep(gpu_handle, small, hs, large, hl, ([0.0], [0.0], None, None, None))
