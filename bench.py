@@ -8,7 +8,9 @@ lag-points), crota/cdelt fixed, solar_r 1.004, order 2, method 'correlation'; se
 2048^2 image to align and FSI-like 3072^2 reference (euispice_coreg_amd/synthetic.py).
 
 A "step" = one full sweep (all 3600 lag-points) through the C ABI with both images already resident in HBM
-(upload + once-only reference preparation happen before the timed region).  N > 1 (torchrun, one rank per GPU):
+(upload + once-only reference preparation happen before the timed region).  `--streams` (default 2) steps are in
+flight at a time, each on its own HIP stream and library context, so that the drain of one sweep overlaps the start of
+the next; every step is a complete sweep.  N > 1 (torchrun, one rank per GPU):
 the (CRVAL1, CRVAL2) lag plane is cut in N blocks (the multi-GPU form of the reference's np.array_split fan-out,
 alignment.py:677-687), every rank sweeps its block with full image replicas and ONE all-gather (RCCL) of the per-lag
 coefficients, followed by an index permutation, assembles the map on every rank.  Total work is fixed as N grows
@@ -94,6 +96,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="sweeps in flight (one HIP stream + library context each)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement after the timed region")
     ap.add_argument("--cpu-sample", type=int, default=0, help="lag-points in the CPU sample (0 = 48 per core)")
     ap.add_argument("--use-lds", type=int, default=1)
@@ -107,6 +110,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+
+    # native libraries (RCCL prints a version banner on first use) write to fd 1: keep stdout for the ONE JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -139,41 +147,55 @@ def main():
     if rank == 0:
         log(f"[bench] scene built in {time.time() - t0:.1f} s; L = {L}")
 
-    h = _lib.CoregHandle(local_rank)
-    h.set_option("use_lds", args.use_lds)
-    for kv in filter(None, os.environ.get("COREG_BENCH_OPTS", "").split(",")):  # tuning experiments: "opt=val,opt=val"
-        k, v = kv.split("=")
-        h.set_option(k, int(v))
-    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    # `--streams S` (default 2) sweeps are in flight at a time, each on its own HIP stream with its own library context:
+    # the tail of one sweep (workgroups draining, the small finalize / next precompute kernels) overlaps the head of
+    # the next.  Every step is still one complete sweep of all lag-points of this rank.
+    n_streams = max(1, args.streams)
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_streams - 1)]
     grid = _lib.Grid(LONLIMS, LATLIMS, GRID_SHAPE, numpy_lat_trig=True)
     lagset = _lib.LagSet(*lags)
-    # inputs resident in HBM before the timed region
     small_m = small.copy()
-    h.set_small(small_m)
-    h.prepare_reference_carrington(large, hl, grid, SOLAR_R, ORDER)
+    handles = []
+    for s in streams:
+        hk = _lib.CoregHandle(local_rank)
+        hk.set_option("use_lds", args.use_lds)
+        for kv in filter(None, os.environ.get("COREG_BENCH_OPTS", "").split(",")):  # tuning: "opt=val,opt=val"
+            k, v = kv.split("=")
+            hk.set_option(k, int(v))
+        hk.set_stream(s.cuda_stream)
+        # inputs resident in HBM before the timed region
+        hk.set_small(small_m)
+        hk.prepare_reference_carrington(large, hl, grid, SOLAR_R, ORDER)
+        handles.append(hk)
+    h = handles[0]
 
     from euispice_coreg_amd import parallel
     lo1, hi1, lo2, hi2 = parallel.block_bounds(lag1.size, lag2.size, world, rank)
     my_lags = _lib.LagSet(lag1[lo1:hi1], lag2[lo2:hi2], None, None, None) if (hi1 > lo1 and hi2 > lo2) else None
     perm_np, chunk = parallel.block_gather_index((lag1.size, lag2.size, 1, 1, 1), world)
-    mine = torch.full((chunk,), float("nan"), dtype=torch.float64, device="cuda")
-    gathered = torch.empty((chunk * world,), dtype=torch.float64, device="cuda") if use_dist else mine
+    mine = [torch.full((chunk,), float("nan"), dtype=torch.float64, device="cuda") for _ in streams]
+    gathered = [torch.empty((chunk * world,), dtype=torch.float64, device="cuda") if use_dist else m for m in mine]
     perm = torch.from_numpy(perm_np).to("cuda")
+    torch.cuda.synchronize()
     result = [None]
+    step_no = [0]
 
     def step():
-        if my_lags is not None:
-            h.sweep_carrington(hs, grid, SOLAR_R, my_lags, order=ORDER, out_dev_ptr=mine.data_ptr())
-        if use_dist:
-            if backend == "nccl":
-                dist.all_gather_into_tensor(gathered, mine)  # the ONE collective of the path
-                result[0] = gathered[perm]
+        k = step_no[0] % n_streams
+        step_no[0] += 1
+        with torch.cuda.stream(streams[k]):
+            if my_lags is not None:
+                handles[k].sweep_carrington(hs, grid, SOLAR_R, my_lags, order=ORDER, out_dev_ptr=mine[k].data_ptr())
+            if use_dist:
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(gathered[k], mine[k])  # the ONE collective of the path
+                    result[0] = gathered[k][perm]
+                else:
+                    parts = [torch.empty(chunk, dtype=torch.float64) for _ in range(world)]
+                    dist.all_gather(parts, mine[k].cpu())
+                    result[0] = torch.cat(parts)[perm.cpu()]
             else:
-                parts = [torch.empty(chunk, dtype=torch.float64) for _ in range(world)]
-                dist.all_gather(parts, mine.cpu())
-                result[0] = torch.cat(parts)[perm.cpu()]
-        else:
-            result[0] = mine[perm]
+                result[0] = mine[k][perm]
 
     for _ in range(args.warmup):
         step()
@@ -192,18 +214,22 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # dominant-kernel duration: the library brackets every k_sweep launch with HIP events on the launch stream; reading
-    # them waits for the sweep, so it is done here, for the last timed step and a few identical extra steps
-    stats = h.last_stats() if my_lags is not None else {"sweep_kernel_ms": 0.0, "precompute_ms": 0.0,
-                                                        "n_active_points": 0, "small_is_f32": 1, "used_lds": 1}
-    kernel_ms.append(stats["sweep_kernel_ms"])
-    pre_ms.append(stats["precompute_ms"])
+    # dominant-kernel duration: the library brackets every k_sweep launch with HIP events on the launch stream.  Reading
+    # them waits for the sweep, and with several sweeps in flight a kernel's event interval also contains the time its
+    # workgroups waited for the other sweep's to leave the CUs -- so the kernel is timed here, right after the timed
+    # region, on identical steps issued ONE at a time
+    stats = {"sweep_kernel_ms": 0.0, "precompute_ms": 0.0, "n_active_points": 0, "small_is_f32": 1, "used_lds": 1}
     for _ in range(min(8, args.steps)):
+        step_no[0] = 0  # handle / stream 0
         step()
         if my_lags is not None:
-            st = h.last_stats()
-            kernel_ms.append(st["sweep_kernel_ms"])
-            pre_ms.append(st["precompute_ms"])
+            stats = h.last_stats()
+            kernel_ms.append(stats["sweep_kernel_ms"])
+            pre_ms.append(stats["precompute_ms"])
+        else:
+            torch.cuda.synchronize()
+    if not kernel_ms:
+        kernel_ms, pre_ms = [0.0], [0.0]
     if use_dist:
         dist.barrier()
     corr = result[0].cpu().numpy()
@@ -247,6 +273,7 @@ def main():
                                    "lags arange(-30,30,1) arcsec, small 2048^2 HRIEUV-like, ref 3072^2 FSI-like, "
                                    "order 2, solar_r 1.004",
                        "lag_points": L, "grid": list(GRID_SHAPE), "parallelism": f"lag-plane blocks x{world} + 1 all-gather",
+                       "sweeps_in_flight": n_streams,
                        "small_stored_f32": bool(stats["small_is_f32"]), "use_lds": bool(stats["used_lds"])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
@@ -256,7 +283,8 @@ def main():
                          "algorithmic_bytes_per_lag": b_lag, "lags_per_launch": lags_per_launch,
                          "note": "algorithmic bytes = one-lag-per-pass model (SURVEY 8d); the kernel batches 256 lags "
                                  "per workgroup and culls grid points outside the small FOV, so frac can exceed 1; "
-                                 "the binding resource is fp64 VALU (see valu_fp64)"},
+                                 "the binding resource is fp64 VALU (see valu_fp64); kernel_ms = HIP events around single, "
+                                 "non-overlapped launches right after the timed region"},
             "valu_fp64": {"achieved": valu_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                           "frac": valu_tf / FP64_VALU_PEAK_TF, "active_points": int(act),
                           "flop_per_point_lag": FLOP_PER_POINT_LAG},
@@ -282,8 +310,12 @@ def main():
                                                                           np.nanargmax(corr_cpu.ravel()[subset]))}
         else:
             out["cpu_baseline"] = None
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
-    h.close()
+        os.dup2(2, 1)
+    for hk in handles:
+        hk.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
