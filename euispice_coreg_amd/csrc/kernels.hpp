@@ -5,8 +5,8 @@
 //     lag-independent part of the pixel-coordinate transform once per tile, drops points that can never
 //     contribute (reference NaN, behind the limb, outside the small image for every lag) and stores the
 //     survivors compacted, tile-major, together with their bounding box in small-image pixel space;
-//   * the sweep kernel (k_sweep) gives every LANE one lag-point (a workgroup = 256 lags of a compact CRVAL patch)
-//     and walks the compacted points of its tiles: point data are wave-uniform (scalar loads), every lane adds
+//   * the sweep kernel (k_sweep) gives every LANE one lag-point (a workgroup = 4 point-groups x 256 lags of a compact
+//     CRVAL patch, all sharing one LDS window) and walks the compacted points of its tiles: point data are wave-uniform (scalar loads), every lane adds
 //     its own lag displacement, gathers the 3x3 (order 2) / 2x2 (order 1) taps from an LDS-staged window of the
 //     small image and accumulates its own six Pearson sums in registers.  No cross-lane reduction exists
 //     anywhere on the hot path; partial sums leave the kernel once per (tile-group, lag);
