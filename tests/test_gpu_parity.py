@@ -195,6 +195,23 @@ def test_sweep_helioprojective_vs_oracle(gpu_handle, order, use_lds):
     H.assert_corr_close(got, want, 1e-7, f"helio order={order} lds={use_lds}")
 
 
+def test_homography_exact_division_path_equals_series_path(gpu_handle):
+    """The projective denominator is inverted by the series 1 - eps + eps^2 when the host proves |eps| < 4e-6, by
+    v_rcp_f64 + a Newton step otherwise (wide fields of view); both agree with the oracle and with each other."""
+    small, hs, large, hl, _ = H.scene(small_n=80, large_n=128)
+    lags = _lags(5, 4, crota=[0.0, -0.4])
+    want = H.oracle_helio(small, hs, large, hl, lags)
+    gpu_handle.set_option("h_series", 0)
+    try:
+        exact = H.gpu_helio(gpu_handle, small, hs, large, hl, lags)
+    finally:
+        gpu_handle.set_option("h_series", 1)
+    series = H.gpu_helio(gpu_handle, small, hs, large, hl, lags)
+    H.assert_corr_close(exact, want, 1e-7, "helio, exact division")
+    H.assert_corr_close(series, want, 1e-7, "helio, series inverse")
+    assert np.nanmax(np.abs(exact - series)) <= 1e-9
+
+
 def test_sweep_helioprojective_serial_semantics(gpu_handle):
     """parallelism=False path of the reference (quirk Q1): target = FULL large-FOV grid, float64 reference."""
     small, hs, large, hl, _ = H.scene(small_n=64, large_n=96)
