@@ -280,6 +280,7 @@ def main():
                          "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.txt)",
                          "algorithmic_bytes_per_launch": b_lag * lags_per_launch,
                          "kernel": "k_sweep<TRANSLATE,2,f32>", "kernel_ms": k_ms,
+                         "timed_region_ms_per_launch": ms_per_step,  # wall per sweep with `sweeps_in_flight` overlapped
                          "algorithmic_bytes_per_lag": b_lag, "lags_per_launch": lags_per_launch,
                          "note": "algorithmic bytes = one-lag-per-pass model (SURVEY 8d); the kernel batches 256 lags "
                                  "per workgroup and culls grid points outside the small FOV, so frac can exceed 1; "
