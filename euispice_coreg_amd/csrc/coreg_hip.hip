@@ -284,7 +284,9 @@ template <typename F>
 int dispatch_resample(coreg_handle* h, int mode, int order, bool ts_f32, bool out_f32, const ResampleArgs& a, F) {
     const long long n = (long long)a.gw * a.gh;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-#define RS(M, O, TS, TO) hipLaunchKernelGGL((k_resample<M, O, TS, TO>), grid, block, 0, h->stream, a)
+    ResampleArgs b = a;
+    b.order_rt = order;
+#define RS(M, O, TS, TO) hipLaunchKernelGGL((k_resample<M, O, TS, TO>), grid, block, 0, h->stream, b)
 #define RS_T(M, O)                                  \
     do {                                            \
         if (ts_f32) {                               \
@@ -297,10 +299,12 @@ int dispatch_resample(coreg_handle* h, int mode, int order, bool ts_f32, bool ou
     } while (0)
     if (mode == MODE_TRANSLATE) {
         if (order == 2) RS_T(MODE_TRANSLATE, 2);
-        else RS_T(MODE_TRANSLATE, 1);
+        else if (order == 1) RS_T(MODE_TRANSLATE, 1);
+        else RS_T(MODE_TRANSLATE, ORDER_RT);
     } else {
         if (order == 2) RS_T(MODE_HOMOGRAPHY, 2);
-        else RS_T(MODE_HOMOGRAPHY, 1);
+        else if (order == 1) RS_T(MODE_HOMOGRAPHY, 1);
+        else RS_T(MODE_HOMOGRAPHY, ORDER_RT);
     }
 #undef RS_T
 #undef RS
@@ -309,8 +313,10 @@ int dispatch_resample(coreg_handle* h, int mode, int order, bool ts_f32, bool ou
 }
 
 int check_order(coreg_handle* h, int order) {
-    if (order != 1 && order != 2)
-        return fail(h, COREG_ENOTIMPL, "reprojection_order must be 1 or 2 (got " + std::to_string(order) + ")");
+    // scipy.ndimage.map_coordinates accepts spline orders 0..5 (utils/Util.py:98-102); 1 and 2 run on the tuned
+    // kernels, the others on the run-time-order variant
+    if (order < 0 || order > 5)
+        return fail(h, COREG_EINVAL, "reprojection_order must be in 0..5 (got " + std::to_string(order) + ")");
     return COREG_OK;
 }
 
@@ -503,7 +509,7 @@ void fill_precompute_common(coreg_handle* h, PrecomputeArgs* a, int tile_w) {
 // indices are already on the device
 int launch_sweep(coreg_handle* h, int mode, int order, int method, const double* params_dev,
                  const long long* outidx_dev, int n_batches, int n_tiles, long long lag_begin, double* out_dev,
-                 const Aff6* car_inv = nullptr) {
+                 const LaunchU* car_inv = nullptr) {
     const long long n_slots = (long long)n_batches * kBlock;
     const int n_groups = pick_groups(h, n_batches, n_tiles);
     HIPCHK(h->partials.reserve((size_t)n_groups * kNumSums * n_slots * sizeof(double)));
@@ -532,6 +538,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     a.lds_elems = (int)(lds_bytes / sizeof(double));
     std::memset(&a.car_inv, 0, sizeof(a.car_inv));
     if (car_inv) a.car_inv = *car_inv;
+    a.car_inv.order_rt = order;
 
     const dim3 grid((unsigned)((long long)n_groups * n_batches)), block(kSweepThreads);
     EventPair* ev = next_event(h, h->ev_sweep, h->ev_sweep_used);
@@ -567,16 +574,19 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     // TRANSLATE = Carrington (float64 samples); HOMOGRAPHY[_SERIES] = helioprojective (samples rounded to float32)
     if (mode == MODE_TRANSLATE) {
         if (order == 2) SW_T(MODE_TRANSLATE, 2, false);
-        else SW_T(MODE_TRANSLATE, 1, false);
+        else if (order == 1) SW_T(MODE_TRANSLATE, 1, false);
+        else SW_T(MODE_TRANSLATE, ORDER_RT, false);
     } else if (mode == MODE_CAR) {
         if (order == 2) SW_T(MODE_CAR, 2, true);
-        else SW_T(MODE_CAR, 1, true);
-    } else if (mode == MODE_HOMOGRAPHY_SERIES) {
+        else if (order == 1) SW_T(MODE_CAR, 1, true);
+        else SW_T(MODE_CAR, ORDER_RT, true);
+    } else if (mode == MODE_HOMOGRAPHY_SERIES && (order == 1 || order == 2)) {
         if (order == 2) SW_T(MODE_HOMOGRAPHY_SERIES, 2, true);
         else SW_T(MODE_HOMOGRAPHY_SERIES, 1, true);
     } else {
         if (order == 2) SW_T(MODE_HOMOGRAPHY, 2, true);
-        else SW_T(MODE_HOMOGRAPHY, 1, true);
+        else if (order == 1) SW_T(MODE_HOMOGRAPHY, 1, true);
+        else SW_T(MODE_HOMOGRAPHY, ORDER_RT, true);
     }
 #undef SW_Q
 #undef SW_T
@@ -1227,7 +1237,7 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
     struct Launch {
         size_t slot_off;
         int n_batches;
-        Aff6 inv;
+        LaunchU inv;
     };
     std::vector<Launch> launches;
     std::vector<double> params;  // per launch: SoA [9][slots of the launch]

@@ -45,10 +45,13 @@ struct __attribute__((aligned(32))) Pt {
 // a truncation error below 1e-16 relative); MODE_HOMOGRAPHY divides exactly (any field of view)
 // MODE_CAR: plate-carree maps on both sides (align_using_initial_carrington): base coordinates = native (phi, theta) of
 // the target pixel [radians], per lag a rotation of the sphere (h[0..8]) between the two native frames, then
-// (atan2, asin) and the affine native -> pixel map of the shifted header (uniform per launch, Aff6)
+// (atan2, asin) and the affine native -> pixel map of the shifted header (uniform per launch, LaunchU)
 enum { MODE_TRANSLATE = 0, MODE_HOMOGRAPHY = 1, MODE_HOMOGRAPHY_SERIES = 2, MODE_CAR = 3 };
-struct Aff6 {
-    double m00, m01, m10, m11, b0, b1;
+// per-launch uniforms of the coordinate map / sampler that are not per-lane
+struct LaunchU {
+    double m00, m01, m10, m11, b0, b1;  // MODE_CAR: native (phi, theta) [rad] -> 0-based pixel
+    int order_rt;                       // ORDER == ORDER_RT kernels: the spline order (0..5)
+    int pad_;
 };
 
 struct CarrDev {
@@ -105,7 +108,7 @@ __device__ __forceinline__ void apply_h_series(const H9& m, double x, double y, 
 }
 // wcslib sphx2s / sphs2x + cars2x for one point: native angles of the target -> unit vector -> rotated -> native angles
 // of the shifted map -> its pixel
-__device__ __forceinline__ void apply_car(const H9& m, const Aff6& u, double phi, double theta, double& ox, double& oy) {
+__device__ __forceinline__ void apply_car(const H9& m, const LaunchU& u, double phi, double theta, double& ox, double& oy) {
     double sp, cp, st, ct;
     sincos(phi, &sp, &cp);
     sincos(theta, &st, &ct);
@@ -119,7 +122,7 @@ __device__ __forceinline__ void apply_car(const H9& m, const Aff6& u, double phi
     oy = fma(u.m10, p, fma(u.m11, t, u.b1));
 }
 template <int MODE>
-__device__ __forceinline__ void apply_map(const H9& m, const Aff6& u, double x, double y, double& ox, double& oy) {
+__device__ __forceinline__ void apply_map(const H9& m, const LaunchU& u, double x, double y, double& ox, double& oy) {
     if (MODE == MODE_CAR) apply_car(m, u, x, y, ox, oy);
     else if (MODE == MODE_HOMOGRAPHY_SERIES) apply_h_series(m, x, y, ox, oy);
     else apply_h(m, x, y, ox, oy);
@@ -175,6 +178,98 @@ __device__ __forceinline__ int mirror_idx(int i, int n) {  // scipy: reflect abo
     i = i < 0 ? -i : i;
     i = i > n - 1 ? 2 * (n - 1) - i : i;
     return min(max(i, 0), n - 1);
+}
+
+// ---- any spline order 0..5 at run time (reprojection_order is a user argument, alignment.py:54): global-memory gather
+// only, not tuned.  Kernels take ORDER == ORDER_RT and read the order from their launch uniforms.
+constexpr int ORDER_RT = 0;
+template <>
+struct Spline<ORDER_RT> {
+    static constexpr int N = 6;  // array bound only
+};
+// scipy ni_splines.c get_spline_interpolation_weights + the start index of ni_interpolation.c
+__device__ inline void spline_weights_rt(int order, double c, int& start, double w[6]) {
+    const bool odd = (order & 1) != 0;
+    const double f = floor(odd ? c : c + 0.5);
+    const double y = c - f;
+    start = (int)f - order / 2;
+    switch (order) {
+        case 0:
+            w[0] = 1.0;
+            break;
+        case 1:
+            w[0] = 1.0 - y;
+            w[1] = y;
+            break;
+        case 2: {
+            w[1] = 0.75 - y * y;
+            const double t = 0.5 - y;
+            w[0] = 0.5 * t * t;
+            w[2] = 1.0 - w[0] - w[1];
+            break;
+        }
+        case 3: {
+            const double z = 1.0 - y;
+            w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
+            w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) / 6.0;
+            w[0] = z * z * z / 6.0;
+            w[3] = 1.0 - w[0] - w[1] - w[2];
+            break;
+        }
+        case 4: {
+            double t = y * y;
+            w[2] = t * (t * 0.25 - 0.625) + 115.0 / 192.0;
+            const double y1 = 1.0 + y;
+            w[1] = y1 * (y1 * (y1 * (5.0 - y1) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+            const double z = 1.0 - y;
+            w[3] = z * (z * (z * (5.0 - z) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+            const double y2 = 0.5 - y;
+            t = y2 * y2;
+            w[0] = t * t / 24.0;
+            w[4] = 1.0 - w[0] - w[1] - w[2] - w[3];
+            break;
+        }
+        default: {  // 5
+            double t = y * y;
+            w[2] = t * (t * (0.25 - y / 12.0) - 0.5) + 0.55;
+            const double z = 1.0 - y;
+            t = z * z;
+            w[3] = t * (t * (0.25 - z / 12.0) - 0.5) + 0.55;
+            const double y1 = y + 1.0;
+            w[1] = y1 * (y1 * (y1 * (y1 * (y1 / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+            const double z1 = z + 1.0;
+            w[4] = z1 * (z1 * (z1 * (z1 * (z1 / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+            t = z * z;
+            w[0] = z * t * t / 120.0;
+            w[5] = 1.0 - w[0] - w[1] - w[2] - w[3] - w[4];
+            break;
+        }
+    }
+}
+__device__ __forceinline__ int mirror_far(int i, int n) {  // scipy NI_EXTEND_MIRROR for indices several samples out
+    if (n <= 1) return 0;
+    const int p = 2 * (n - 1);
+    i = i < 0 ? -i : i;
+    i = i % p;
+    return i > n - 1 ? p - i : i;
+}
+template <typename TS>
+__device__ inline double spline_global_rt(const TS* __restrict__ img, int W, int H, double nx, double ny, int order,
+                                          bool& inb) {
+    inb = (nx >= 0.0) & (nx <= (double)(W - 1)) & (ny >= 0.0) & (ny <= (double)(H - 1));
+    const double cx = inb ? nx : 0.0, cy = inb ? ny : 0.0;
+    int sx, sy;
+    double wx[6], wy[6];
+    spline_weights_rt(order, cx, sx, wx);
+    spline_weights_rt(order, cy, sy, wy);
+    double acc = 0.0;
+    for (int a = 0; a <= order; ++a) {
+        const TS* __restrict__ rowp = img + (size_t)mirror_far(sy + a, H) * W;
+        double row = 0.0;
+        for (int b = 0; b <= order; ++b) row = fma((double)rowp[mirror_far(sx + b, W)], wx[b], row);
+        acc = fma(row, wy[a], acc);
+    }
+    return acc;
 }
 
 // One sample of map_coordinates(order, mode='constant', prefilter=False) from global memory.
@@ -310,6 +405,7 @@ struct ResampleArgs {
     double x0, y0;  // Carrington origin (utils/rectify.py:402-404)
     H9 hom;
     void* out;
+    int order_rt;  // ORDER == ORDER_RT: the spline order
 };
 template <int MODE, int ORDER, typename TS, typename TO>
 __global__ void __launch_bounds__(256) k_resample(const ResampleArgs a) {
@@ -328,7 +424,9 @@ __global__ void __launch_bounds__(256) k_resample(const ResampleArgs a) {
     }
     bool inb;
     if (!ok) nx = __builtin_nan("");
-    double v = spline_global<ORDER, TS>((const TS*)a.img, a.W, a.H, nx, ny, inb);
+    double v;
+    if constexpr (ORDER == ORDER_RT) v = spline_global_rt<TS>((const TS*)a.img, a.W, a.H, nx, ny, a.order_rt, inb);
+    else v = spline_global<ORDER, TS>((const TS*)a.img, a.W, a.H, nx, ny, inb);
     if (!inb) v = __builtin_nan("");
     ((TO*)a.out)[idx] = (TO)v;
 }
@@ -340,7 +438,7 @@ struct PrecomputeArgs {
     int tile_w, tile_h;  // tile_w * tile_h == kTilePts
     int tiles_x, tiles_y;
     CarrDev carr;             // MODE_TRANSLATE
-    Aff6 car_fwd;             // MODE_CAR: 0-based target pixel -> its native (phi, theta) [rad]
+    LaunchU car_fwd;             // MODE_CAR: 0-based target pixel -> its native (phi, theta) [rad]
     double f0lo, f0hi, f1lo, f1hi;  // cull box on the base coordinates (inclusive)
     int residus;              // 1: method 'residus' -> pts hold the raw reference value and 1/sqrt(value)
     const double* pivot_a;    // device scalar: mean of the finite reference values
@@ -561,7 +659,7 @@ struct SweepArgs {
     const double* pivots;  // device: [0] mean(reference) (already subtracted in aval), [1] mean(small image)
     int use_lds;
     int lds_elems;     // capacity of the dynamic LDS window in float64 elements
-    Aff6 car_inv;      // MODE_CAR: native (phi, theta) [rad] -> 0-based pixel of the shifted map of this launch
+    LaunchU car_inv;      // MODE_CAR: native (phi, theta) [rad] -> 0-based pixel of the shifted map of this launch
 };
 
 struct Acc {
@@ -645,10 +743,10 @@ struct Taps<2> {
 template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false>
 __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                           int ox, int oy, int W, int H, double wmax, double hmax, double px0, double py0,
-                                          double pxw, double pyw, const H9& hm, const Aff6& cu, double b0, double b1, double av,
+                                          double pxw, double pyw, const H9& hm, const LaunchU& cu, double b0, double b1, double av,
                                           double isa, double pivot_b) {
     constexpr int N = Spline<ORDER>::N;
-    if (INTERIOR && LDS) {
+    if constexpr (INTERIOR && LDS) {
         // Every sample is inside the image: no bounds rule.  Window-relative coordinate u = coordinate + 0.5 - 1 -
         // origin (order 2) / coordinate - origin (order 1): trunc(u) = window index of the first tap, fract(u) -> t.
         // (For TRANSLATE the constant is folded into the lane's origin, which moves the float64 rounding of the sum by
@@ -733,7 +831,10 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
         int sx, sy;
         double wx[N], wy[N];
         double v = 0.0;
-        if (LDS) {
+        if constexpr (ORDER == ORDER_RT) {
+            bool inb;
+            v = spline_global_rt<TS>(img, W, H, nx, ny, cu.order_rt, inb);
+        } else if constexpr (LDS) {
             // tap addresses first, so that the reads are in flight while the weights are computed
             const double fx = floor(nx + (ORDER == 2 ? 0.5 : 0.0)), fy = floor(ny + (ORDER == 2 ? 0.5 : 0.0));
             const int r0 = (int)fy - (ORDER == 2 ? 1 : 0) - oy;
@@ -803,7 +904,7 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
 template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false>
 __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                             int ox, int oy, int W, int H, double px0, double py0, double pxw,
-                                            double pyw, const H9& hm, const Aff6& cu, const Pt* __restrict__ pts, int p_begin, int p_end,
+                                            double pyw, const H9& hm, const LaunchU& cu, const Pt* __restrict__ pts, int p_begin, int p_end,
                                             double pivot_b, int pg) {
     // points [p_begin, p_end) of the tile: p_begin is a multiple of kChunk * kPointGroups, p_end is one too or the
     // tile's point count
@@ -940,11 +1041,14 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
         const int ww = ex - ox + 1, wh = ey - oy + 1;
         const int pitch = ww | 1;  // odd pitch: measured best for the ~2-pixel lag lattice (rejected layouts)
         const long long need = (long long)pitch * wh;
-        const bool in_lds = a.use_lds && (need <= (long long)a.lds_elems);
+        const bool in_lds = ORDER != ORDER_RT && a.use_lds && (need <= (long long)a.lds_elems);
 
         const Pt* __restrict__ pts = a.pts + (size_t)tile * kTilePts;
 
-        if (in_lds) {
+        bool swept = false;
+        if constexpr (ORDER != ORDER_RT) {
+          if (in_lds) {
+            swept = true;
             // Stage the window.  The loads are L2 round trips: kStage rows per wave are in flight at a time (one wave
             // would otherwise wait out ~20 dependent load -> store round trips per visit).
             constexpr int kStage = 8;
@@ -991,7 +1095,9 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
                 tile_points<MODE, ORDER, TS, true, ROUND, RESID>(acc, win, img, pitch, ox, oy, W, H, px0, py0, 0.0, 0.0, hm,
                                                                  a.car_inv, pts, p_begin, p_end, pivot_b, pg);
             }
-        } else {
+          }
+        }
+        if (!swept) {
             tile_points<MODE, ORDER, TS, false, ROUND, RESID>(acc, win, img, 0, 0, 0, W, H, px0, py0, 0.0, 0.0, hm, a.car_inv, pts,
                                                               p_begin, p_end, pivot_b, pg);
         }

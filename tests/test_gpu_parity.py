@@ -303,8 +303,8 @@ def test_errors_are_loud(gpu_handle):
             h2.sweep_helioprojective(hs, hs, _lib.LagSet([0.0], [0.0], None, None, None))
         h2.set_small(small)
         h2.prepare_reference_helioprojective(large, hl, hs, 2)
-        with pytest.raises(_lib.CoregError):  # unsupported spline order
-            h2.sweep_helioprojective(hs, hs, _lib.LagSet([0.0], [0.0], None, None, None), order=3)
+        with pytest.raises(_lib.CoregError):  # spline order outside scipy's 0..5
+            h2.sweep_helioprojective(hs, hs, _lib.LagSet([0.0], [0.0], None, None, None), order=7)
         with pytest.raises(_lib.CoregError):  # unknown method: refuse, never fall back
             h2.sweep_helioprojective(hs, hs, _lib.LagSet([0.0], [0.0], None, None, None), method=7)
         with pytest.raises(_lib.CoregError):
@@ -336,3 +336,35 @@ def test_cfg1_against_committed_golden(gpu_handle):
     H.assert_corr_close(got, g["carrington"], 1e-10, "cfg1 carrington vs golden")
     am = np.unravel_index(np.nanargmax(got), got.shape)
     assert (lags[0][am[0]], lags[1][am[1]]) == (truth["lag_crval1"], truth["lag_crval2"])
+
+
+@pytest.mark.parametrize("order", [0, 3, 4, 5])
+def test_other_spline_orders_vs_oracle(gpu_handle, order):
+    """reprojection_order is a user argument (alignment.py:54) and scipy's map_coordinates takes 0..5: the orders the
+    tuned kernels do not cover run on the run-time-order variant (global-memory gather), all three frames."""
+    small, hs, large, hl, _ = H.scene(small_n=72, large_n=112)
+    lags = _lags(4, 3, crota=[0.0, 0.3])
+    want = H.oracle_carrington(small, hs, large, hl, lags, (40, 36), order=order)
+    got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, (40, 36), order=order)
+    H.assert_corr_close(got, want, 1e-9, f"carrington order={order}")
+    for serial in (False, True):
+        want = H.oracle_helio(small, hs, large, hl, lags, order=order, parallelism=not serial)
+        got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order, serial_semantics=serial)
+        H.assert_corr_close(got, want, 1e-7, f"helio order={order} serial={serial}")
+    from euispice_coreg_amd import _lib, synthetic
+    cs, chs, cl, chl, _ = synthetic.make_car_scene(small_shape=(60, 70), large_shape=(90, 100))
+    clags = (np.array([0.0, 0.018]), np.array([-0.011, 0.004]), None, None, None)
+    gpu_handle.set_small(cs)
+    gpu_handle.set_reference_on_grid(np.asarray(cl, dtype=np.float32))
+    ls = _lib.LagSet(*clags)
+    got = gpu_handle.sweep_helioprojective(chl, chs, ls, order=order).reshape(ls.shape + (1,))
+    want = H.oracle_helio(cs.astype(np.float64), chs, cl.astype(np.float64), chl, clags, order=order, parallelism=False,
+                          unit_lag="deg")
+    H.assert_corr_close(got, want, 1e-7, f"CAR order={order}")
+
+
+def test_spline_order_out_of_range_is_an_error(gpu_handle):
+    from euispice_coreg_amd import _lib
+    small, hs, large, hl, _ = H.scene(small_n=32, large_n=48)
+    with pytest.raises(_lib.CoregError):
+        H.gpu_helio(gpu_handle, small, hs, large, hl, _lags(2, 2), order=6)
