@@ -131,7 +131,11 @@ int coreg_threshold_small(coreg_handle* h, int has_min, double vmin, int has_max
  * [gy][gx], dtype COREG_F32 (helioprojective sub-map, alignment.py:995) or COREG_F64 (Carrington). */
 int coreg_set_reference_on_grid(coreg_handle* h, const void* ref, int dtype, int32_t gy, int32_t gx);
 
-/* Once-per-sweep reference preparation on the GPU.
+/* `order` everywhere below: the spline order of scipy.ndimage.map_coordinates(..., prefilter=False) (utils/Util.py:98-102,
+ * Alignment(reprojection_order=...), alignment.py:54), 0..5; 2 (the default of the reference) and 1 run on the tuned
+ * kernels.
+ *
+ * Once-per-sweep reference preparation on the GPU.
  * carrington:      alignment.py:646-648 -> :889-901  (large image -> Carrington grid, float64)
  * helioprojective: alignment.py:649-651 -> :987-1000 (large image -> small header's pixel grid, float32) */
 int coreg_prepare_reference_carrington(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
@@ -166,7 +170,9 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
                            double solar_r, const coreg_lags* lags, int order, int method, int cdelt_semantics,
                            int64_t lag_begin, int64_t lag_end, double* corr_out, int out_on_device);
 /* hdr_target: header whose pixel grid the reference image lives on (the unshifted small header in the
- * parallelism=True path, alignment.py:1000; the large header in the serial path, quirk Q1). */
+ * parallelism=True path, alignment.py:1000; the large header in the serial path, quirk Q1).  Both headers TAN
+ * (helioprojective), or both CAR: Carrington maps, align_using_initial_carrington (alignment.py:344-399), hdr_target =
+ * the reference map's header. */
 int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_small,
                                 const coreg_lags* lags, int order, int method, int cdelt_semantics,
                                 int64_t lag_begin, int64_t lag_end, double* corr_out, int out_on_device);
