@@ -3,7 +3,7 @@
 # usage (on the GPU box, from the repo root):  bash profiles/run_pmc.sh <outdir> [bench args...]
 set -e
 O=$1; shift
-A="--steps 3 --warmup 1 --no-cpu-baseline $@"
+A="--steps 3 --warmup 1 --no-cpu-baseline --no-pcie --streams 1 $@"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p $O
 run() { n=$1; shift; timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$n -- python3 bench.py $A > /dev/null 2> $O/$n.err; }
