@@ -100,7 +100,6 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement after the timed region")
     ap.add_argument("--cpu-sample", type=int, default=0, help="lag-points in the CPU sample (0 = 48 per core)")
     ap.add_argument("--use-lds", type=int, default=1)
-    ap.add_argument("--dense", action="store_true", help="extra line: grid tightened onto the small FOV (full overlap)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
