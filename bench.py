@@ -7,14 +7,19 @@ lon (200, 300) deg, lat (-20, 20) deg, lag_crval1 = lag_crval2 = arange(-30, 30,
 lag-points), crota/cdelt fixed, solar_r 1.004, order 2, method 'correlation'; seeded synthetic HRIEUV-like
 2048^2 image to align and FSI-like 3072^2 reference (euispice_coreg_amd/synthetic.py).
 
-A "step" = one full sweep (all 3600 lag-points) through the C ABI with both images already resident in HBM
-(upload + once-only reference preparation happen before the timed region).  `--streams` (default 2) steps are in
-flight at a time, each on its own HIP stream and library context, so that the drain of one sweep overlaps the start of
-the next; every step is a complete sweep.  N > 1 (torchrun, one rank per GPU):
-the (CRVAL1, CRVAL2) lag plane is cut in N blocks (the multi-GPU form of the reference's np.array_split fan-out,
-alignment.py:677-687), every rank sweeps its block with full image replicas and ONE all-gather (RCCL) of the per-lag
-coefficients, followed by an index permutation, assembles the map on every rank.  Total work is fixed as N grows
--> "scaling": "strong".
+A "step" = one full sweep (all 3600 lag-points) through the C ABI with both images already RESIDENT in HBM
+(upload + once-only reference preparation happen before the timed region; `config.resident` says so, and the
+PCIe-inclusive rate of the same step is printed beside it as `pcie_inclusive`, never as `value`).  `--streams`
+(default 2) steps are in flight at a time, each on its own HIP stream and library context, so that the drain of one
+sweep overlaps the start of the next; every step is a complete sweep, and the rate with ONE sweep in flight is printed
+as `one_sweep_in_flight`.
+
+N > 1: `python bench.py --gpus N` starts its own N rank processes (torch.distributed.run, one rank per GPU) as CHILDREN,
+before anything in this process has touched the GPU, and exits with their return code; launched under torchrun
+(WORLD_SIZE set) it is a rank.  The (CRVAL1, CRVAL2) lag plane is cut in N blocks (the multi-GPU form of the
+reference's np.array_split fan-out, alignment.py:677-687), every rank sweeps its block with full image replicas and
+ONE all-gather (RCCL) of the per-lag coefficients, followed by an index permutation, assembles the map on every rank.
+Total work is fixed as N grows -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` and `cpu_baseline` objects.
 """
@@ -23,8 +28,6 @@ import json
 import os
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -36,11 +39,17 @@ LATLIMS = (-20.0, 20.0)
 SOLAR_R = 1.004
 ORDER = 2
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md)
-FP64_VALU_PEAK_TF = 78.6  # MI355X vector FP64 spec
-FLOP_PER_POINT_LAG = 70.0  # ~70 fp64 flop per (grid point, lag)
+FP64_VALU_PEAK_TF = 78.6  # MI355X vector FP64 spec: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0  # wave-instructions/s: one VALU instruction per SIMD every 4 cycles
+LDS_CYCLES_PEAK = 256 * 2.4e9            # LDS-array cycles/s, all CUs
+# Counted float64 operations of k_sweep<TRANSLATE, 2> per (grid point, lag), interior-window path (kernels.hpp
+# point_lag): 2 add (coordinate) + 2 fract + 10 (doubled spline weights, 5 per axis) + 3 x (mul + 2 fma) rows
+# + (mul + 2 fma) column + sums (2 add + 3 fma) = 31 float64 instructions = 42 flop with fma = 2.  (The whole loop
+# body is ~38.7 VALU instructions: + 2 cvt, 1 class test, the integer count and address arithmetic.)
+FLOP_PER_POINT_LAG = 42.0
+F64_INSTR_PER_POINT_LAG = 31.0
 
-
-METRIC = "lag-points/sec (whole node) on 2048\u00b2 grid, 60\u00d760 CRVAL sweep; argmax-shift match"
+METRIC = "lag-points/sec (whole node) on 2048² grid, 60×60 CRVAL sweep; argmax-shift match"
 try:
     with open(os.path.join(ROOT, "BASELINE.json")) as _f:
         METRIC = json.load(_f).get("metric", METRIC)
@@ -48,27 +57,47 @@ except Exception:
     pass
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per k_sweep launch from the committed rocprofv3 PMC summary of this same command
-    (profiles/r01_pmc_summary.txt; FETCH_SIZE/WRITE_SIZE are KiB per dispatch, FETCH_SIZE doubled: gfx950 counts
-    128-B read requests as 64 B -- MI355X_MICROARCH.md, HBM section).  None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.txt")
-    try:
-        vals = {}
-        for line in open(path):
-            parts = line.split()
-            if len(parts) >= 4 and parts[0] in ("FETCH_SIZE", "WRITE_SIZE"):
-                vals[parts[0]] = float(parts[3])
-        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-    except Exception:
-        return None
-
-
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(small, hs, large, hl, lags, n_sample, cores):
+def self_launch(n, argv):
+    """--gpus N > 1 without a torchrun environment: start the N ranks as children and relay their result.  Runs before
+    torch / HIP are imported here (a process that has initialised the GPU must never exec or fork GPU workers)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("[bench] launching", n, "ranks:", " ".join(cmd))
+    # the children inherit stdout: rank 0 prints the ONE JSON line
+    return subprocess.run(cmd, env=env).returncode
+
+
+def pmc_summary():
+    """Counter means per k_sweep launch from the newest committed rocprofv3 PMC summary of this command
+    (profiles/rNN_pmc_summary.txt, written by profiles/run_pmc.sh).  {} when none is committed."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.txt")))
+    if not paths:
+        return {}, None
+    vals = {}
+    try:
+        for line in open(paths[-1]):
+            parts = line.split()
+            if len(parts) >= 4 and parts[1] == "mean/dispatch":
+                vals[parts[0]] = float(parts[3])
+    except Exception:
+        return {}, None
+    return vals, os.path.relpath(paths[-1], ROOT)
+
+
+def cpu_baseline(np, small, hs, large, hl, lags, n_sample, cores):
     """The oracle's restatement of the reference's parallelism=True path (process fan-out over np.array_split
     chunks, images in shared memory), timed on a seeded random subsample of the same 3600 lag-points."""
     from oracle import coreg_oracle as O
@@ -93,8 +122,8 @@ def cpu_baseline(small, hs, large, hl, lags, n_sample, cores):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300)   # ~3.6 ms each: a timed region above one second
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="sweeps in flight (one HIP stream + library context each)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement after the timed region")
@@ -102,12 +131,13 @@ def main():
     ap.add_argument("--use-lds", type=int, default=1)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
     # native libraries (RCCL prints a version banner on first use) write to fd 1: keep stdout for the ONE JSON line
@@ -115,15 +145,25 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    import numpy as np
     import torch
     import torch.distributed as dist
-    from euispice_coreg_amd import _lib, synthetic
+    from euispice_coreg_amd import parallel
 
     # COREG_BENCH_BACKEND=gloo: rehearse the N > 1 path on a box with fewer GPUs than ranks (ranks share devices,
     # the all-gather runs on the CPU); the driver's runs use the default, nccl (= RCCL over xGMI)
     backend = os.environ.get("COREG_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
+    # COREG_BENCH_DRY=1 (tests of the launcher on a box without a GPU): every GPU call is left out -- each rank fills
+    # its block with the raveled lag indices instead of sweeping -- so that process start-up, the process group, the
+    # collective, the block permutation and the JSON line can be checked.  The line says "dry_run": true, value null.
+    dry = os.environ.get("COREG_BENCH_DRY", "0") == "1"
+    if dry and backend == "nccl":
+        raise SystemExit("COREG_BENCH_DRY=1 needs COREG_BENCH_BACKEND=gloo")
+    dev = "cpu" if dry else "cuda"
+    if not dry:
+        from euispice_coreg_amd import _lib, synthetic
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
     # COREG_BENCH_FORCE_DIST=1: initialise the process group (and run the all-gather) even with one rank, to exercise
     # the RCCL code path on a one-GPU box
     use_dist = world > 1 or os.environ.get("COREG_BENCH_FORCE_DIST", "0") == "1"
@@ -136,54 +176,73 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+    n_ranks_seen = dist.get_world_size() if use_dist else 1
 
-    t0 = time.time()
-    small, hs, large, hl, truth = synthetic.make_scene()
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     lag1 = np.arange(-30, 30, 1, dtype=np.float64)
     lag2 = np.arange(-30, 30, 1, dtype=np.float64)
     lags = (lag1, lag2, None, None, None)
     L = lag1.size * lag2.size
-    if rank == 0:
-        log(f"[bench] scene built in {time.time() - t0:.1f} s; L = {L}")
-
-    # `--streams S` (default 2) sweeps are in flight at a time, each on its own HIP stream with its own library context:
-    # the tail of one sweep (workgroups draining, the small finalize / next precompute kernels) overlaps the head of
-    # the next.  Every step is still one complete sweep of all lag-points of this rank.
-    n_streams = max(1, args.streams)
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_streams - 1)]
-    grid = _lib.Grid(LONLIMS, LATLIMS, GRID_SHAPE, numpy_lat_trig=True)
-    lagset = _lib.LagSet(*lags)
-    small_m = small.copy()
-    handles = []
-    for s in streams:
-        hk = _lib.CoregHandle(local_rank)
-        hk.set_option("use_lds", args.use_lds)
-        for kv in filter(None, os.environ.get("COREG_BENCH_OPTS", "").split(",")):  # tuning: "opt=val,opt=val"
-            k, v = kv.split("=")
-            hk.set_option(k, int(v))
-        hk.set_stream(s.cuda_stream)
-        # inputs resident in HBM before the timed region
-        hk.set_small(small_m)
-        hk.prepare_reference_carrington(large, hl, grid, SOLAR_R, ORDER)
-        handles.append(hk)
-    h = handles[0]
-
-    from euispice_coreg_amd import parallel
     lo1, hi1, lo2, hi2 = parallel.block_bounds(lag1.size, lag2.size, world, rank)
-    my_lags = _lib.LagSet(lag1[lo1:hi1], lag2[lo2:hi2], None, None, None) if (hi1 > lo1 and hi2 > lo2) else None
+    have_lags = hi1 > lo1 and hi2 > lo2
     perm_np, chunk = parallel.block_gather_index((lag1.size, lag2.size, 1, 1, 1), world)
-    mine = [torch.full((chunk,), float("nan"), dtype=torch.float64, device="cuda") for _ in streams]
-    gathered = [torch.empty((chunk * world,), dtype=torch.float64, device="cuda") if use_dist else m for m in mine]
-    perm = torch.from_numpy(perm_np).to("cuda")
-    torch.cuda.synchronize()
+    n_streams = max(1, args.streams)
+
+    if dry:
+        streams, handles, h = [None] * n_streams, [], None
+        truth = {"lag_crval1": 17.0, "lag_crval2": -9.0}
+        block = (np.arange(lo1, hi1)[:, None] * lag2.size + np.arange(lo2, hi2)[None, :]).astype(np.float64).ravel()
+    else:
+        t0 = time.time()
+        small, hs, large, hl, truth = synthetic.make_scene()
+        if rank == 0:
+            log(f"[bench] scene built in {time.time() - t0:.1f} s; L = {L}")
+        # `--streams S` sweeps are in flight at a time, each on its own HIP stream with its own library context: the
+        # tail of one sweep (workgroups draining, the small finalize / next precompute kernels) overlaps the head of
+        # the next.  Every step is still one complete sweep of all lag-points of this rank.
+        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_streams - 1)]
+        grid = _lib.Grid(LONLIMS, LATLIMS, GRID_SHAPE, numpy_lat_trig=True)
+        small_m = small.copy()
+        handles = []
+        for s in streams:
+            hk = _lib.CoregHandle(local_rank)
+            hk.set_option("use_lds", args.use_lds)
+            for kv in filter(None, os.environ.get("COREG_BENCH_OPTS", "").split(",")):  # tuning: "opt=val,opt=val"
+                k, v = kv.split("=")
+                hk.set_option(k, int(v))
+            hk.set_stream(s.cuda_stream)
+            # inputs resident in HBM before the timed region
+            hk.set_small(small_m)
+            hk.prepare_reference_carrington(large, hl, grid, SOLAR_R, ORDER)
+            handles.append(hk)
+        h = handles[0]
+        my_lags = _lib.LagSet(lag1[lo1:hi1], lag2[lo2:hi2], None, None, None) if have_lags else None
+
+    mine = [torch.full((chunk,), float("nan"), dtype=torch.float64, device=dev) for _ in range(n_streams)]
+    gathered = [torch.empty((chunk * world,), dtype=torch.float64, device=dev) if use_dist else m for m in mine]
+    perm = torch.from_numpy(perm_np).to(dev)
+    sync()
     result = [None]
     step_no = [0]
 
-    def step():
-        k = step_no[0] % n_streams
+    def step(n_in_flight=n_streams):
+        k = step_no[0] % n_in_flight
         step_no[0] += 1
+        if dry:
+            if have_lags:
+                mine[k][:block.size] = torch.from_numpy(block)
+            if use_dist:
+                parts = [torch.empty(chunk, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(parts, mine[k])
+                result[0] = torch.cat(parts)[perm]
+            else:
+                result[0] = mine[k][perm]
+            return
         with torch.cuda.stream(streams[k]):
-            if my_lags is not None:
+            if have_lags:
                 handles[k].sweep_carrington(hs, grid, SOLAR_R, my_lags, order=ORDER, out_dev_ptr=mine[k].data_ptr())
             if use_dist:
                 if backend == "nccl":
@@ -196,104 +255,148 @@ def main():
             else:
                 result[0] = mine[k][perm]
 
+    def timed(n_steps, n_in_flight):
+        """EXACTLY n_steps steps between barrier + synchronize on both sides; max over ranks.  Seconds."""
+        step_no[0] = 0
+        if use_dist:
+            dist.barrier()
+        sync()
+        t_start = time.perf_counter()
+        for _ in range(n_steps):
+            step(n_in_flight)  # asynchronous: the host plans step k+1 while the GPU runs step k; nothing is read back
+        if use_dist:
+            dist.barrier()
+        sync()
+        el = time.perf_counter() - t_start
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     for _ in range(args.warmup):
         step()
-    kernel_ms, pre_ms = [], []
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()  # asynchronous: the host plans step k+1 while the GPU runs step k; nothing is read back in here
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(args.steps, n_streams)
+    # the same steps with ONE sweep in flight (stream 0 only), for the record
+    one_in_flight = None
+    if n_streams > 1 and not dry:
+        n1 = max(1, min(args.steps, 100))
+        one_in_flight = timed(n1, 1) / n1
+
     # dominant-kernel duration: the library brackets every k_sweep launch with HIP events on the launch stream.  Reading
     # them waits for the sweep, and with several sweeps in flight a kernel's event interval also contains the time its
     # workgroups waited for the other sweep's to leave the CUs -- so the kernel is timed here, right after the timed
     # region, on identical steps issued ONE at a time
     stats = {"sweep_kernel_ms": 0.0, "precompute_ms": 0.0, "n_active_points": 0, "small_is_f32": 1, "used_lds": 1}
-    for _ in range(min(8, args.steps)):
-        step_no[0] = 0  # handle / stream 0
-        step()
-        if my_lags is not None:
-            stats = h.last_stats()
-            kernel_ms.append(stats["sweep_kernel_ms"])
-            pre_ms.append(stats["precompute_ms"])
-        else:
-            torch.cuda.synchronize()
+    kernel_ms, pre_ms = [], []
+    if not dry:
+        for _ in range(min(16, args.steps)):
+            step_no[0] = 0  # handle / stream 0
+            step(1)
+            if have_lags:
+                stats = h.last_stats()
+                kernel_ms.append(stats["sweep_kernel_ms"])
+                pre_ms.append(stats["precompute_ms"])
+            else:
+                torch.cuda.synchronize()
     if not kernel_ms:
         kernel_ms, pre_ms = [0.0], [0.0]
+    k_ms = float(np.mean(kernel_ms))
+    per_rank = [{"rank": rank, "kernel_ms": k_ms, "lags": (hi1 - lo1) * (hi2 - lo2) if have_lags else 0,
+                 "active_points": int(stats["n_active_points"])}]
     if use_dist:
         dist.barrier()
-    corr = result[0].cpu().numpy()
-    corr = corr.reshape(lag1.size, lag2.size)
+        gathered_stats = [None] * world
+        dist.all_gather_object(gathered_stats, per_rank[0])
+        per_rank = gathered_stats
+    corr = result[0].cpu().numpy().reshape(lag1.size, lag2.size)
 
     # the boundary hands over host buffers: the same step with both images uploaded (and the reference re-prepared) and
     # the map copied back to the host every call -- reported beside `value`, never as `value`
     pcie = None
-    if world == 1 and not args.no_pcie:
+    if world == 1 and not args.no_pcie and not dry:
         full_lags = _lib.LagSet(*lags)
+        small32, large32 = small_m.astype(np.float32), large.astype(np.float32)  # what a BITPIX=-32 FITS file holds
         times = []
-        for _ in range(4):
+        for _ in range(5):
             t0 = time.perf_counter()
-            h.set_small(small_m)
-            h.prepare_reference_carrington(large, hl, grid, SOLAR_R, ORDER)
-            h.sweep_carrington(hs, grid, SOLAR_R, full_lags, order=ORDER)
+            h.set_small(small32)
+            h.prepare_reference_carrington(large32, hl, grid, SOLAR_R, ORDER)
+            out_host = h.sweep_carrington(hs, grid, SOLAR_R, full_lags, order=ORDER)
             times.append(time.perf_counter() - t0)
         best = min(times[1:])
         pcie = {"value": L / best, "unit": "lag-points/s", "ms_per_step": 1e3 * best,
-                "what": "host float64 images in (2048^2 image to align + 3072^2 reference, 104 MiB, reference "
-                        "re-prepared), host correlation map out, every call"}
+                "identical_to_resident_map": bool(np.array_equal(out_host.reshape(corr.shape), corr, equal_nan=True)),
+                "what": "SURVEY 8d wall time of one call: host float32 images in (2048^2 image to align + 3072^2 "
+                        "reference = 52 MiB, the pixels a BITPIX=-32 FITS file holds; reference re-prepared), sweep, "
+                        "host correlation map out; best of 4 after one warm-up"}
 
     if rank == 0:
-        value = L * args.steps / elapsed
         ms_per_step = 1e3 * elapsed / args.steps
         G = GRID_SHAPE[0] * GRID_SHAPE[1]
-        S = small.shape[0] * small.shape[1]
+        S = 2048 * 2048
         b_lag = G * 8 + S * 8  # SURVEY.md 8d: reference grid value + small-image pixel, fp64, touched once per lag
-        k_ms = float(np.mean(kernel_ms))
         lags_per_launch = (hi1 - lo1) * (hi2 - lo2)
-        achieved = b_lag * lags_per_launch / (k_ms * 1e-3) / 1e9
-        act = stats["n_active_points"]
-        valu_tf = act * lags_per_launch * FLOP_PER_POINT_LAG / (k_ms * 1e-3) / 1e12
+        act = int(stats["n_active_points"])
+        k_s = max(k_ms, 1e-9) * 1e-3
+        flops = act * lags_per_launch * FLOP_PER_POINT_LAG
+        achieved_tf = flops / k_s / 1e12
+        pmc, pmc_path = pmc_summary()
+        roof = {
+            # the binding resources are float64 VALU issue and the LDS gather, co-limited (DESIGN.md section 4)
+            "bound": "valu_fp64+lds", "achieved": achieved_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+            "frac": achieved_tf / FP64_VALU_PEAK_TF,
+            "kernel": "k_sweep<TRANSLATE,2,f32>", "kernel_ms": k_ms, "lags_per_launch": lags_per_launch,
+            "active_points": act, "flop_per_point_lag": FLOP_PER_POINT_LAG,
+            "f64_instr_per_point_lag": F64_INSTR_PER_POINT_LAG,
+            "traffic": None, "hbm_model": {
+                "algorithmic_bytes_per_lag": b_lag, "algorithmic_bytes_per_launch": b_lag * lags_per_launch,
+                "achieved_gbs": b_lag * lags_per_launch / k_s / 1e9, "peak_gbs": HBM_PEAK_GBS,
+                "hbm_model_frac": b_lag * lags_per_launch / k_s / 1e9 / HBM_PEAK_GBS,
+                "note": "SURVEY 8d one-lag-per-pass byte model; the kernel shares every staged byte between 256 lags "
+                        "and culls grid points outside the small FOV, so this fraction exceeds 1 and HBM is not the "
+                        "bound (see traffic)"},
+            "note": "achieved = counted float64 flop of the interior gather path x active points x lags / kernel_ms "
+                    "(HIP events around single, non-overlapped launches right after the timed region)"}
+        if pmc and world == 1:
+            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                # KiB per dispatch; FETCH_SIZE doubled: gfx950 counts 128-B read requests as 64 B (MI355X_MICROARCH.md)
+                roof["traffic"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+                roof["traffic_unit"] = "HBM bytes per launch"
+            if "SQ_INSTS_VALU" in pmc:
+                roof["valu_issue_frac"] = pmc["SQ_INSTS_VALU"] / k_s / VALU_ISSUE_PEAK
+            if "SQ_LDS_IDX_ACTIVE" in pmc:
+                roof["lds_busy_frac"] = pmc["SQ_LDS_IDX_ACTIVE"] / k_s / LDS_CYCLES_PEAK
+                if "SQ_LDS_BANK_CONFLICT" in pmc:
+                    roof["lds_conflict_cycle_frac"] = pmc["SQ_LDS_BANK_CONFLICT"] / pmc["SQ_LDS_IDX_ACTIVE"]
+            roof["pmc_source"] = f"{pmc_path} (rocprofv3 --pmc means per launch of this command, committed)"
         am = np.unravel_index(np.nanargmax(corr), corr.shape)
         out = {
             "metric": METRIC,
-            "value": value, "unit": "lag-points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": None if dry else L * args.steps / elapsed, "unit": "lag-points/s", "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "headline: Carrington 'fa' 2048x2048 grid lon(200,300) lat(-20,20), 60x60 CRVAL "
                                    "lags arange(-30,30,1) arcsec, small 2048^2 HRIEUV-like, ref 3072^2 FSI-like, "
                                    "order 2, solar_r 1.004",
-                       "lag_points": L, "grid": list(GRID_SHAPE), "parallelism": f"lag-plane blocks x{world} + 1 all-gather",
-                       "sweeps_in_flight": n_streams,
+                       "lag_points": L, "grid": list(GRID_SHAPE),
+                       "parallelism": f"lag-plane blocks x{world} + 1 all-gather ({backend})",
+                       "resident": True, "sweeps_in_flight": n_streams,
                        "small_stored_f32": bool(stats["small_is_f32"]), "use_lds": bool(stats["used_lds"])},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.txt)",
-                         "algorithmic_bytes_per_launch": b_lag * lags_per_launch,
-                         "kernel": "k_sweep<TRANSLATE,2,f32>", "kernel_ms": k_ms,
-                         "timed_region_ms_per_launch": ms_per_step,  # wall per sweep with `sweeps_in_flight` overlapped
-                         "algorithmic_bytes_per_lag": b_lag, "lags_per_launch": lags_per_launch,
-                         "note": "algorithmic bytes = one-lag-per-pass model (SURVEY 8d); the kernel batches 256 lags "
-                                 "per workgroup and culls grid points outside the small FOV, so frac can exceed 1; "
-                                 "the binding resource is fp64 VALU (see valu_fp64); kernel_ms = HIP events around single, "
-                                 "non-overlapped launches right after the timed region"},
-            "valu_fp64": {"achieved": valu_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                          "frac": valu_tf / FP64_VALU_PEAK_TF, "active_points": int(act),
-                          "flop_per_point_lag": FLOP_PER_POINT_LAG},
+            "one_sweep_in_flight": None if one_in_flight is None else
+            {"value": L / one_in_flight, "unit": "lag-points/s", "ms_per_step": 1e3 * one_in_flight},
+            "roofline": roof,
+            "per_rank": per_rank,
             "precompute_ms": float(np.mean(pre_ms)),
             "pcie_inclusive": pcie,
             "argmax_lag_arcsec": [float(lag1[am[0]]), float(lag2[am[1]])],
             "injected_shift_arcsec": [truth["lag_crval1"], truth["lag_crval2"]],
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
+        if dry:
+            out["dry_run"] = True
+            out["dry_run_map_ok"] = bool(np.array_equal(corr.ravel(), np.arange(L, dtype=np.float64)))
+        if not args.no_cpu_baseline and world == 1 and not dry:  # the CPU leg is timed at N = 1 only
             # the GPU box gives one GPU's job a 16-core share whatever os.cpu_count() says
             try:
                 avail = len(os.sched_getaffinity(0))
@@ -302,7 +405,7 @@ def main():
             cores = int(os.environ.get("COREG_CPU_CORES", min(avail, 16)))
             n_sample = args.cpu_sample or 48 * cores
             log(f"[bench] CPU baseline: {n_sample} lag-points on {cores} cores ...")
-            cb, corr_cpu, subset = cpu_baseline(small, hs, large, hl, lags, n_sample, cores)
+            cb, corr_cpu, subset = cpu_baseline(np, small, hs, large, hl, lags, n_sample, cores)
             out["cpu_baseline"] = cb
             d = np.abs(corr.ravel()[subset] - corr_cpu.ravel()[subset])
             out["parity_vs_cpu_sample"] = {"max_abs_dcorr": float(np.nanmax(d)), "n": int(len(subset)),

@@ -77,6 +77,9 @@ SYMBOLS = [
     ("coreg_prepare_reference_carrington", C.c_int,
      [_P, _P, C.c_int32, C.c_int32, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
     ("coreg_prepare_reference_helioprojective", C.c_int, [_P, _P, C.c_int32, C.c_int32, _WP, _WP, C.c_int]),
+    ("coreg_prepare_reference_carrington_f32", C.c_int,
+     [_P, _P, C.c_int32, C.c_int32, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
+    ("coreg_prepare_reference_helioprojective_f32", C.c_int, [_P, _P, C.c_int32, C.c_int32, _WP, _WP, C.c_int]),
     ("coreg_get_reference_on_grid", C.c_int, [_P, _P, C.c_int]),
     ("coreg_resample_carrington", C.c_int, [_P, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int, _P]),
     ("coreg_resample_helioprojective", C.c_int, [_P, _WP, _WP, C.c_int, _P]),
@@ -273,21 +276,31 @@ class CoregHandle:
         self.reference_tag = None
         self._chk(self._lib.coreg_set_reference_on_grid(self._h, ref.ctypes.data, dt, ref.shape[0], ref.shape[1]))
 
+    @staticmethod
+    def _reference_pixels(large):
+        """float32 arrays (FITS BITPIX=-32 pixels) go up as they are, anything else as float64."""
+        large = np.asarray(large)
+        if large.ndim != 2:
+            raise ValueError("reference image must be 2-D")
+        if large.dtype == np.float32:
+            return np.ascontiguousarray(large), True
+        return np.ascontiguousarray(large, dtype=np.float64), False
+
     def prepare_reference_carrington(self, large, hdr_large, grid: Grid, solar_r, order=2):
-        large = np.ascontiguousarray(large, dtype=np.float64)
+        large, f32 = self._reference_pixels(large)
         w = wcs_from_header(hdr_large, carrington=True)
         self.reference_tag = None
-        self._chk(self._lib.coreg_prepare_reference_carrington(self._h, large.ctypes.data, large.shape[0],
-                                                               large.shape[1], C.byref(w), C.byref(grid.c),
-                                                               float(solar_r), int(order)))
+        fn = self._lib.coreg_prepare_reference_carrington_f32 if f32 else self._lib.coreg_prepare_reference_carrington
+        self._chk(fn(self._h, large.ctypes.data, large.shape[0], large.shape[1], C.byref(w), C.byref(grid.c),
+                     float(solar_r), int(order)))
 
     def prepare_reference_helioprojective(self, large, hdr_large, hdr_small, order=2):
-        large = np.ascontiguousarray(large, dtype=np.float64)
+        large, f32 = self._reference_pixels(large)
         wl, ws = wcs_from_header(hdr_large), wcs_from_header(hdr_small)
         self.reference_tag = None
-        self._chk(self._lib.coreg_prepare_reference_helioprojective(self._h, large.ctypes.data, large.shape[0],
-                                                                    large.shape[1], C.byref(wl), C.byref(ws),
-                                                                    int(order)))
+        fn = self._lib.coreg_prepare_reference_helioprojective_f32 if f32 else \
+            self._lib.coreg_prepare_reference_helioprojective
+        self._chk(fn(self._h, large.ctypes.data, large.shape[0], large.shape[1], C.byref(wl), C.byref(ws), int(order)))
 
     def get_reference_on_grid(self, shape, dtype):
         out = np.empty(shape, dtype=dtype)

@@ -101,7 +101,9 @@ struct coreg_handle {
     DevBuf t_sin_lon, t_cos_lon, t_cos_lat, t_sin_lat;
     CarrTables tabs;
     std::vector<double> tabs_key;
-    PinBuf pin_params, pin_outidx, pin_img;
+    PinBuf pin_params, pin_outidx, pin_img[2];
+    hipEvent_t ev_img[2] = {nullptr, nullptr};
+    int pin_img_next = 0;
     // precompute outputs
     DevBuf pts, tile_count, tile_list, tile_cum, group_first, tile_info, tile_bbox;
     // sweep
@@ -109,7 +111,7 @@ struct coreg_handle {
     DevBuf up_f64, up_flag;  // upload staging on the device (float64 copy, exactness flag)
 
     // options
-    int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1;
+    int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1;
 
     coreg_stats stats;
     bool stats_pending = false;   // a device-output sweep is in flight: timings are collected on demand
@@ -188,14 +190,21 @@ void parallel_memcpy(void* dst, const void* src, size_t bytes) {
 }
 
 int staged_upload(coreg_handle* h, void* dev, const void* host, size_t bytes) {
-    HIPCHK(hipStreamSynchronize(h->stream));  // an earlier upload may still be reading the staging buffer
-    HIPCHK(h->pin_img.reserve(bytes));
-    const size_t seg = (size_t)16 << 20;
+    // two staging buffers used alternately, each guarded by an event recorded behind its last copy: filling the
+    // buffer for this upload overlaps the DMA (and whatever else the stream is doing) of the previous one
+    const int k = h->pin_img_next;
+    h->pin_img_next ^= 1;
+    if (!h->ev_img[k]) HIPCHK(hipEventCreateWithFlags(&h->ev_img[k], hipEventDisableTiming));
+    else HIPCHK(hipEventSynchronize(h->ev_img[k]));  // the upload that last used this buffer has left it
+    HIPCHK(h->pin_img[k].reserve(bytes));
+    char* pin = (char*)h->pin_img[k].p;
+    const size_t seg = (size_t)8 << 20;
     for (size_t off = 0; off < bytes; off += seg) {
         const size_t len = std::min(seg, bytes - off);
-        parallel_memcpy((char*)h->pin_img.p + off, (const char*)host + off, len);
-        HIPCHK(hipMemcpyAsync((char*)dev + off, (char*)h->pin_img.p + off, len, hipMemcpyHostToDevice, h->stream));
+        parallel_memcpy(pin + off, (const char*)host + off, len);
+        HIPCHK(hipMemcpyAsync((char*)dev + off, pin + off, len, hipMemcpyHostToDevice, h->stream));
     }
+    HIPCHK(hipEventRecord(h->ev_img[k], h->stream));
     return COREG_OK;
 }
 
@@ -395,6 +404,33 @@ Plan choose_plan(coreg_handle* h, const Geometry& g, int m1, int n2, long long l
         }
     }
     return best_cost < std::numeric_limits<double>::max() ? best : fallback;
+}
+
+// indices of the smallest, the most central and the largest value of a lag axis (any order, NaNs ignored)
+void extreme_lags(const double* v, int n, int out[3]) {
+    int lo = 0, hi = 0;
+    for (int i = 1; i < n; ++i) {
+        if (v[i] < v[lo] || v[lo] != v[lo]) lo = i;
+        if (v[i] > v[hi] || v[hi] != v[hi]) hi = i;
+    }
+    const double mid = 0.5 * (v[lo] + v[hi]);
+    int m = lo;
+    for (int i = 0; i < n; ++i)
+        if (std::fabs(v[i] - mid) < std::fabs(v[m] - mid)) m = i;
+    out[0] = lo;
+    out[1] = m;
+    out[2] = hi;
+}
+
+// mean spacing of a lag axis over its value range (plan heuristics only; lists may come in any order)
+double lag_step(const double* v, int n) {
+    if (n < 2) return 0.0;
+    double lo = v[0], hi = v[0];
+    for (int i = 1; i < n; ++i) {
+        lo = std::min(lo, v[i]);
+        hi = std::max(hi, v[i]);
+    }
+    return (hi - lo) / (double)(n - 1);
 }
 
 struct SlotList {
@@ -747,7 +783,10 @@ void coreg_destroy(coreg_handle* h) {
     for (DevBuf* b : bufs) b->release();
     h->pin_params.release();
     h->pin_outidx.release();
-    h->pin_img.release();
+    for (int k = 0; k < 2; ++k) {
+        h->pin_img[k].release();
+        if (h->ev_img[k]) (void)hipEventDestroy(h->ev_img[k]);
+    }
     for (auto& e : h->ev_sweep) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -798,6 +837,8 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         h->opt_n_groups = value;
     } else if (n == "skew") {
         (void)value;  // accepted for compatibility: the LDS row skew was measured to lose and is gone
+    } else if (n == "tile_skip") {
+        h->opt_tile_skip = value ? 1 : 0;  // 0: k_precompute evaluates every grid point (tests compare both)
     } else if (n == "h_series") {
         h->opt_h_series = value ? 1 : 0;
     } else if (n == "patch_w") {
@@ -894,14 +935,24 @@ int coreg_set_reference_on_grid(coreg_handle* h, const void* ref, int dtype, int
     return ref_pivot(h);
 }
 
-int coreg_prepare_reference_carrington(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
-                                       const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r, int order) {
+// the reference image's pixels: float64 from the caller (tested for float32-exactness on the GPU), or the float32
+// pixels a BITPIX=-32 FITS file holds (half the PCIe bytes; the reference's float64 cast of them is exact)
+static int upload_reference_source(coreg_handle* h, const void* large, size_t n, bool src_f32, bool* f32) {
+    if (!src_f32) return upload_image(h, (const double*)large, n, h->tmp_img, f32);
+    HIPCHK(h->tmp_img.reserve(n * sizeof(float)));
+    RETCHK(staged_upload(h, h->tmp_img.p, large, n * sizeof(float)));
+    *f32 = true;
+    return COREG_OK;
+}
+
+static int prepare_carrington(coreg_handle* h, const void* large, bool src_f32, int32_t ny, int32_t nx,
+                              const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r, int order) {
     if (!h) return COREG_EINVAL;
     if (!large || !hdr || !grid || ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
     RETCHK(check_order(h, order));
     RETCHK(bind_device(h));
     bool f32;
-    RETCHK(upload_image(h, large, (size_t)ny * nx, h->tmp_img, &f32));
+    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, src_f32, &f32));
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
     RETCHK(upload_carr_tables(h, *grid, *hdr, &a.carr));
@@ -919,12 +970,23 @@ int coreg_prepare_reference_carrington(coreg_handle* h, const double* large, int
     h->gH = a.gh;
     h->ref_dtype = COREG_F64;
     RETCHK(ref_pivot(h));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    // no host sync: the pinned staging is guarded by staged_upload's own wait, everything else is stream-ordered
     return COREG_OK;  // tmp_img stays allocated: the next preparation re-uses it (hipFree would stall the device)
 }
 
-int coreg_prepare_reference_helioprojective(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
-                                            const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order) {
+int coreg_prepare_reference_carrington(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
+                                       const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r, int order) {
+    return prepare_carrington(h, large, false, ny, nx, hdr, grid, solar_r, order);
+}
+
+int coreg_prepare_reference_carrington_f32(coreg_handle* h, const float* large, int32_t ny, int32_t nx,
+                                           const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r,
+                                           int order) {
+    return prepare_carrington(h, large, true, ny, nx, hdr, grid, solar_r, order);
+}
+
+static int prepare_helioprojective(coreg_handle* h, const void* large, bool src_f32, int32_t ny, int32_t nx,
+                                   const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order) {
     if (!h) return COREG_EINVAL;
     if (!large || !hdr_large || !hdr_small || ny < 1 || nx < 1)
         return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
@@ -934,7 +996,7 @@ int coreg_prepare_reference_helioprojective(coreg_handle* h, const double* large
     RETCHK(check_order(h, order));
     RETCHK(bind_device(h));
     bool f32;
-    RETCHK(upload_image(h, large, (size_t)ny * nx, h->tmp_img, &f32));
+    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, src_f32, &f32));
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
     homography(*hdr_small, *hdr_large, a.hom.h);  // alignment.py:993: pixels of hdr_cut -> pixels of hdr_large
@@ -950,8 +1012,18 @@ int coreg_prepare_reference_helioprojective(coreg_handle* h, const double* large
     h->gH = a.gh;
     h->ref_dtype = COREG_F32;
     RETCHK(ref_pivot(h));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return COREG_OK;  // tmp_img stays allocated: the next preparation re-uses it (hipFree would stall the device)
+    return COREG_OK;
+}
+
+int coreg_prepare_reference_helioprojective(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
+                                            const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order) {
+    return prepare_helioprojective(h, large, false, ny, nx, hdr_large, hdr_small, order);
+}
+
+int coreg_prepare_reference_helioprojective_f32(coreg_handle* h, const float* large, int32_t ny, int32_t nx,
+                                                const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small,
+                                                int order) {
+    return prepare_helioprojective(h, large, true, ny, nx, hdr_large, hdr_small, order);
 }
 
 int coreg_get_reference_on_grid(coreg_handle* h, void* out, int dtype) {
@@ -1064,8 +1136,7 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
         geo.dx_dj = c0x - a0;
         geo.dy_dj = c0y - a1;
         // utils/rectify.py:399-404: X0 = -(c d1 + s d2)/cdelt1, Y0 = -(-s d1 + c d2)/cdelt2
-        const double s1 = d.n1 > 1 ? lags->crval1[1] - lags->crval1[0] : 0.0;
-        const double s2 = d.n2 > 1 ? lags->crval2[1] - lags->crval2[0] : 0.0;
+        const double s1 = lag_step(lags->crval1, d.n1), s2 = lag_step(lags->crval2, d.n2);
         geo.ax = c0.cr * s1 / hdr_small->cdelt1;
         geo.ay = c0.sr * s1 / hdr_small->cdelt2;
         geo.bx = c0.sr * s2 / hdr_small->cdelt1;
@@ -1159,6 +1230,17 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
         pa.f0hi = L.f0hi;
         pa.f1lo = L.f1lo;
         pa.f1hi = L.f1hi;
+        {
+            // whole-tile skip bound (k_precompute): pixels per radian of grid-point motion, grid steps in radians
+            const double dm1 = L.cc.dist - 1.0;
+            pa.tile_skip = (h->opt_tile_skip && dm1 > 0.0) ? 1 : 0;
+            const double per_rad = pa.tile_skip ? (1.0 / dm1 + 1.0 / (dm1 * dm1)) * kRad2Deg * 3600.0 : 0.0;
+            pa.lip_x = per_rad / std::fabs(L.cc.cdelt1) * (1.0 + 1e-9);
+            pa.lip_y = per_rad / std::fabs(L.cc.cdelt2) * (1.0 + 1e-9);
+            // float32 linspace grid: the spacing is uniform to ~1e-7 relative of the coordinate
+            pa.dlon = grid->n_lon > 1 ? (std::fabs(grid->lon1 - grid->lon0) / (grid->n_lon - 1) * 1.001 + 1e-4) * kDeg2Rad : 0.0;
+            pa.dlat = grid->n_lat > 1 ? (std::fabs(grid->lat1 - grid->lat0) / (grid->n_lat - 1) * 1.001 + 1e-4) * kDeg2Rad : 0.0;
+        }
         RETCHK(launch_precompute<MODE_TRANSLATE>(h, pa, n_tiles, pick_groups(h, L.n_batches, n_tiles)));
         // SoA block of this launch starts at 2 * slot_off doubles (every earlier launch contributed 2 per slot)
         RETCHK(launch_sweep(h, MODE_TRANSLATE, order, method, h->lane_params.as<double>() + 2 * L.slot_off,
@@ -1179,20 +1261,26 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
     Mat3 r_target;
     if (car_native_to_celestial(*hdr_target, &r_target))
         return fail(h, COREG_EINVAL, "hdr_target: no valid native pole for this CRVAL2 / LONPOLE (CAR)");
-    auto shifted = [&](const coreg_wcs2d& base, int i1, int i2) {
+    auto shifted_by = [&](const coreg_wcs2d& base, double v1, double v2) {
         coreg_wcs2d hl = base;
-        hl.crval1 = hdr_small->crval1 + lags->crval1[i1];  // alignment.py:404
-        hl.crval2 = hdr_small->crval2 + lags->crval2[i2];  // alignment.py:412
+        hl.crval1 = hdr_small->crval1 + v1;  // alignment.py:404
+        hl.crval2 = hdr_small->crval2 + v2;  // alignment.py:412
         return hl;
     };
-    // ---- plan: local geometry from the maps of the central lag and of its two neighbours
+    auto shifted = [&](const coreg_wcs2d& base, int i1, int i2) {
+        return shifted_by(base, lags->crval1[i1], lags->crval2[i2]);
+    };
+    // ---- plan: local geometry from the maps of a central lag and of that lag plus one mean step on either axis
     Geometry geo;
     {
-        const int c1 = d.n1 / 2, c2 = d.n2 / 2;
+        int e1[3], e2[3];
+        extreme_lags(lags->crval1, d.n1, e1);
+        extreme_lags(lags->crval2, d.n2, e2);
+        const double v1 = lags->crval1[e1[1]], v2 = lags->crval2[e2[1]];
         CarMapHost m0, m1h, m2h;
-        if (m0.init(*hdr_target, shifted(*hdr_small, c1, c2)) ||
-            m1h.init(*hdr_target, shifted(*hdr_small, std::min(c1 + 1, d.n1 - 1), c2)) ||
-            m2h.init(*hdr_target, shifted(*hdr_small, c1, std::min(c2 + 1, d.n2 - 1)))) {
+        if (m0.init(*hdr_target, shifted_by(*hdr_small, v1, v2)) ||
+            m1h.init(*hdr_target, shifted_by(*hdr_small, v1 + lag_step(lags->crval1, d.n1), v2)) ||
+            m2h.init(*hdr_target, shifted_by(*hdr_small, v1, v2 + lag_step(lags->crval2, d.n2)))) {
             geo.dx_di = geo.dy_dj = 1.0;  // central lag invalid: any plan will do, its lanes are NaN
             geo.dy_di = geo.dx_dj = geo.ax = geo.ay = geo.bx = geo.by = 0.0;
         } else {
@@ -1325,17 +1413,20 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     // ---- plan: local geometry from the maps of the central lag and of its two neighbours
     Geometry geo;
     {
-        auto map_of = [&](int i1, int i2, double hm[9]) {
+        auto map_of = [&](double v1, double v2, double hm[9]) {
             coreg_wcs2d hl = *hdr_small;
-            hl.crval1 = hdr_small->crval1 + lags->crval1[i1];
-            hl.crval2 = hdr_small->crval2 + lags->crval2[i2];
+            hl.crval1 = hdr_small->crval1 + v1;
+            hl.crval2 = hdr_small->crval2 + v2;
             homography(*hdr_target, hl, hm);
         };
-        const int c1 = d.n1 / 2, c2 = d.n2 / 2;
+        int e1[3], e2[3];
+        extreme_lags(lags->crval1, d.n1, e1);
+        extreme_lags(lags->crval2, d.n2, e2);
+        const double v1 = lags->crval1[e1[1]], v2 = lags->crval2[e2[1]];
         double m0[9], m1h[9], m2h[9];
-        map_of(c1, c2, m0);
-        map_of(std::min(c1 + 1, d.n1 - 1), c2, m1h);
-        map_of(c1, std::min(c2 + 1, d.n2 - 1), m2h);
+        map_of(v1, v2, m0);
+        map_of(v1 + lag_step(lags->crval1, d.n1), v2, m1h);
+        map_of(v1, v2 + lag_step(lags->crval2, d.n2), m2h);
         const double u = hdr_target->naxis1 * 0.5, v = hdr_target->naxis2 * 0.5;
         double x0, y0, x1, y1;
         apply_h(m0, u, v, &x0, &y0);
@@ -1388,13 +1479,16 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
             }
         }
         // which target pixels can ever be in bounds: inverse maps of the small image's corners for the lags on the
-        // boundary of the (CRVAL1, CRVAL2) rectangle (corners + edge midpoints + centre; the maps vary smoothly and
-        // monotonically with the lag, the +-3 px margin below covers the curvature in between)
-        const int e1[3] = {i1_lo, (i1_lo + i1_hi) / 2, i1_hi}, e2[3] = {0, (d.n2 - 1) / 2, d.n2 - 1};
+        // boundary of the (CRVAL1, CRVAL2) rectangle, chosen BY VALUE (the reference accepts lag lists in any order):
+        // smallest, largest and the value nearest the middle of each axis (the maps vary smoothly and monotonically
+        // with the lag value, the +-3 px margin below covers the curvature in between)
+        int e1[3], e2[3];
+        extreme_lags(lags->crval1 + i1_lo, i1_hi - i1_lo + 1, e1);
+        extreme_lags(lags->crval2, d.n2, e2);
         for (int a1 = 0; a1 < 3; ++a1)
             for (int a2 = 0; a2 < 3; ++a2) {
                 coreg_wcs2d hl = hc;
-                hl.crval1 = hdr_small->crval1 + lags->crval1[e1[a1]];
+                hl.crval1 = hdr_small->crval1 + lags->crval1[i1_lo + e1[a1]];
                 hl.crval2 = hdr_small->crval2 + lags->crval2[e2[a2]];
                 double hi[9];
                 homography(hl, *hdr_target, hi);

@@ -441,6 +441,9 @@ struct PrecomputeArgs {
     LaunchU car_fwd;             // MODE_CAR: 0-based target pixel -> its native (phi, theta) [rad]
     double f0lo, f0hi, f1lo, f1hi;  // cull box on the base coordinates (inclusive)
     int residus;              // 1: method 'residus' -> pts hold the raw reference value and 1/sqrt(value)
+    int tile_skip;            // MODE_TRANSLATE: 1 = drop whole tiles that provably miss the cull box
+    double lip_x, lip_y;      // pixels per radian of grid-point motion (upper bounds), see k_precompute
+    double dlon, dlat;        // grid steps in radians (upper bounds)
     const double* pivot_a;    // device scalar: mean of the finite reference values
     Pt* pts;                  // [n_tiles][kTilePts] compacted points
     int* tile_count;          // [n_tiles]
@@ -455,32 +458,23 @@ __global__ void __launch_bounds__(256) k_precompute(const PrecomputeArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double pivot = a.pivot_a[0];
     const double inf = __builtin_inf();
-    if (MODE == MODE_TRANSLATE) {
-        // Whole tile outside the cull box?  The map (i, j) -> (t0, t1) is smooth and, over one tile, monotone to well
-        // within the margin used here, so the tile's nine sample points (corners, edge midpoints, centre) bound it:
-        // if all nine are visible and their box, widened by a quarter of its own size plus 4 px, misses the cull
-        // box, no point of the tile can be kept.  (Tiles touching the limb -- any sample behind it -- are never skipped.)
+    if (MODE == MODE_TRANSLATE && a.tile_skip) {
+        // Whole tile outside the cull box?  A bound, not a heuristic: (t0, t1) = K atan(x''/zd), K atan(y''/zd) with
+        // (x'', y'', zz) components of a rotated unit vector and zd = dist - zz >= dist - 1 > 0, so moving the grid
+        // point by an angle d (radians, <= |d lon| + |d lat|) moves x''/zd by at most d (1/(dist-1) + 1/(dist-1)^2) and
+        // atan is 1-Lipschitz: |t - t_centre| <= lip * (|di| dlon + |dj| dlat) for every point of the tile, visible or
+        // not (host: lip_x/lip_y, dlon/dlat with their rounding margins; tile_skip = 0 when dist <= 1).
         __shared__ int s_skip;
         const int i0 = tx * a.tile_w, j0 = ty * a.tile_h;
         const int i1 = min(i0 + a.tile_w, a.gw) - 1, j1 = min(j0 + a.tile_h, a.gh) - 1;
-        if (wave == 0) {  // lanes 0..8 evaluate one sample each, the rest repeat sample 8
-            const int k = min(lane, 8);
-            const int ii = (k % 3 == 0) ? i0 : ((k % 3 == 1) ? (i0 + i1) / 2 : i1);
-            const int jj = (k / 3 == 0) ? j0 : ((k / 3 == 1) ? (j0 + j1) / 2 : j1);
+        if (threadIdx.x == 0) {
+            const int ic = (i0 + i1) / 2, jc = (j0 + j1) / 2;
             double t0, t1;
-            const bool vis = carr_term(a.carr, ii, jj, t0, t1);
-            double q0lo = t0, q0hi = t0, q1lo = t1, q1hi = t1;
-            for (int o = 8; o > 0; o >>= 1) {  // lanes 0..15 hold all nine samples
-                q0lo = fmin(q0lo, __shfl_xor(q0lo, o));
-                q0hi = fmax(q0hi, __shfl_xor(q0hi, o));
-                q1lo = fmin(q1lo, __shfl_xor(q1lo, o));
-                q1hi = fmax(q1hi, __shfl_xor(q1hi, o));
-            }
-            const bool all_vis = (__ballot(vis) & 0x1ffull) == 0x1ffull;
-            const double m0 = 0.25 * (q0hi - q0lo) + 4.0, m1 = 0.25 * (q1hi - q1lo) + 4.0;
-            if (lane == 0)
-                s_skip = all_vis &&
-                         (q0hi + m0 < a.f0lo || q0lo - m0 > a.f0hi || q1hi + m1 < a.f1lo || q1lo - m1 > a.f1hi);
+            carr_term(a.carr, ic, jc, t0, t1);
+            const double ang = (double)max(ic - i0, i1 - ic) * a.dlon + (double)max(jc - j0, j1 - jc) * a.dlat;
+            const double m0 = a.lip_x * ang + 1.0, m1 = a.lip_y * ang + 1.0;
+            // (a NaN centre compares false everywhere: no skip)
+            s_skip = (t0 + m0 < a.f0lo) || (t0 - m0 > a.f0hi) || (t1 + m1 < a.f1lo) || (t1 - m1 > a.f1hi);
         }
         __syncthreads();
         if (s_skip) {

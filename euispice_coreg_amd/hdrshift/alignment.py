@@ -88,7 +88,9 @@ class Alignment:
             self.data_small = np.asarray(ds)  # float32 (BITPIX=-32) pixels stay float32: the float64 cast is exact
         else:
             ds, hs = fits_io.read_image(self.small_fov_to_correct, self.small_fov_window)
-            self.data_small = np.array(ds, dtype=np.float64)  # alignment.py:198 / :314
+            ds = np.asarray(ds)
+            # alignment.py:198 / :314 cast to float64 (exact for float32 pixels, which are kept as they are)
+            self.data_small = fits_io.native_pixels(ds)
         self.hdr_small = fits_io.Header(hs)
         hdrutil.check_and_create_pcij_matrix(self.hdr_small, self.force_crota_0)  # alignment.py:232 / :310
         hdrutil.check_and_create_pcij_matrix(self.hdr_large, self.force_crota_0)
@@ -96,7 +98,10 @@ class Alignment:
     def _large_pixels(self):
         if self.data_large is None:
             dl, _ = fits_io.read_image(self.large_fov_known_pointing, self.large_fov_window)
-            self.data_large = np.array(dl, dtype=np.float64)  # alignment.py:191 / :301
+            dl = np.asarray(dl)
+            # alignment.py:191 / :301 cast to float64; float32 pixels (BITPIX=-32) are kept as they are -- the cast is
+            # exact and the library does it on the GPU, half the bytes cross PCIe
+            self.data_large = fits_io.native_pixels(dl)
         return self.data_large
 
     def _reference_tag(self, frame, *what):
@@ -331,7 +336,7 @@ class Alignment:
                                                         self.order)
                     target = self.hdr_small
                 else:
-                    h.set_reference_on_grid(self._large_pixels())  # quirk Q1: full large grid, float64
+                    h.set_reference_on_grid(np.asarray(self._large_pixels(), dtype=np.float64))  # quirk Q1: float64
                     target = self.hdr_large
                 part = h.sweep_helioprojective(target, self.hdr_small, lags, order=self.order, method=method,
                                                cdelt_semantics=sem, lag_begin=lo, lag_end=hi)

@@ -127,6 +127,15 @@ def _select(hdus, window):
     return i
 
 
+def native_pixels(a):
+    """Pixels as the sweep takes them: float32 data (BITPIX=-32, either byte order) as native float32, everything else as
+    float64 (the reference's own cast, alignment.py:191 / :198 / :301 / :314; exact for float32)."""
+    a = np.asarray(a)
+    if a.dtype.kind == "f" and a.dtype.itemsize == 4:
+        return np.ascontiguousarray(a, dtype=np.float32)
+    return np.array(a, dtype=np.float64)
+
+
 def read_image(path, window=-1):
     """(data, header) of one HDU.  `path` may also be a (data, header) pair already in memory."""
     if isinstance(path, (tuple, list)) and len(path) == 2:

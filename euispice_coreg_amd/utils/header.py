@@ -98,6 +98,8 @@ def correct_pointing_header(header, lag_cdelt1, lag_cdelt2, lag_crota, lag_crval
         header["PC2_2"] = np.cos(rho)
         header["PC1_2"] = -lam * np.sin(rho)
         header["PC2_1"] = (1 / lam) * np.sin(rho)
+    # `>= 1.0` is the helper's test (Util.py:238); correct_pointing_header's own `> 1.0` (Util.py:166) runs after it
+    # and can then never be true
     if header["PC1_1"] >= 1.0:
         header["PC1_1"] = 1.0
         header["PC2_2"] = 1.0

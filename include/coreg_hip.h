@@ -143,6 +143,14 @@ int coreg_prepare_reference_carrington(coreg_handle* h, const double* large, int
                                        int order);
 int coreg_prepare_reference_helioprojective(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
                                             const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order);
+/* The same with the reference image handed over as the float32 pixels a BITPIX=-32 FITS file holds (the reference
+ * casts them to float64, alignment.py:191 / :301 -- exactly, so results are identical): half the bytes over PCIe. */
+int coreg_prepare_reference_carrington_f32(coreg_handle* h, const float* large, int32_t ny, int32_t nx,
+                                           const coreg_wcs2d* hdr_large, const coreg_carr_grid* grid, double solar_r,
+                                           int order);
+int coreg_prepare_reference_helioprojective_f32(coreg_handle* h, const float* large, int32_t ny, int32_t nx,
+                                                const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order);
+
 /* Copy the resident reference-on-grid back (tests / figures). out: [gy][gx] of `dtype` (must match). */
 int coreg_get_reference_on_grid(coreg_handle* h, void* out, int dtype);
 

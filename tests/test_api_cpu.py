@@ -239,3 +239,29 @@ def test_plot_correlation_writes_a_figure(tmp_path):
     assert out.stat().st_size > 1000
     assert ax.get_xlabel() == "CRVAL1 [arcsec]" and len(ax.images) == 1
     assert ax.images[0].get_array().shape == (6, 11)
+
+
+def _run_bench(extra_env, *argv, timeout=600):
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):  # a plain driver command: no torchrun
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout  # ONE JSON line, nothing else on stdout
+    import json
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_its_ranks_gloo_world2():
+    """`python bench.py --gpus 2` with no torchrun environment starts its two ranks itself (children, before any GPU
+    call), runs the process group + the one all-gather + the block permutation, and rank 0 prints ONE JSON line.  Dry
+    run: no GPU on this box, each rank fills its lag block with the raveled lag indices instead of sweeping."""
+    out = _run_bench({"COREG_BENCH_BACKEND": "gloo", "COREG_BENCH_DRY": "1"}, "--gpus", "2", "--steps", "3", "--warmup",
+                     "1")
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["dry_run"] is True and out["value"] is None
+    assert out["dry_run_map_ok"] is True  # gathered blocks + permutation == C-order raveled lag map
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1] and sum(r["lags"] for r in out["per_rank"]) == 3600
+    assert out["scaling"] == "strong" and out["config"]["resident"] is True

@@ -123,3 +123,15 @@ def test_alignment_spice_l2_dropin():
     wantc = H.oracle_carrington(B.data_small, B.hdr_small, large, hl, (lag1, lag2, None, None, None), kw["shape"],
                                 kw["lonlims"], kw["latlims"])
     H.assert_corr_close(resc.corr, wantc, 1e-10, "AlignmentSpice.align_using_carrington")
+
+
+def test_bench_two_ranks_on_one_gpu_gloo():
+    """bench.py --gpus 2 started as a plain command on the one-GPU box (ranks share the device, all-gather over gloo):
+    real sweeps on both ranks, the assembled map has the injected shift as its argmax, per-rank kernel times present."""
+    from tests.test_api_cpu import _run_bench
+    out = _run_bench({"COREG_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "4", "--warmup", "2",
+                     "--no-cpu-baseline", timeout=900)
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["value"] > 0
+    assert out["argmax_lag_arcsec"] == out["injected_shift_arcsec"][:2] == [17.0, -9.0]
+    assert len(out["per_rank"]) == 2 and all(r["kernel_ms"] > 0 and r["lags"] == 1800 for r in out["per_rank"])
+    assert 0.0 < out["roofline"]["frac"] <= 1.0

@@ -368,3 +368,53 @@ def test_spline_order_out_of_range_is_an_error(gpu_handle):
     small, hs, large, hl, _ = H.scene(small_n=32, large_n=48)
     with pytest.raises(_lib.CoregError):
         H.gpu_helio(gpu_handle, small, hs, large, hl, _lags(2, 2), order=6)
+
+
+@pytest.mark.parametrize("serial", [False, True])
+def test_sweep_helioprojective_unsorted_lag_lists(gpu_handle, serial):
+    """The reference takes lag lists in any order (alignment.py:667-674 meshes them as given).  With the serial
+    semantics (target = full large grid) the cull box of the precompute decides which grid points exist: it must cover
+    the extreme lags BY VALUE, wherever they sit in the list."""
+    small, hs, large, hl, _ = H.scene(small_n=64, large_n=128)
+    lags = (np.array([0.0, -24.0, 38.0, -8.0, 16.0, 29.0]), np.array([3.0, 31.0, -27.0, -9.0, 12.0]), None, None,
+            [0.3, 0.0])
+    want = H.oracle_helio(small, hs, large, hl, lags, parallelism=not serial)
+    got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, serial_semantics=serial)
+    H.assert_corr_close(got, want, 1e-7, f"helio unsorted lags serial={serial}")
+    # and the sorted sweep holds the same numbers at the permuted positions
+    o1, o2 = np.argsort(lags[0]), np.argsort(lags[1])
+    srt = H.gpu_helio(gpu_handle, small, hs, large, hl, (lags[0][o1], lags[1][o2], None, None, [0.0, 0.3]),
+                      serial_semantics=serial)
+    assert np.allclose(srt, got[o1][:, o2][:, :, :, :, ::-1], rtol=0, atol=1e-12, equal_nan=True)
+
+
+def test_sweep_carrington_unsorted_lag_lists(gpu_handle):
+    small, hs, large, hl, _ = H.scene()
+    lags = (np.array([17.0, -11.0, 25.0, 3.0]), np.array([-9.0, 19.0, -23.0, 5.0, -1.0]), None, None, None)
+    want = H.oracle_carrington(small, hs, large, hl, lags, (72, 64))
+    got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, (72, 64))
+    H.assert_corr_close(got, want, 1e-10, "carrington unsorted lags")
+
+
+def test_tile_skip_is_exact_on_a_coarse_limb_crossing_grid(gpu_handle):
+    """k_precompute drops whole tiles whose (Lipschitz-bounded) image misses the cull box.  The bound is provable, so
+    the kept-point count and the map must be IDENTICAL with the skip switched off -- checked on a coarse grid that
+    crosses the limb and is much wider than the small field of view (most tiles are skipped), with long thin tiles."""
+    small, hs, large, hl, _ = H.scene(small_n=96, large_n=160)
+    lags = (17.0 + 3.0 * (np.arange(6) - 3), -9.0 + 3.0 * (np.arange(5) - 2), None, None, [0.0, 0.4])
+    lon, lat, shape = (150.0, 350.0), (-89.0, 89.0), (700, 300)
+    res = {}
+    for tw in (0, 256, 4):
+        gpu_handle.set_option("tile_w", tw)
+        try:
+            for skip in (1, 0):
+                gpu_handle.set_option("tile_skip", skip)
+                got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, shape, lonlims=lon, latlims=lat)
+                res[(tw, skip)] = (got, gpu_handle.last_stats()["n_active_points"])
+        finally:
+            gpu_handle.set_option("tile_skip", 1)
+            gpu_handle.set_option("tile_w", 0)
+        assert res[(tw, 1)][1] == res[(tw, 0)][1] > 0
+        assert np.array_equal(res[(tw, 1)][0], res[(tw, 0)][0], equal_nan=True)
+    want = H.oracle_carrington(small, hs, large, hl, lags, shape, lonlims=lon, latlims=lat)
+    H.assert_corr_close(res[(0, 1)][0], want, 1e-10, "coarse limb-crossing grid")
