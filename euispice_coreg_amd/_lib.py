@@ -98,6 +98,7 @@ SYMBOLS = [
      [_WP, _WP, C.POINTER(Lags), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
     ("coreg_carrington_origin", C.c_int, [_WP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("coreg_car_map", C.c_int, [_WP, _WP, C.c_int64, _P, _P, _P, _P]),
+    ("coreg_wcslib_pixel_to_pixel", C.c_int, [_WP, _WP, C.c_int64, _P, _P, _P, _P, _P, _P]),
 ]
 
 _lib = None
@@ -436,6 +437,21 @@ def car_map(hdr_from, hdr_to, px, py):
     if rc != COREG_OK:
         raise CoregError(rc, "coreg_car_map: bad arguments")
     return ox, oy
+
+
+def wcslib_pixel_to_pixel(hdr_from, hdr_to, px, py):
+    """pixel -> sky -> ang2pipi -> pixel through the library's restatement of wcslib (host, no GPU).
+    Returns (x, y, lng_deg, lat_deg)."""
+    lib = load_library()
+    px = np.ascontiguousarray(px, dtype=np.float64).ravel()
+    py = np.ascontiguousarray(py, dtype=np.float64).ravel()
+    out = [np.empty_like(px) for _ in range(4)]
+    wf, wt = wcs_from_header(hdr_from), wcs_from_header(hdr_to)
+    rc = lib.coreg_wcslib_pixel_to_pixel(C.byref(wf), C.byref(wt), px.size, px.ctypes.data, py.ctypes.data,
+                                         *[o.ctypes.data for o in out])
+    if rc != COREG_OK:
+        raise CoregError(rc, "coreg_wcslib_pixel_to_pixel")
+    return tuple(out)
 
 
 def carrington_origin(hdr):

@@ -109,6 +109,13 @@ struct coreg_handle {
     // sweep
     DevBuf lane_params, out_index, partials, out_dev, tmp_img;
     DevBuf up_f64, up_flag;  // upload staging on the device (float64 copy, exactness flag)
+    // zero-lag border decision of the helioprojective sub-map path (geometry.hpp WcslibTan): grid pixels the
+    // reference's wcslib round trip drops, cached per header
+    std::vector<double> border_key;
+    std::vector<int> border_dropped;
+    DevBuf border_dev;
+    PinBuf pin_border;
+    int64_t opt_border_fix = 1;
 
     // options
     int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1;
@@ -543,12 +550,18 @@ void fill_precompute_common(coreg_handle* h, PrecomputeArgs* a, int tile_w) {
 
 // one sweep-kernel launch + finalize over n_batches * 256 slots whose parameters (SoA [np][n_slots]) and output
 // indices are already on the device
+struct BorderFix {
+    std::vector<long long> slots;  // slots (of this launch) whose lag is the identity map
+    int n_dropped = 0;             // pixels listed in h->border_dev
+};
+
 int launch_sweep(coreg_handle* h, int mode, int order, int method, const double* params_dev,
                  const long long* outidx_dev, int n_batches, int n_tiles, long long lag_begin, double* out_dev,
-                 const LaunchU* car_inv = nullptr) {
+                 const LaunchU* car_inv = nullptr, const BorderFix* fix = nullptr) {
     const long long n_slots = (long long)n_batches * kBlock;
     const int n_groups = pick_groups(h, n_batches, n_tiles);
-    HIPCHK(h->partials.reserve((size_t)n_groups * kNumSums * n_slots * sizeof(double)));
+    const bool fixing = fix && !fix->slots.empty() && fix->n_dropped > 0;
+    HIPCHK(h->partials.reserve((size_t)(n_groups + (fixing ? 1 : 0)) * kNumSums * n_slots * sizeof(double)));
 
     SweepArgs a;
     a.img = h->small.p;
@@ -631,9 +644,36 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     h->stats.n_sweep_launches++;
     h->stats.used_lds = a.use_lds;
 
+    if (fixing) {
+        // one more slab: zero, except minus the dropped border pixels' totals at the identity lag's slot
+        double* slab = h->partials.as<double>() + (size_t)n_groups * kNumSums * n_slots;
+        HIPCHK(hipMemsetAsync(slab, 0, (size_t)kNumSums * n_slots * sizeof(double), h->stream));
+        BorderFixArgs b;
+        b.img = h->small.p;
+        b.W = h->sW;
+        b.H = h->sH;
+        b.ref = h->ref.p;
+        b.ref_f32 = h->ref_dtype == COREG_F32 ? 1 : 0;
+        b.dropped = h->border_dev.as<int>();
+        b.n_dropped = fix->n_dropped;
+        b.gw = h->gW;
+        b.order = order;
+        b.round_f32 = mode == MODE_TRANSLATE ? 0 : 1;
+        b.residus = method == COREG_METHOD_RESIDUS ? 1 : 0;
+        b.pivots = h->pivots.as<double>();
+        b.slab = slab;
+        b.n_slots = n_slots;
+        for (long long sl : fix->slots) {
+            b.slot = sl;
+            if (h->small_f32) hipLaunchKernelGGL((k_border_fix<float>), dim3(1), dim3(256), 0, h->stream, b);
+            else hipLaunchKernelGGL((k_border_fix<double>), dim3(1), dim3(256), 0, h->stream, b);
+        }
+        HIPCHK(hipGetLastError());
+    }
+
     FinalizeArgs f;
     f.partials = h->partials.as<double>();
-    f.n_groups = n_groups;
+    f.n_groups = n_groups + (fixing ? 1 : 0);
     f.n_slots = n_slots;
     f.out_index = outidx_dev;
     f.lag_begin = lag_begin;
@@ -643,6 +683,72 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_slots + 63) / 64)), dim3(64 * kFinLanes), 0, h->stream, f);
     HIPCHK(hipGetLastError());
     return COREG_OK;
+}
+
+// Grid pixels of `hdr` (the target header == the shifted header of the zero lag) that the reference's round trip
+// pixel -> sky -> ang2pipi -> pixel (alignment.py:1038-1069) sends outside [0, W-1] x [0, H-1] of the image to align
+// (bounds rule of scipy's map_coordinates).  Only the perimeter can be affected (|eps| << 1 px).  Cached per header.
+int border_dropped_pixels(coreg_handle* h, const coreg_wcs2d& hdr, int* n_out) {
+    const int gw = h->gW, gh = h->gH;
+    std::vector<double> key = {hdr.crpix1, hdr.crpix2, hdr.crval1, hdr.crval2, hdr.cdelt1, hdr.cdelt2, hdr.pc1_1,
+                               hdr.pc1_2, hdr.pc2_1, hdr.pc2_2, hdr.unit_to_deg, hdr.lonpole, (double)gw, (double)gh,
+                               (double)h->sW, (double)h->sH};
+    if (key != h->border_key || !h->border_dev.p) {
+        WcslibTan w;
+        w.init(hdr);
+        std::vector<int> per;  // perimeter, row-major
+        per.reserve(2 * (size_t)(gw + gh));
+        for (int j = 0; j < gh; ++j) {
+            if (j == 0 || j == gh - 1) {
+                for (int i = 0; i < gw; ++i) per.push_back(j * gw + i);
+            } else {
+                per.push_back(j * gw);
+                if (gw > 1) per.push_back(j * gw + gw - 1);
+            }
+        }
+        std::vector<char> drop(per.size(), 0);
+        const double wmax = (double)(h->sW - 1), hmax = (double)(h->sH - 1);
+        auto work = [&](size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi; ++k) {
+                double x, y;
+                wcslib_pixel_to_pixel(w, w, (double)(per[k] % gw), (double)(per[k] / gw), &x, &y);
+                drop[k] = !((x >= 0.0) && (x <= wmax) && (y >= 0.0) && (y <= hmax));  // NaN -> dropped
+            }
+        };
+        unsigned nt = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+        if (per.size() < 2048) nt = 1;
+        if (nt <= 1) {
+            work(0, per.size());
+        } else {
+            std::vector<std::thread> th;
+            const size_t step = (per.size() + nt - 1) / nt;
+            for (unsigned t = 0; t < nt; ++t) {
+                const size_t lo = std::min(per.size(), (size_t)t * step), hi = std::min(per.size(), lo + step);
+                if (hi > lo) th.emplace_back(work, lo, hi);
+            }
+            for (auto& x : th) x.join();
+        }
+        h->border_dropped.clear();
+        for (size_t k = 0; k < per.size(); ++k)
+            if (drop[k]) h->border_dropped.push_back(per[k]);
+        const size_t bytes = std::max<size_t>(1, h->border_dropped.size()) * sizeof(int);
+        HIPCHK(h->border_dev.reserve(bytes));
+        HIPCHK(hipStreamSynchronize(h->stream));  // an earlier sweep may still read the old list / staging
+        HIPCHK(h->pin_border.reserve(bytes));
+        std::memcpy(h->pin_border.p, h->border_dropped.data(), h->border_dropped.size() * sizeof(int));
+        if (!h->border_dropped.empty())
+            HIPCHK(hipMemcpyAsync(h->border_dev.p, h->pin_border.p, h->border_dropped.size() * sizeof(int),
+                                  hipMemcpyHostToDevice, h->stream));
+        h->border_key.swap(key);
+    }
+    *n_out = (int)h->border_dropped.size();
+    return COREG_OK;
+}
+
+bool same_tan_wcs(const coreg_wcs2d& a, const coreg_wcs2d& b) {
+    return a.crpix1 == b.crpix1 && a.crpix2 == b.crpix2 && a.crval1 == b.crval1 && a.crval2 == b.crval2 &&
+           a.cdelt1 == b.cdelt1 && a.cdelt2 == b.cdelt2 && a.pc1_1 == b.pc1_1 && a.pc1_2 == b.pc1_2 &&
+           a.pc2_1 == b.pc2_1 && a.pc2_2 == b.pc2_2 && a.unit_to_deg == b.unit_to_deg && a.lonpole == b.lonpole;
 }
 
 int collect_stats(coreg_handle* h);
@@ -779,7 +885,7 @@ void coreg_destroy(coreg_handle* h) {
     DevBuf* bufs[] = {&h->small, &h->ref, &h->pivots, &h->red_sum, &h->red_cnt, &h->t_sin_lon, &h->t_cos_lon,
                       &h->t_cos_lat, &h->t_sin_lat, &h->pts, &h->tile_count, &h->tile_list, &h->tile_cum, &h->group_first,
                       &h->tile_info, &h->tile_bbox, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
-                      &h->tmp_img, &h->up_f64, &h->up_flag};
+                      &h->tmp_img, &h->up_f64, &h->up_flag, &h->border_dev};
     for (DevBuf* b : bufs) b->release();
     h->pin_params.release();
     h->pin_outidx.release();
@@ -799,6 +905,7 @@ void coreg_destroy(coreg_handle* h) {
     if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
     if (h->ev_upload) (void)hipEventDestroy(h->ev_upload);
     h->pin_info.release();
+    h->pin_border.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -837,6 +944,8 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         h->opt_n_groups = value;
     } else if (n == "skew") {
         (void)value;  // accepted for compatibility: the LDS row skew was measured to lose and is gone
+    } else if (n == "border_fix") {
+        h->opt_border_fix = value ? 1 : 0;  // 0: the zero lag keeps every border pixel (exact identity map)
     } else if (n == "tile_skip") {
         h->opt_tile_skip = value ? 1 : 0;  // 0: k_precompute evaluates every grid point (tests compare both)
     } else if (n == "h_series") {
@@ -1455,6 +1564,11 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     double fx0 = 1e300, fx1 = -1e300, fy0 = 1e300, fy1 = -1e300;  // cull box in target pixels
     HomographyFamily fam;
     fam.init(*hdr_target, *hdr_small, lags->crval1, d.n1, lags->crval2, d.n2);
+    // a lag whose shifted header equals the target header (the zero lag of the sub-map path) needs the grid to be the
+    // image's own pixel grid
+    const bool identity_possible = h->opt_border_fix && h->gW == h->sW && h->gH == h->sH &&
+                                   hdr_target->naxis1 == h->sW && hdr_target->naxis2 == h->sH;
+    BorderFix fix;
     const int i1_lo = (int)(lag_begin / row), i1_hi = (int)((lag_end - 1) / row);
     const double nanv = std::numeric_limits<double>::quiet_NaN();
     for (long long c = 0; c < d.nc; ++c) {
@@ -1476,6 +1590,17 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                 for (int k = 0; k < 9; ++k) hm[k] = nanv;
             } else {
                 fam.get(B, slots.i1[s], slots.i2[s], hm);
+                if (identity_possible) {
+                    coreg_wcs2d hl = hc;
+                    hl.crval1 = hdr_small->crval1 + lags->crval1[slots.i1[s]];
+                    hl.crval2 = hdr_small->crval2 + lags->crval2[slots.i2[s]];
+                    if (same_tan_wcs(hl, *hdr_target)) {
+                        // the target header IS this lag's header: identity map, border pixels decided as the
+                        // reference's wcslib round trip decides them (geometry.hpp WcslibTan, k_border_fix)
+                        for (int k = 0; k < 9; ++k) hm[k] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+                        fix.slots.push_back((long long)(outidx.size() + s));
+                    }
+                }
             }
         }
         // which target pixels can ever be in bounds: inverse maps of the small image's corners for the lags on the
@@ -1531,9 +1656,10 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     pa.f0hi = std::ceil(fx1) + 3.0;
     pa.f1lo = std::floor(fy0) - 3.0;
     pa.f1hi = std::ceil(fy1) + 3.0;
+    if (!fix.slots.empty()) RETCHK(border_dropped_pixels(h, *hdr_target, &fix.n_dropped));
     RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles, pick_groups(h, n_batches, n_tiles)));
     RETCHK(launch_sweep(h, sweep_mode, order, method, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
-                        n_tiles, lag_begin, out_dev));
+                        n_tiles, lag_begin, out_dev, nullptr, &fix));
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }
 
@@ -1583,6 +1709,23 @@ int coreg_lag_homography(const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_s
     HomographyFamily fam;
     fam.init(*hdr_target, *hdr_small, lags->crval1, lags->n_crval1, lags->crval2, lags->n_crval2);
     fam.get(HomographyFamily::combo(hc), idx[0], idx[1], h9);
+    return COREG_OK;
+}
+
+int coreg_wcslib_pixel_to_pixel(const coreg_wcs2d* from, const coreg_wcs2d* to, int64_t n, const double* px,
+                                const double* py, double* ox, double* oy, double* lng, double* lat) {
+    if (!from || !to || n < 0 || (n > 0 && (!px || !py || !ox || !oy))) return COREG_EINVAL;
+    if (from->proj != COREG_PROJ_TAN || to->proj != COREG_PROJ_TAN) return COREG_ENOTIMPL;
+    WcslibTan a, b;
+    a.init(*from);
+    b.init(*to);
+    for (int64_t i = 0; i < n; ++i) {
+        double l, t;
+        a.p2s(px[i], py[i], &l, &t);
+        if (lng) lng[i] = l;
+        if (lat) lat[i] = t;
+        b.s2p(ang2pipi_deg(l), ang2pipi_deg(t), &ox[i], &oy[i]);
+    }
     return COREG_OK;
 }
 

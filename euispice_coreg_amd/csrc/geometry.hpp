@@ -9,6 +9,8 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include "../../include/coreg_hip.h"
@@ -191,6 +193,265 @@ inline void apply_h(const double h[9], double x, double y, double* ox, double* o
     const double w = h[6] * x + h[7] * y + h[8];
     *ox = (h[0] * x + h[1] * y + h[2]) / w;
     *oy = (h[3] * x + h[4] * y + h[5]) / w;
+}
+
+// ---- wcslib's own pixel -> sky -> pixel chain, operation by operation -------------------------------------------
+// For ONE lag-point of a helioprojective sweep the exact homography is not what decides the result: the zero lag of the
+// parallelism=True path, where the target header IS the shifted header (alignment.py:1000, :1038-1069).  The map is
+// then the identity up to wcslib's rounding noise (|eps| ~ 1e-12..1e-9 px), and the sign of that noise decides,
+// through the bounds rule c < 0 or c > n-1 (utils/Util.py:98-102 -> scipy map_coordinates), whether a border pixel
+// of the grid is kept.  Reproducing the decision needs wcslib's arithmetic itself.  Restated from wcslib 7.x
+// (third-party, bundled with astropy; absent from the reference tree): lin.c linp2x / linx2p / matinv, prj.c tanx2s /
+// tans2x, sph.c sphx2s / sphs2x, wcstrig.c -- including the macro expansions that fix the order of the roundings
+// (`#define D2R PI/180.0`, `#define R2D 180.0/PI`: angle*D2R is (angle*PI)/180, atan2(y,x)*R2D is (atan2*180)/PI) and
+// glibc's sincos().  Pinned bit for bit, for every border pixel of five headers, against astropy 4.3.1 / wcslib 7.6
+// (tests/golden/border_golden.npz).  The numbers depend on the libm in use, as the reference's do.
+struct WcslibTan {
+    double crpix[2], cdelt[2], piximg[2][2], imgpix[2][2];
+    bool unity;
+    double e0, e1, e2, e3, e4;  // celprm euler: lng_p, 90 - lat_p, phi_p, cos(e1), sin(e1)
+
+    static void sincosd(double a, double* s, double* c) {
+#pragma clang fp contract(off)
+        if (std::fmod(a, 90.0) == 0.0) {
+            const int i = std::abs((int)std::floor(a / 90.0 + 0.5)) % 4;
+            switch (i) {
+                case 0: *s = 0.0; *c = 1.0; return;
+                case 1: *s = (a > 0.0) ? 1.0 : -1.0; *c = 0.0; return;
+                case 2: *s = 0.0; *c = -1.0; return;
+                default: *s = (a > 0.0) ? -1.0 : 1.0; *c = 0.0; return;
+            }
+        }
+        ::sincos(a * kPi / 180.0, s, c);
+    }
+    static double cosd(double a) {
+#pragma clang fp contract(off)
+        if (std::fmod(a, 90.0) == 0.0) {
+            const int i = std::abs((int)std::floor(a / 90.0 + 0.5)) % 4;
+            return i == 0 ? 1.0 : (i == 2 ? -1.0 : 0.0);
+        }
+        return std::cos(a * kPi / 180.0);
+    }
+    static double sind(double a) {
+#pragma clang fp contract(off)
+        if (std::fmod(a, 90.0) == 0.0) {
+            const int i = std::abs((int)std::floor(a / 90.0 - 0.5)) % 4;
+            return i == 0 ? 1.0 : (i == 2 ? -1.0 : 0.0);
+        }
+        return std::sin(a * kPi / 180.0);
+    }
+    static double atan2d(double y, double x) {
+#pragma clang fp contract(off)
+        if (y == 0.0) {
+            if (x >= 0.0) return 0.0;
+            if (x < 0.0) return 180.0;
+        } else if (x == 0.0) {
+            if (y > 0.0) return 90.0;
+            if (y < 0.0) return -90.0;
+        }
+        return std::atan2(y, x) * 180.0 / kPi;
+    }
+    static double asind(double v) {
+#pragma clang fp contract(off)
+        if (v <= -1.0) {
+            if (v + 1.0 > -1e-10) return -90.0;
+        } else if (v == 0.0) {
+            return 0.0;
+        } else if (v >= 1.0) {
+            if (v - 1.0 < 1e-10) return 90.0;
+        }
+        return std::asin(v) * 180.0 / kPi;
+    }
+    static double acosd(double v) {
+#pragma clang fp contract(off)
+        if (v >= 1.0) {
+            if (v - 1.0 < 1e-10) return 0.0;
+        } else if (v == 0.0) {
+            return 90.0;
+        } else if (v <= -1.0) {
+            if (v + 1.0 > -1e-10) return 180.0;
+        }
+        return std::acos(v) * 180.0 / kPi;
+    }
+    // lin.c matinv() for n = 2: LU decomposition with scaled partial pivoting, then one solve per unit vector
+    static void matinv2(const double m[2][2], double inv[2][2]) {
+#pragma clang fp contract(off)
+        int mxl[2] = {0, 1}, lxm[2] = {0, 0};
+        double rowmax[2] = {0.0, 0.0}, lu[2][2] = {{m[0][0], m[0][1]}, {m[1][0], m[1][1]}};
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) rowmax[i] = std::fmax(rowmax[i], std::fabs(m[i][j]));
+        for (int k = 0; k < 2; ++k) {
+            double colmax = std::fabs(lu[k][k]) / rowmax[k];
+            int pivot = k;
+            for (int i = k + 1; i < 2; ++i) {
+                const double d = std::fabs(lu[i][k]) / rowmax[i];
+                if (d > colmax) {
+                    colmax = d;
+                    pivot = i;
+                }
+            }
+            if (pivot > k) {
+                for (int j = 0; j < 2; ++j) std::swap(lu[pivot][j], lu[k][j]);
+                std::swap(rowmax[pivot], rowmax[k]);
+                std::swap(mxl[pivot], mxl[k]);
+            }
+            for (int i = k + 1; i < 2; ++i)
+                if (lu[i][k] != 0.0) {
+                    lu[i][k] /= lu[k][k];
+                    for (int j = k + 1; j < 2; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
+                }
+        }
+        for (int i = 0; i < 2; ++i) lxm[mxl[i]] = i;
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) inv[i][j] = 0.0;
+        for (int k = 0; k < 2; ++k) {
+            inv[lxm[k]][k] = 1.0;
+            for (int i = lxm[k] + 1; i < 2; ++i)
+                for (int j = lxm[k]; j < i; ++j) inv[i][k] -= lu[i][j] * inv[j][k];
+            for (int i = 1; i >= 0; --i) {
+                for (int j = i + 1; j < 2; ++j) inv[i][k] -= lu[i][j] * inv[j][k];
+                inv[i][k] /= lu[i][i];
+            }
+        }
+    }
+    void init(const coreg_wcs2d& w) {
+#pragma clang fp contract(off)
+        crpix[0] = w.crpix1;
+        crpix[1] = w.crpix2;
+        // wcslib's unit fix scales CDELT and CRVAL to degrees (arcsec: x 1/3600)
+        cdelt[0] = w.cdelt1 * w.unit_to_deg;
+        cdelt[1] = w.cdelt2 * w.unit_to_deg;
+        unity = w.pc1_1 == 1.0 && w.pc2_2 == 1.0 && w.pc1_2 == 0.0 && w.pc2_1 == 0.0;
+        piximg[0][0] = cdelt[0] * w.pc1_1;
+        piximg[0][1] = cdelt[0] * w.pc1_2;
+        piximg[1][0] = cdelt[1] * w.pc2_1;
+        piximg[1][1] = cdelt[1] * w.pc2_2;
+        matinv2(piximg, imgpix);
+        e0 = w.crval1 * w.unit_to_deg;  // zenithal projection: the pole of the native system is the reference point
+        e1 = 90.0 - w.crval2 * w.unit_to_deg;
+        e2 = w.lonpole;
+        sincosd(e1, &e4, &e3);
+    }
+    // wcsp2s: 0-based pixel -> (lng, lat) degrees
+    void p2s(double px0, double py0, double* lng_out, double* lat_out) const {
+#pragma clang fp contract(off)
+        const double t0 = (px0 + 1.0) - crpix[0], t1 = (py0 + 1.0) - crpix[1];
+        double x, y;
+        if (unity) {
+            x = cdelt[0] * t0;
+            y = cdelt[1] * t1;
+        } else {
+            x = 0.0;
+            y = 0.0;
+            x += piximg[0][0] * t0;
+            y += piximg[1][0] * t0;
+            x += piximg[0][1] * t1;
+            y += piximg[1][1] * t1;
+        }
+        const double xj = x + 0.0, yj = y + 0.0;
+        const double r = std::sqrt(xj * xj + yj * yj);
+        const double phi = r == 0.0 ? 0.0 : atan2d(xj, -yj);
+        const double theta = atan2d(180.0 / kPi, r);
+        const double dphi = phi - e2;
+        double sinthe, costhe, sinphi, cosphi;
+        sincosd(theta, &sinthe, &costhe);
+        const double costhe3 = costhe * e3, costhe4 = costhe * e4, sinthe3 = sinthe * e3, sinthe4 = sinthe * e4;
+        sincosd(dphi, &sinphi, &cosphi);
+        double xx = sinthe4 - costhe3 * cosphi;
+        if (std::fabs(xx) < 1.0e-5) xx = -cosd(theta + e1) + costhe3 * (1.0 - cosphi);
+        const double yy = -costhe * sinphi;
+        const double dlng = (xx != 0.0 || yy != 0.0) ? atan2d(yy, xx) : dphi + 180.0;
+        double lng = e0 + dlng;
+        if (e0 >= 0.0) {
+            if (lng < 0.0) lng += 360.0;
+        } else {
+            if (lng > 0.0) lng -= 360.0;
+        }
+        if (lng > 360.0) lng -= 360.0;
+        else if (lng < -360.0) lng += 360.0;
+        double lat;
+        if (std::fmod(dphi, 180.0) == 0.0) {
+            lat = theta + cosphi * e1;
+            if (lat > 90.0) lat = 180.0 - lat;
+            if (lat < -90.0) lat = -180.0 - lat;
+        } else {
+            const double z = sinthe3 + costhe4 * cosphi;
+            if (std::fabs(z) > 0.99) lat = std::copysign(acosd(std::sqrt(xx * xx + yy * yy)), z);
+            else lat = asind(z);
+        }
+        *lng_out = lng;
+        *lat_out = lat;
+    }
+    // wcss2p: (lng, lat) degrees -> 0-based pixel (NaN where wcslib flags the point)
+    void s2p(double lng, double lat, double* px_out, double* py_out) const {
+#pragma clang fp contract(off)
+        const double dlng = lng - e0;
+        double sinlat, coslat, sinlng, coslng;
+        sincosd(lat, &sinlat, &coslat);
+        const double coslat3 = coslat * e3, coslat4 = coslat * e4, sinlat3 = sinlat * e3, sinlat4 = sinlat * e4;
+        sincosd(dlng, &sinlng, &coslng);
+        double xx = sinlat4 - coslat3 * coslng;
+        if (std::fabs(xx) < 1.0e-5) xx = -cosd(lat + e1) + coslat3 * (1.0 - coslng);
+        const double yy = -coslat * sinlng;
+        const double dphi = (xx != 0.0 || yy != 0.0) ? atan2d(yy, xx) : dlng - 180.0;
+        double phi = std::fmod(e2 + dphi, 360.0);
+        if (phi > 180.0) phi -= 360.0;
+        else if (phi < -180.0) phi += 360.0;
+        double theta;
+        if (std::fmod(dlng, 180.0) == 0.0) {
+            theta = lat + coslng * e1;
+            if (theta > 90.0) theta = 180.0 - theta;
+            if (theta < -90.0) theta = -180.0 - theta;
+        } else {
+            const double z = sinlat3 + coslat4 * coslng;
+            if (std::fabs(z) > 0.99) theta = std::copysign(acosd(std::sqrt(xx * xx + yy * yy)), z);
+            else theta = asind(z);
+        }
+        double sinphi, cosphi;
+        sincosd(phi, &sinphi, &cosphi);
+        const double s = sind(theta);
+        if (s == 0.0 || s < 0.0) {  // tans2x: divergent / behind the tangent plane -> invalid
+            *px_out = *py_out = std::nan("");
+            return;
+        }
+        const double r = 180.0 / kPi * cosd(theta) / s;
+        const double x = r * sinphi - 0.0, y = -r * cosphi - 0.0;
+        double p0, p1;
+        if (unity) {
+            p0 = x / cdelt[0] + crpix[0];
+            p1 = y / cdelt[1] + crpix[1];
+        } else {
+            p0 = 0.0;
+            p0 += imgpix[0][0] * x;
+            p0 += imgpix[0][1] * y;
+            p0 += crpix[0];
+            p1 = 0.0;
+            p1 += imgpix[1][0] * x;
+            p1 += imgpix[1][1] * y;
+            p1 += crpix[1];
+        }
+        *px_out = p0 - 1.0;
+        *py_out = p1 - 1.0;
+    }
+};
+// AlignCommonUtil.ang2pipi on a value in degrees (utils/Util.py:76-80; numpy's remainder takes the divisor's sign)
+inline double ang2pipi_deg(double a) {
+#pragma clang fp contract(off)
+    const double x = -a + 180.0;
+    double m = std::fmod(x, 360.0);
+    if (m != 0.0) {
+        if (m < 0.0) m += 360.0;
+    } else {
+        m = 0.0;
+    }
+    return -(m - 180.0);
+}
+// alignment.py:1038-1069 for one pixel of the target header: pixel -> sky (`from`) -> ang2pipi -> pixel (`to`)
+inline void wcslib_pixel_to_pixel(const WcslibTan& from, const WcslibTan& to, double px, double py, double* ox,
+                                  double* oy) {
+    double lng, lat;
+    from.p2s(px, py, &lng, &lat);
+    to.s2p(ang2pipi_deg(lng), ang2pipi_deg(lat), ox, oy);
 }
 
 // ---- plate carree (CAR) inputs: align_using_initial_carrington, alignment.py:344-399 --------------------

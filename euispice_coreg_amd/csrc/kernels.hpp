@@ -1131,6 +1131,72 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
     }
 }
 
+// ---- zero-lag border fix (helioprojective, target header == shifted header) ------------------------------------------
+// The sweep evaluates that lag-point with the exact identity map, which keeps every border pixel of the grid; the
+// reference's pixel -> sky -> pixel round trip through wcslib drops the border pixels whose coordinate comes back a
+// hair outside [0, n-1] (geometry.hpp, WcslibTan).  The host lists those pixels; this kernel subtracts their
+// contributions from the lag-point's six sums by writing MINUS their totals into an extra partial-sum slab that
+// k_finalize adds like any other.  One workgroup, fixed summation order.
+struct BorderFixArgs {
+    const void* img;  // small image, TS [H][W]
+    int W, H;
+    const void* ref;  // reference on grid, float32 (ref_f32) or float64, [gh][gw]
+    int ref_f32;
+    const int* dropped;  // linear grid indices j * gw + i of the pixels to take out
+    int n_dropped;
+    int gw;
+    int order;
+    int round_f32;  // 1: sample rounded to float32 before the mask (alignment.py:1024)
+    int residus;
+    const double* pivots;
+    double* slab;  // [kNumSums][n_slots], the extra slab
+    long long n_slots, slot;
+};
+template <typename TS>
+__global__ void __launch_bounds__(256) k_border_fix(const BorderFixArgs a) {
+    __shared__ double red[256];
+    const double pivot_a = a.pivots[0], pivot_b = a.pivots[1];
+    double s[kNumSums];
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) s[k] = 0.0;
+    for (int p = threadIdx.x; p < a.n_dropped; p += 256) {
+        const int idx = a.dropped[p];
+        const int i = idx % a.gw, j = idx / a.gw;
+        const double araw = a.ref_f32 ? (double)((const float*)a.ref)[idx] : ((const double*)a.ref)[idx];
+        if (!isfinite(araw)) continue;  // never entered the sums (k_precompute drops it)
+        bool inb;
+        double v = spline_global_rt<TS>((const TS*)a.img, a.W, a.H, (double)i, (double)j, a.order, inb);
+        if (!inb) continue;
+        if (a.round_f32) v = (double)(float)v;
+        if (a.residus) {
+            const double d = (araw - v) * (1.0 / sqrt(araw));
+            if (isfinite(d)) {
+                s[0] += 1.0;
+                s[2] += d;
+                s[4] = fma(d, d, s[4]);
+            }
+        } else if (isfinite(v)) {
+            const double av = araw - pivot_a, bm = v - pivot_b;
+            s[0] += 1.0;
+            s[1] += av;
+            s[2] += bm;
+            s[3] = fma(av, av, s[3]);
+            s[4] = fma(bm, bm, s[4]);
+            s[5] = fma(av, bm, s[5]);
+        }
+    }
+    for (int k = 0; k < kNumSums; ++k) {
+        red[threadIdx.x] = s[k];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.slab[(size_t)k * a.n_slots + a.slot] = -red[0];
+        __syncthreads();
+    }
+}
+
 // ---- finalize: add the tile-group slabs in a fixed order, Pearson coefficient (c_correlate.py:39-72) -------------
 struct FinalizeArgs {
     const double* partials;

@@ -214,6 +214,13 @@ int coreg_shift_header(const coreg_wcs2d* ref, double d_crval1, double d_crval2,
 int coreg_homography(const coreg_wcs2d* from, const coreg_wcs2d* to, double* h9);
 int coreg_lag_homography(const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_small, const coreg_lags* lags,
                          const int32_t idx[5], int cdelt_semantics, double* h9);
+/* alignment.py:1038-1069 + utils/Util.py:282-312 for n pixels of header `from`, through wcslib's own arithmetic
+ * (restated operation by operation, csrc/geometry.hpp WcslibTan; pinned bit for bit by tests/golden/border_golden.npz):
+ * pixel -> sky (`from`) -> ang2pipi -> pixel (`to`).  lng / lat (optional): the sky coordinates in degrees.  This is
+ * what decides the border pixels of the zero lag of a helioprojective sweep; every other lag uses the exact
+ * homography (coreg_lag_homography). */
+int coreg_wcslib_pixel_to_pixel(const coreg_wcs2d* from, const coreg_wcs2d* to, int64_t n, const double* px,
+                                const double* py, double* ox, double* oy, double* lng, double* lat);
 int coreg_carrington_origin(const coreg_wcs2d* hdr, double* x0, double* y0);
 /* CAR -> CAR map of one lag-point on the host: 0-based pixels of `from` -> 0-based pixels of `to` through the common
  * sphere, WCS(to).world_to_pixel(WCS(from).pixel_to_world(p)) for CRLN-CAR / CRLT-CAR headers (alignment.py:1038-1069

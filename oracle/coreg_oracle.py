@@ -12,7 +12,10 @@ Parity status ("pinning"):
     run in the build container; vectors + generating script in `tests/golden/`.
   * TAN pixel<->world (third-party astropy.wcs / wcslib, pinned astropy 7.2.0 in
     poetry.lock, not vendored): restated from FITS WCS Paper II; PINNED by vectors generated
-    with astropy 4.3.1 / wcslib 7.6 (`tests/golden/make_golden_wcs.py`).
+    with astropy 4.3.1 / wcslib 7.6 (`tests/golden/make_golden_wcs.py`).  The zero lag of the sub-map
+    path (identical headers: border pixels decided by wcslib's rounding noise) goes through a scalar,
+    operation-by-operation restatement of wcslib (`WcslibTan`), PINNED bit for bit by
+    `tests/golden/border_golden.npz` (`make_golden_border.py`).
   * `scipy.ndimage.map_coordinates` (third-party, pinned scipy 1.17.1): the oracle calls
     scipy itself (1.15.3 here); a scalar model of its order-1/2 semantics is also restated
     (`spline_sample_model`) and checked against scipy in tests.
@@ -240,6 +243,273 @@ class TanWCS:
         return px, py
 
 
+# --------------------------------------------------------------------------------------
+# wcslib's own arithmetic, operation by operation, on libm (scalar).  For the ONE lag-point of a helioprojective
+# sweep where the numpy restatement above is not enough: the zero lag of the parallelism=True path, where the target
+# header IS the shifted header (alignment.py:1000, :1038-1069).  pixel -> sky -> ang2pipi -> pixel is then the identity up
+# to wcslib's rounding noise (|eps| ~ 1e-12..1e-9 px), and the SIGN of that noise decides, through the bounds rule of
+# map_coordinates (c < 0 or c > n-1, utils/Util.py:98-102), whether a border pixel is kept -- about half of them are
+# dropped.  Restated from wcslib 7.x (third-party, bundled with astropy; absent from the reference tree): lin.c
+# linp2x / linx2p / matinv, prj.c tanx2s / tans2x, sph.c sphx2s / sphs2x, wcstrig.c, including the macro expansions
+# that fix the order of the roundings (`#define D2R PI/180.0`, `#define R2D 180.0/PI`: angle*D2R is (angle*PI)/180,
+# atan2(y,x)*R2D is (atan2(y,x)*180)/PI) and glibc's sincos().  PINNED bit for bit, for every border pixel of five
+# headers, by tests/golden/border_golden.npz (astropy 4.3.1 / wcslib 7.6).  libm-dependent, as the reference is.
+import ctypes  # noqa: E402
+
+_libm = ctypes.CDLL("libm.so.6")
+_libm.sincos.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+_libm.sincos.restype = None
+def _sincos(x):
+    s = ctypes.c_double(); c = ctypes.c_double()
+    _libm.sincos(x, ctypes.byref(s), ctypes.byref(c))
+    return s.value, c.value
+D2R = math.pi / 180.0
+R2D = 180.0 / math.pi
+
+def cosd(a):
+    if math.fmod(a, 90.0) == 0.0:
+        i = abs(int(math.floor(a / 90.0 + 0.5))) % 4
+        return (1.0, 0.0, -1.0, 0.0)[i]
+    return math.cos(a * math.pi / 180.0)
+
+def sind(a):
+    if math.fmod(a, 90.0) == 0.0:
+        i = abs(int(math.floor(a / 90.0 - 0.5))) % 4
+        return (1.0, 0.0, -1.0, 0.0)[i]
+    return math.sin(a * math.pi / 180.0)
+
+def sincosd(a):
+    if math.fmod(a, 90.0) == 0.0:
+        i = abs(int(math.floor(a / 90.0 + 0.5))) % 4
+        if i == 0: return 0.0, 1.0
+        if i == 1: return (1.0 if a > 0.0 else -1.0), 0.0
+        if i == 2: return 0.0, -1.0
+        return (-1.0 if a > 0.0 else 1.0), 0.0
+    return _sincos(a * math.pi / 180.0)
+
+def atan2d(y, x):
+    if y == 0.0:
+        if x >= 0.0: return 0.0
+        if x < 0.0: return 180.0
+    elif x == 0.0:
+        if y > 0.0: return 90.0
+        if y < 0.0: return -90.0
+    return math.atan2(y, x) * 180.0 / math.pi
+
+def asind(v):
+    if v <= -1.0:
+        if v + 1.0 > -1e-12: return -90.0   # wcstrig tolerance (WCSTRIG_TOL = 1e-10)
+    elif v == 0.0:
+        return 0.0
+    elif v >= 1.0:
+        if v - 1.0 < 1e-12: return 90.0
+    return math.asin(v) * 180.0 / math.pi
+
+def acosd(v):
+    if v >= 1.0:
+        if v - 1.0 < 1e-10: return 0.0
+    elif v == 0.0:
+        return 90.0
+    elif v <= -1.0:
+        if v + 1.0 > -1e-10: return 180.0
+    return math.acos(v) * 180.0 / math.pi
+
+def matinv2(m):
+    """lin.c matinv() for n = 2: LU with scaled partial pivoting, then column-by-column solve."""
+    n = 2
+    mxl = [0, 1]; lxm = [0, 0]; rowmax = [0.0, 0.0]
+    lu = [[m[0][0], m[0][1]], [m[1][0], m[1][1]]]
+    for i in range(n):
+        for j in range(n):
+            d = abs(m[i][j])
+            if d > rowmax[i]: rowmax[i] = d
+    for k in range(n):
+        colmax = abs(lu[k][k]) / rowmax[k]
+        pivot = k
+        for i in range(k + 1, n):
+            d = abs(lu[i][k]) / rowmax[i]
+            if d > colmax:
+                colmax = d; pivot = i
+        if pivot > k:
+            lu[pivot], lu[k] = lu[k], lu[pivot]
+            rowmax[pivot], rowmax[k] = rowmax[k], rowmax[pivot]
+            mxl[pivot], mxl[k] = mxl[k], mxl[pivot]
+        for i in range(k + 1, n):
+            if lu[i][k] != 0.0:
+                lu[i][k] /= lu[k][k]
+                for j in range(k + 1, n):
+                    lu[i][j] -= lu[i][k] * lu[k][j]
+    for i in range(n):
+        lxm[mxl[i]] = i
+    inv = [[0.0, 0.0], [0.0, 0.0]]
+    for k in range(n):
+        inv[lxm[k]][k] = 1.0
+        for i in range(lxm[k] + 1, n):
+            for j in range(lxm[k], i):
+                inv[i][k] -= lu[i][j] * inv[j][k]
+        for i in range(n - 1, -1, -1):
+            for j in range(i + 1, n):
+                inv[i][k] -= lu[i][j] * inv[j][k]
+            inv[i][k] /= lu[i][i]
+    return inv
+
+class WcslibTan:
+    def __init__(self, crpix, cdelt_deg, crval_deg, pc, lonpole=180.0):
+        self.crpix = crpix
+        self.unity = (pc[0][0] == 1.0 and pc[1][1] == 1.0 and pc[0][1] == 0.0 and pc[1][0] == 0.0)
+        self.cdelt = cdelt_deg
+        self.piximg = [[cdelt_deg[0] * pc[0][0], cdelt_deg[0] * pc[0][1]],
+                       [cdelt_deg[1] * pc[1][0], cdelt_deg[1] * pc[1][1]]]
+        self.imgpix = None if self.unity else matinv2(self.piximg)
+        # celset, zenithal: euler = (lng0, 90 - lat0, phiP, cos, sin)
+        self.e0 = crval_deg[0]
+        self.e1 = 90.0 - crval_deg[1]
+        self.e2 = lonpole
+        self.e4, self.e3 = sincosd(self.e1)   # e3 = cos(e1), e4 = sin(e1)
+
+    def p2s(self, px0, py0):
+        # astropy: pixcrd += 1 - origin; linp2x
+        t0 = (px0 + 1.0) - self.crpix[0]
+        t1 = (py0 + 1.0) - self.crpix[1]
+        if self.unity:
+            x = self.cdelt[0] * t0
+            y = self.cdelt[1] * t1
+        else:
+            x = 0.0; y = 0.0
+            x += self.piximg[0][0] * t0
+            y += self.piximg[1][0] * t0
+            x += self.piximg[0][1] * t1
+            y += self.piximg[1][1] * t1
+        # tanx2s
+        xj = x + 0.0
+        yj = y + 0.0
+        r = math.sqrt(xj * xj + yj * yj)
+        phi = 0.0 if r == 0.0 else atan2d(xj, -yj)
+        theta = atan2d(R2D, r)
+        # sphx2s
+        dphi = phi - self.e2
+        sinthe, costhe = sincosd(theta)
+        costhe3 = costhe * self.e3; costhe4 = costhe * self.e4
+        sinthe3 = sinthe * self.e3; sinthe4 = sinthe * self.e4
+        sinphi, cosphi = sincosd(dphi)
+        xx = sinthe4 - costhe3 * cosphi
+        if abs(xx) < 1e-5:
+            xx = -cosd(theta + self.e1) + costhe3 * (1.0 - cosphi)
+        yy = -costhe * sinphi
+        if xx != 0.0 or yy != 0.0:
+            dlng = atan2d(yy, xx)
+        else:
+            dlng = dphi + 180.0
+        lng = self.e0 + dlng
+        if self.e0 >= 0.0:
+            if lng < 0.0: lng += 360.0
+        else:
+            if lng > 0.0: lng -= 360.0
+        if lng > 360.0: lng -= 360.0
+        elif lng < -360.0: lng += 360.0
+        if math.fmod(dphi, 180.0) == 0.0:
+            lat = theta + cosphi * self.e1
+            if lat > 90.0: lat = 180.0 - lat
+            if lat < -90.0: lat = -180.0 - lat
+        else:
+            z = sinthe3 + costhe4 * cosphi
+            if abs(z) > 0.99:
+                lat = math.copysign(acosd(math.sqrt(xx * xx + yy * yy)), z)
+            else:
+                lat = asind(z)
+        return lng, lat
+
+    def s2p(self, lng, lat):
+        dlng = lng - self.e0
+        sinlat, coslat = sincosd(lat)
+        coslat3 = coslat * self.e3; coslat4 = coslat * self.e4
+        sinlat3 = sinlat * self.e3; sinlat4 = sinlat * self.e4
+        sinlng, coslng = sincosd(dlng)
+        xx = sinlat4 - coslat3 * coslng
+        if abs(xx) < 1e-5:
+            xx = -cosd(lat + self.e1) + coslat3 * (1.0 - coslng)
+        yy = -coslat * sinlng
+        if xx != 0.0 or yy != 0.0:
+            dphi = atan2d(yy, xx)
+        else:
+            dphi = dlng - 180.0
+        phi = math.fmod(self.e2 + dphi, 360.0)
+        if phi > 180.0: phi -= 360.0
+        elif phi < -180.0: phi += 360.0
+        if math.fmod(dlng, 180.0) == 0.0:
+            theta = lat + coslng * self.e1
+            if theta > 90.0: theta = 180.0 - theta
+            if theta < -90.0: theta = -180.0 - theta
+        else:
+            z = sinlat3 + coslat4 * coslng
+            if abs(z) > 0.99:
+                theta = math.copysign(acosd(math.sqrt(xx * xx + yy * yy)), z)
+            else:
+                theta = asind(z)
+        # tans2x
+        sinphi, cosphi = sincosd(phi)
+        s = sind(theta)
+        if s == 0.0:
+            return float("nan"), float("nan")
+        r = R2D * cosd(theta) / s
+        if s < 0.0:
+            return float("nan"), float("nan")
+        x = r * sinphi - 0.0
+        y = -r * cosphi - 0.0
+        # linx2p
+        if self.unity:
+            p0 = x / self.cdelt[0] + self.crpix[0]
+            p1 = y / self.cdelt[1] + self.crpix[1]
+        else:
+            p0 = 0.0
+            p0 += self.imgpix[0][0] * x
+            p0 += self.imgpix[0][1] * y
+            p0 += self.crpix[0]
+            p1 = 0.0
+            p1 += self.imgpix[1][0] * x
+            p1 += self.imgpix[1][1] * y
+            p1 += self.crpix[1]
+        return p0 - 1.0, p1 - 1.0
+
+
+    @classmethod
+    def from_header(cls, hdr):
+        u1 = unit_to_deg(hdr.get("CUNIT1", "deg"))
+        u2 = unit_to_deg(hdr.get("CUNIT2", "deg"))
+        return cls([float(hdr["CRPIX1"]), float(hdr["CRPIX2"])], [float(hdr["CDELT1"]) * u1, float(hdr["CDELT2"]) * u2],
+                   [float(hdr["CRVAL1"]) * u1, float(hdr["CRVAL2"]) * u2],
+                   [[float(hdr.get("PC1_1", 1.0)), float(hdr.get("PC1_2", 0.0))],
+                    [float(hdr.get("PC2_1", 0.0)), float(hdr.get("PC2_2", 1.0))]], float(hdr.get("LONPOLE", 180.0)))
+
+
+_WCS_KEYS = ("NAXIS1", "NAXIS2", "CRPIX1", "CRPIX2", "CRVAL1", "CRVAL2", "CDELT1", "CDELT2", "PC1_1", "PC1_2", "PC2_1",
+             "PC2_2", "CUNIT1", "CUNIT2", "LONPOLE", "CTYPE1")
+
+
+def same_wcs(h1, h2):
+    return all(h1.get(k) == h2.get(k) for k in _WCS_KEYS)
+
+
+def wcslib_roundtrip_perimeter(hdr, x, y):
+    """Overwrite, in place, the perimeter of the coordinate arrays (x, y) [naxis2][naxis1] of the map `hdr` -> `hdr`
+    with the values wcslib's pixel -> sky -> ang2pipi -> pixel chain returns (scalar, libm)."""
+    w = WcslibTan.from_header(hdr)
+    ny, nx = x.shape
+
+    def one(i, j):
+        lng, lat = w.p2s(float(i), float(j))
+        lng = float(ang2pipi(np.float64(lng)))
+        lat = float(ang2pipi(np.float64(lat)))
+        x[j, i], y[j, i] = w.s2p(lng, lat)
+
+    for i in range(nx):
+        one(i, 0)
+        one(i, ny - 1)
+    for j in range(1, ny - 1):
+        one(0, j)
+        one(nx - 1, j)
+
+
 class InvalidTransformError(ValueError):
     """wcslib celset: 'No valid solution for latp' (astropy.wcs raises InvalidTransformError)."""
 
@@ -418,7 +688,12 @@ def extract_coordinates_pixels(header_initial_to_project, header_target_projecti
     `header_initial_to_project`.  alignment.py:1038-1069 (non-sunpy branch)."""
     w_to = make_wcs(header_target_projection)
     lon, lat = extract_EUI_coordinates(header_initial_to_project)
-    return w_to.world_to_pixel(lon, lat)
+    x, y = w_to.world_to_pixel(lon, lat)
+    if isinstance(w_to, TanWCS) and same_wcs(header_initial_to_project, header_target_projection):
+        # identity up to wcslib's rounding noise: its sign decides the border pixels (see WcslibTan)
+        x, y = np.array(x, dtype=np.float64), np.array(y, dtype=np.float64)
+        wcslib_roundtrip_perimeter(header_initial_to_project, x, y)
+    return x, y
 
 
 # --------------------------------------------------------------------------------------

@@ -114,3 +114,30 @@ def test_helioprojective_full_size(gpu_handle, big_scene):
     self_corr = gpu_handle.sweep_helioprojective(hs, hs, ls).reshape(3, 3)
     assert abs(self_corr[1, 1] - 1.0) <= 1e-12
     assert np.argmax(self_corr) == 4 and (self_corr[self_corr != self_corr[1, 1]] < 1.0 - 1e-6).all()
+
+
+def test_zero_lag_full_size_measured(gpu_handle, big_scene):
+    """Config 2 size, README lag axes through exactly 0: the zero lag against the oracle (whose border decision is
+    wcslib's, border_golden.npz) at 1e-7, and the MEASURED weight of that decision at this size: the coefficient
+    with every border pixel kept (border_fix = 0) differs by less than 1e-4 -- 4 110 of 4 194 304 pixels -- and the
+    argmax is the same either way."""
+    from oracle import coreg_oracle as O
+    small, hs, large, hl, truth = big_scene
+    lags = (np.array([-1.0, 0.0, 17.0]), np.array([-9.0, 0.0, 1.0]), None, None, None)
+    got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags)
+    gpu_handle.set_option("border_fix", 0)
+    try:
+        raw = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, prepare=False)
+    finally:
+        gpu_handle.set_option("border_fix", 1)
+    st = H.oracle_state(small, hs, large, hl, lags)
+    O.set_initial_header_values(st)
+    sub = O.create_submap_of_large_data(st)
+    want0 = O.step(st, "helioprojective", st.data_small, sub, 0.0, 0.0, 0.0, 0.0, 0.0, 1.004)
+    assert abs(got[1, 1, 0, 0, 0, 0] - want0) <= 1e-7
+    d = np.abs(raw - got)
+    print(f"\\n[zero lag, 2048^2] |corr(all border kept) - corr(wcslib decision)| = {d[1, 1, 0, 0, 0, 0]:.3e}")
+    assert 0.0 < d[1, 1, 0, 0, 0, 0] < 1e-4
+    d[1, 1] = 0.0
+    assert d.max() == 0.0  # no other lag-point is touched
+    assert np.argmax(raw) == np.argmax(got) == np.ravel_multi_index((2, 0, 0, 0, 0, 0), got.shape)

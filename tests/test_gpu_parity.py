@@ -336,6 +336,44 @@ def test_cfg1_against_committed_golden(gpu_handle):
     H.assert_corr_close(got, g["carrington"], 1e-10, "cfg1 carrington vs golden")
     am = np.unravel_index(np.nanargmax(got), got.shape)
     assert (lags[0][am[0]], lags[1][am[1]]) == (truth["lag_crval1"], truth["lag_crval2"])
+    # BASELINE's own window, lag_crval1/2 in [-5, 5]: it contains the ZERO lag, whose border pixels on the sub-map path
+    # are decided by wcslib's rounding noise (golden made by the oracle's WcslibTan, pinned by border_golden.npz)
+    l0 = G.lags_baseline()
+    got = H.gpu_helio(gpu_handle, small, hs, large, hl, l0, serial_semantics=True)
+    H.assert_corr_close(got, g["serial0"], 1e-7, "cfg1 [-5,5] serial semantics vs golden")
+    got = H.gpu_helio(gpu_handle, small, hs, large, hl, l0)
+    H.assert_corr_close(got, g["parallel0"], 1e-7, "cfg1 [-5,5] parallel semantics vs golden")
+    assert abs(got[5, 5, 0, 0, 0, 0] - g["parallel0"][5, 5, 0, 0, 0, 0]) <= 1e-7  # the zero lag itself
+    got = H.gpu_carrington(gpu_handle, small, hs, large, hl, l0, (512, 512), (228.0, 262.0), (-12.0, 22.0))
+    H.assert_corr_close(got, g["carrington0"], 1e-10, "cfg1 [-5,5] carrington vs golden")
+
+
+def test_zero_lag_border_pixels_follow_wcslib(gpu_handle):
+    """The zero lag of the sub-map path (target header == shifted header): the map is the identity up to wcslib's
+    rounding noise and the sign of the noise decides, per border pixel, whether the bounds rule keeps it
+    (alignment.py:1038-1069, utils/Util.py:98-102).  The library evaluates the round trip of the border pixels with
+    wcslib's own arithmetic on the host and takes the dropped ones out of the six sums (k_border_fix): parity with
+    the oracle at 1e-7 on 50-pixel images, where every border pixel weighs 1e-3 of the coefficient, for both
+    orders, both methods, a rolled and an unrolled header and float32 / float64 pixels."""
+    for seed, crota, order, f32 in ((3, 3.0, 2, True), (4, 0.0, 1, False), (5, -27.5, 2, False)):
+        small, hs, large, hl, _ = H.scene(small_n=50, large_n=96, seed=seed, float32_exact=f32, nan_frac=0.01)
+        hs = dict(hs)
+        rho = np.deg2rad(crota)
+        hs["CROTA"] = crota
+        hs["PC1_1"] = hs["PC2_2"] = float(np.cos(rho))
+        hs["PC1_2"], hs["PC2_1"] = float(-np.sin(rho)), float(np.sin(rho))
+        lags = (np.array([-4.0, 0.0, 4.0]), np.array([0.0, -3.0]), None, None, [0.0, 0.5])
+        want = H.oracle_helio(small, hs, large, hl, lags, order=order)
+        got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order)
+        H.assert_corr_close(got, want, 1e-7, f"zero lag seed={seed}")
+        # without the fix the zero lag keeps every border pixel: visibly different at this size (the others agree)
+        gpu_handle.set_option("border_fix", 0)
+        try:
+            raw = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order)
+        finally:
+            gpu_handle.set_option("border_fix", 1)
+        d = np.abs(raw - want)
+        assert d[1, 0, 0, 0, 0, 0] > 1e-6 and np.delete(d.ravel(), np.ravel_multi_index((1, 0, 0, 0, 0, 0), d.shape)).max() <= 1e-7
 
 
 @pytest.mark.parametrize("order", [0, 3, 4, 5])

@@ -193,3 +193,52 @@ def test_car_composite_matches_wcslib(car_golden, tag):
     x, y = wb.world_to_pixel(lon, lat)
     assert np.abs(x - g[tag + "/x"]).max() <= 1e-9
     assert np.abs(y - g[tag + "/y"]).max() <= 1e-9
+
+
+BORDER_CASES = ["hri2048", "px50", "hri512", "spice", "far"]
+
+
+def _border_header(g, name):
+    h = dict(zip([str(k) for k in g[name + "/keys"]], [float(v) for v in g[name + "/vals"]]))
+    h["CUNIT1"] = h["CUNIT2"] = str(g[name + "/unit"])
+    h["NAXIS1"], h["NAXIS2"] = int(h["NAXIS1"]), int(h["NAXIS2"])
+    h["CTYPE1"], h["CTYPE2"] = "HPLN-TAN", "HPLT-TAN"
+    return h
+
+
+@pytest.mark.parametrize("name", BORDER_CASES)
+def test_wcslib_restatement_is_bit_exact_on_border_pixels(name):
+    """The zero lag of the sub-map path: pixel -> sky -> ang2pipi -> pixel with IDENTICAL headers is the identity up to
+    wcslib's rounding noise, whose sign decides the border pixels.  The oracle's scalar restatement of wcslib reproduces
+    astropy 4.3.1 / wcslib 7.6 BIT FOR BIT for every border pixel (sky coordinates, round-trip pixels, keep/drop)."""
+    import os
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "border_golden.npz"))
+    h = _border_header(g, name)
+    w = O.WcslibTan.from_header(h)
+    bx, by = g[name + "/bx"], g[name + "/by"]
+    step = 1 if bx.size < 3000 else 3  # every border pixel, or every third one of the 2048^2 image (pure-Python loop)
+    for k in range(0, bx.size, step):
+        lng, lat = w.p2s(float(bx[k]), float(by[k]))
+        assert lng == g[name + "/lon"][k] and lat == g[name + "/lat"][k], (name, k)
+        l2, b2 = float(O.ang2pipi(np.float64(lng))), float(O.ang2pipi(np.float64(lat)))
+        assert l2 == g[name + "/lon_pipi"][k] and b2 == g[name + "/lat_pipi"][k]
+        x, y = w.s2p(l2, b2)
+        assert x == g[name + "/rx"][k] and y == g[name + "/ry"][k], (name, k)
+    if not w.unity:
+        assert np.array_equal(np.array(w.imgpix), g[name + "/imgpix"])  # lin.c matinv restated
+    # about half of the border pixels fall to the bounds rule
+    n = int(g[name + "/dropped"].sum())
+    assert 0.4 * bx.size < n < 0.6 * bx.size
+
+
+def test_oracle_zero_lag_uses_wcslib_border_decision():
+    import os
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "border_golden.npz"))
+    h = _border_header(g, "px50")
+    x, y = O.extract_coordinates_pixels(h, dict(h))
+    bx, by = g["px50/bx"].astype(int), g["px50/by"].astype(int)
+    assert np.array_equal(x[by, bx], g["px50/rx"]) and np.array_equal(y[by, bx], g["px50/ry"])
+    drop = (x < 0) | (x > 49) | (y < 0) | (y > 49)
+    assert int(drop.sum()) == int(g["px50/dropped"].sum()) and not drop[1:-1, 1:-1].any()
