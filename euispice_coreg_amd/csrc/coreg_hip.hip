@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -111,8 +112,7 @@ struct coreg_handle {
     DevBuf up_f64, up_flag;  // upload staging on the device (float64 copy, exactness flag)
     // zero-lag border decision of the helioprojective sub-map path (geometry.hpp WcslibTan): grid pixels the
     // reference's wcslib round trip drops, cached per header
-    std::vector<double> border_key;
-    std::vector<int> border_dropped;
+    std::map<std::vector<double>, std::vector<int>> border_cache;
     DevBuf border_dev;
     PinBuf pin_border;
     int64_t opt_border_fix = 1;
@@ -550,9 +550,13 @@ void fill_precompute_common(coreg_handle* h, PrecomputeArgs* a, int tile_w) {
 
 // one sweep-kernel launch + finalize over n_batches * 256 slots whose parameters (SoA [np][n_slots]) and output
 // indices are already on the device
-struct BorderFix {
-    std::vector<long long> slots;  // slots (of this launch) whose lag is the identity map
-    int n_dropped = 0;             // pixels listed in h->border_dev
+struct BorderFix {  // lag-points of a launch whose border pixels are decided by wcslib's rounding noise
+    struct Item {
+        long long slot;  // slot of the launch
+        int first, n;    // its pixels in h->border_dev: [first, first + n)
+    };
+    std::vector<Item> items;
+    std::vector<int> pixels;  // concatenated linear grid indices (host copy of h->border_dev)
 };
 
 int launch_sweep(coreg_handle* h, int mode, int order, int method, const double* params_dev,
@@ -560,7 +564,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
                  const LaunchU* car_inv = nullptr, const BorderFix* fix = nullptr) {
     const long long n_slots = (long long)n_batches * kBlock;
     const int n_groups = pick_groups(h, n_batches, n_tiles);
-    const bool fixing = fix && !fix->slots.empty() && fix->n_dropped > 0;
+    const bool fixing = fix && !fix->items.empty();
     HIPCHK(h->partials.reserve((size_t)(n_groups + (fixing ? 1 : 0)) * kNumSums * n_slots * sizeof(double)));
 
     SweepArgs a;
@@ -654,8 +658,6 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
         b.H = h->sH;
         b.ref = h->ref.p;
         b.ref_f32 = h->ref_dtype == COREG_F32 ? 1 : 0;
-        b.dropped = h->border_dev.as<int>();
-        b.n_dropped = fix->n_dropped;
         b.gw = h->gW;
         b.order = order;
         b.round_f32 = mode == MODE_TRANSLATE ? 0 : 1;
@@ -663,8 +665,11 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
         b.pivots = h->pivots.as<double>();
         b.slab = slab;
         b.n_slots = n_slots;
-        for (long long sl : fix->slots) {
-            b.slot = sl;
+        for (const BorderFix::Item& it : fix->items) {
+            b.slot = it.slot;
+            b.dropped = h->border_dev.as<int>() + it.first;
+            b.n_dropped = it.n;
+            b.hom = params_dev;  // SoA [9][n_slots]: the (snapped) map of the slot gives the sample coordinates
             if (h->small_f32) hipLaunchKernelGGL((k_border_fix<float>), dim3(1), dim3(256), 0, h->stream, b);
             else hipLaunchKernelGGL((k_border_fix<double>), dim3(1), dim3(256), 0, h->stream, b);
         }
@@ -685,70 +690,107 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     return COREG_OK;
 }
 
-// Grid pixels of `hdr` (the target header == the shifted header of the zero lag) that the reference's round trip
-// pixel -> sky -> ang2pipi -> pixel (alignment.py:1038-1069) sends outside [0, W-1] x [0, H-1] of the image to align
-// (bounds rule of scipy's map_coordinates).  Only the perimeter can be affected (|eps| << 1 px).  Cached per header.
-int border_dropped_pixels(coreg_handle* h, const coreg_wcs2d& hdr, int* n_out) {
+// Zero-CRVAL lags of a helioprojective sweep share the target header's tangent point, so the map target pixel ->
+// shifted pixel is exactly affine, A = (CDELT' PC')^-1 (CDELT PC) about CRPIX.  When A leaves an image axis invariant
+// (the zero lag: A = I; a CDELT1-only lag: rows map to rows; CDELT2-only: columns to columns; `reference` CDELT
+// semantics: A = I up to the rebuilt PC's last bit) the border rows / columns of the grid sit ON the bounds rule
+// c < 0 or c > n-1 and what the reference does with them is decided by the rounding noise of its wcslib round trip
+// (alignment.py:1038-1069).  For such a lag the device map is SNAPPED to the exact invariant form (every border
+// pixel in bounds along that axis) and the pixels wcslib drops are listed for k_border_fix.
+struct AxisInvariance {
+    bool rows = false, cols = false;
+};
+AxisInvariance snap_invariant_axes(const coreg_wcs2d& target, const coreg_wcs2d& shifted, int gw, int gh, double hm[9]) {
+    AxisInvariance inv;
+    if (target.crval1 != shifted.crval1 || target.crval2 != shifted.crval2 || target.lonpole != shifted.lonpole ||
+        target.unit_to_deg != shifted.unit_to_deg)
+        return inv;
+    const Mat3 a = mat_mul(iwc_to_pix(shifted), pix_to_iwc(target));
+    const double tol = 1e-6;  // pixels, over the whole grid; rounding noise is < 1e-9, a real lag moves >> 1e-6
+    const double a00 = (double)a.m[0][0], a01 = (double)a.m[0][1], a02 = (double)a.m[0][2];
+    const double a10 = (double)a.m[1][0], a11 = (double)a.m[1][1], a12 = (double)a.m[1][2];
+    inv.rows = std::fabs(a10) * gw + std::fabs(a11 - 1.0) * gh + std::fabs(a12) < tol;
+    inv.cols = std::fabs(a00 - 1.0) * gw + std::fabs(a01) * gh + std::fabs(a02) < tol;
+    if (inv.rows || inv.cols) {
+        hm[0] = inv.cols ? 1.0 : a00;
+        hm[1] = inv.cols ? 0.0 : a01;
+        hm[2] = inv.cols ? 0.0 : a02;
+        hm[3] = inv.rows ? 0.0 : a10;
+        hm[4] = inv.rows ? 1.0 : a11;
+        hm[5] = inv.rows ? 0.0 : a12;
+        hm[6] = hm[7] = 0.0;
+        hm[8] = 1.0;
+    }
+    return inv;
+}
+
+// Pixels of the invariant border rows / columns that the reference's round trip pixel -> sky (target header) ->
+// ang2pipi -> pixel (shifted header) sends outside [0, W-1] x [0, H-1] of the image to align.  Appended to `out`.
+void wcslib_dropped_border_pixels(coreg_handle* h, const coreg_wcs2d& target, const coreg_wcs2d& shifted,
+                                  AxisInvariance inv, std::vector<int>* out) {
     const int gw = h->gW, gh = h->gH;
-    std::vector<double> key = {hdr.crpix1, hdr.crpix2, hdr.crval1, hdr.crval2, hdr.cdelt1, hdr.cdelt2, hdr.pc1_1,
-                               hdr.pc1_2, hdr.pc2_1, hdr.pc2_2, hdr.unit_to_deg, hdr.lonpole, (double)gw, (double)gh,
-                               (double)h->sW, (double)h->sH};
-    if (key != h->border_key || !h->border_dev.p) {
-        WcslibTan w;
-        w.init(hdr);
-        std::vector<int> per;  // perimeter, row-major
-        per.reserve(2 * (size_t)(gw + gh));
+    std::vector<double> key = {target.crpix1, target.crpix2, target.crval1, target.crval2, target.cdelt1, target.cdelt2,
+                               target.pc1_1, target.pc1_2, target.pc2_1, target.pc2_2, target.unit_to_deg, target.lonpole,
+                               shifted.crpix1, shifted.crpix2, shifted.cdelt1, shifted.cdelt2, shifted.pc1_1,
+                               shifted.pc1_2, shifted.pc2_1, shifted.pc2_2, (double)gw, (double)gh, (double)h->sW,
+                               (double)h->sH, inv.rows ? 1.0 : 0.0, inv.cols ? 1.0 : 0.0};
+    auto hit = h->border_cache.find(key);
+    if (hit == h->border_cache.end()) {
+        WcslibTan wf, wt;
+        wf.init(target);
+        wt.init(shifted);
+        std::vector<int> cand;  // row-major, each pixel once
+        const int jb = h->sH - 1, ib = h->sW - 1;
         for (int j = 0; j < gh; ++j) {
-            if (j == 0 || j == gh - 1) {
-                for (int i = 0; i < gw; ++i) per.push_back(j * gw + i);
-            } else {
-                per.push_back(j * gw);
-                if (gw > 1) per.push_back(j * gw + gw - 1);
+            const bool row = inv.rows && (j == 0 || j == jb);
+            if (row) {
+                for (int i = 0; i < gw; ++i) cand.push_back(j * gw + i);
+            } else if (inv.cols) {
+                cand.push_back(j * gw);
+                if (ib > 0 && ib < gw) cand.push_back(j * gw + ib);
             }
         }
-        std::vector<char> drop(per.size(), 0);
+        std::vector<char> drop(cand.size(), 0);
         const double wmax = (double)(h->sW - 1), hmax = (double)(h->sH - 1);
         auto work = [&](size_t lo, size_t hi) {
             for (size_t k = lo; k < hi; ++k) {
                 double x, y;
-                wcslib_pixel_to_pixel(w, w, (double)(per[k] % gw), (double)(per[k] / gw), &x, &y);
+                wcslib_pixel_to_pixel(wf, wt, (double)(cand[k] % gw), (double)(cand[k] / gw), &x, &y);
                 drop[k] = !((x >= 0.0) && (x <= wmax) && (y >= 0.0) && (y <= hmax));  // NaN -> dropped
             }
         };
         unsigned nt = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
-        if (per.size() < 2048) nt = 1;
+        if (cand.size() < 2048) nt = 1;
         if (nt <= 1) {
-            work(0, per.size());
+            work(0, cand.size());
         } else {
             std::vector<std::thread> th;
-            const size_t step = (per.size() + nt - 1) / nt;
+            const size_t step = (cand.size() + nt - 1) / nt;
             for (unsigned t = 0; t < nt; ++t) {
-                const size_t lo = std::min(per.size(), (size_t)t * step), hi = std::min(per.size(), lo + step);
+                const size_t lo = std::min(cand.size(), (size_t)t * step), hi = std::min(cand.size(), lo + step);
                 if (hi > lo) th.emplace_back(work, lo, hi);
             }
             for (auto& x : th) x.join();
         }
-        h->border_dropped.clear();
-        for (size_t k = 0; k < per.size(); ++k)
-            if (drop[k]) h->border_dropped.push_back(per[k]);
-        const size_t bytes = std::max<size_t>(1, h->border_dropped.size()) * sizeof(int);
-        HIPCHK(h->border_dev.reserve(bytes));
-        HIPCHK(hipStreamSynchronize(h->stream));  // an earlier sweep may still read the old list / staging
-        HIPCHK(h->pin_border.reserve(bytes));
-        std::memcpy(h->pin_border.p, h->border_dropped.data(), h->border_dropped.size() * sizeof(int));
-        if (!h->border_dropped.empty())
-            HIPCHK(hipMemcpyAsync(h->border_dev.p, h->pin_border.p, h->border_dropped.size() * sizeof(int),
-                                  hipMemcpyHostToDevice, h->stream));
-        h->border_key.swap(key);
+        std::vector<int> dropped;
+        for (size_t k = 0; k < cand.size(); ++k)
+            if (drop[k]) dropped.push_back(cand[k]);
+        if (h->border_cache.size() >= 64) h->border_cache.clear();
+        hit = h->border_cache.emplace(std::move(key), std::move(dropped)).first;
     }
-    *n_out = (int)h->border_dropped.size();
-    return COREG_OK;
+    out->insert(out->end(), hit->second.begin(), hit->second.end());
 }
 
-bool same_tan_wcs(const coreg_wcs2d& a, const coreg_wcs2d& b) {
-    return a.crpix1 == b.crpix1 && a.crpix2 == b.crpix2 && a.crval1 == b.crval1 && a.crval2 == b.crval2 &&
-           a.cdelt1 == b.cdelt1 && a.cdelt2 == b.cdelt2 && a.pc1_1 == b.pc1_1 && a.pc1_2 == b.pc1_2 &&
-           a.pc2_1 == b.pc2_1 && a.pc2_2 == b.pc2_2 && a.unit_to_deg == b.unit_to_deg && a.lonpole == b.lonpole;
+int upload_border_pixels(coreg_handle* h, const std::vector<int>& pixels) {
+    const size_t bytes = std::max<size_t>(1, pixels.size()) * sizeof(int);
+    HIPCHK(h->border_dev.reserve(bytes));
+    HIPCHK(hipStreamSynchronize(h->stream));  // an earlier sweep may still read the old list / the staging buffer
+    HIPCHK(h->pin_border.reserve(bytes));
+    std::memcpy(h->pin_border.p, pixels.data(), pixels.size() * sizeof(int));
+    if (!pixels.empty())
+        HIPCHK(hipMemcpyAsync(h->border_dev.p, h->pin_border.p, pixels.size() * sizeof(int), hipMemcpyHostToDevice,
+                              h->stream));
+    return COREG_OK;
 }
 
 int collect_stats(coreg_handle* h);
@@ -1564,10 +1606,6 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     double fx0 = 1e300, fx1 = -1e300, fy0 = 1e300, fy1 = -1e300;  // cull box in target pixels
     HomographyFamily fam;
     fam.init(*hdr_target, *hdr_small, lags->crval1, d.n1, lags->crval2, d.n2);
-    // a lag whose shifted header equals the target header (the zero lag of the sub-map path) needs the grid to be the
-    // image's own pixel grid
-    const bool identity_possible = h->opt_border_fix && h->gW == h->sW && h->gH == h->sH &&
-                                   hdr_target->naxis1 == h->sW && hdr_target->naxis2 == h->sH;
     BorderFix fix;
     const int i1_lo = (int)(lag_begin / row), i1_hi = (int)((lag_end - 1) / row);
     const double nanv = std::numeric_limits<double>::quiet_NaN();
@@ -1590,15 +1628,21 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                 for (int k = 0; k < 9; ++k) hm[k] = nanv;
             } else {
                 fam.get(B, slots.i1[s], slots.i2[s], hm);
-                if (identity_possible) {
+                if (h->opt_border_fix) {
                     coreg_wcs2d hl = hc;
                     hl.crval1 = hdr_small->crval1 + lags->crval1[slots.i1[s]];
                     hl.crval2 = hdr_small->crval2 + lags->crval2[slots.i2[s]];
-                    if (same_tan_wcs(hl, *hdr_target)) {
-                        // the target header IS this lag's header: identity map, border pixels decided as the
-                        // reference's wcslib round trip decides them (geometry.hpp WcslibTan, k_border_fix)
-                        for (int k = 0; k < 9; ++k) hm[k] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
-                        fix.slots.push_back((long long)(outidx.size() + s));
+                    // same tangent point as the target (sub-map path, zero CRVAL lag) and an invariant image axis:
+                    // exact invariant map on the device, border pixels decided as the reference's wcslib round trip
+                    // decides them (geometry.hpp WcslibTan, k_border_fix)
+                    const AxisInvariance inv = snap_invariant_axes(*hdr_target, hl, h->gW, h->gH, hm);
+                    if (inv.rows || inv.cols) {
+                        BorderFix::Item it;
+                        it.slot = (long long)(outidx.size() + s);
+                        it.first = (int)fix.pixels.size();
+                        wcslib_dropped_border_pixels(h, *hdr_target, hl, inv, &fix.pixels);
+                        it.n = (int)fix.pixels.size() - it.first;
+                        if (it.n > 0) fix.items.push_back(it);
                     }
                 }
             }
@@ -1656,7 +1700,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     pa.f0hi = std::ceil(fx1) + 3.0;
     pa.f1lo = std::floor(fy0) - 3.0;
     pa.f1hi = std::ceil(fy1) + 3.0;
-    if (!fix.slots.empty()) RETCHK(border_dropped_pixels(h, *hdr_target, &fix.n_dropped));
+    if (!fix.items.empty()) RETCHK(upload_border_pixels(h, fix.pixels));
     RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles, pick_groups(h, n_batches, n_tiles)));
     RETCHK(launch_sweep(h, sweep_mode, order, method, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
                         n_tiles, lag_begin, out_dev, nullptr, &fix));

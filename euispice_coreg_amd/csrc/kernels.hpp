@@ -1149,6 +1149,7 @@ struct BorderFixArgs {
     int round_f32;  // 1: sample rounded to float32 before the mask (alignment.py:1024)
     int residus;
     const double* pivots;
+    const double* hom;  // lane parameters of the launch, SoA [9][n_slots]: the slot's (snapped, affine) map
     double* slab;  // [kNumSums][n_slots], the extra slab
     long long n_slots, slot;
 };
@@ -1156,6 +1157,9 @@ template <typename TS>
 __global__ void __launch_bounds__(256) k_border_fix(const BorderFixArgs a) {
     __shared__ double red[256];
     const double pivot_a = a.pivots[0], pivot_b = a.pivots[1];
+    double hm[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) hm[k] = a.hom[(long long)k * a.n_slots + a.slot];
     double s[kNumSums];
 #pragma unroll
     for (int k = 0; k < kNumSums; ++k) s[k] = 0.0;
@@ -1165,7 +1169,10 @@ __global__ void __launch_bounds__(256) k_border_fix(const BorderFixArgs a) {
         const double araw = a.ref_f32 ? (double)((const float*)a.ref)[idx] : ((const double*)a.ref)[idx];
         if (!isfinite(araw)) continue;  // never entered the sums (k_precompute drops it)
         bool inb;
-        double v = spline_global_rt<TS>((const TS*)a.img, a.W, a.H, (double)i, (double)j, a.order, inb);
+        // the coordinates k_sweep used for this pixel (same fma order as apply_h_series with h6 = h7 = 0)
+        const double nx = fma(hm[0], (double)i, fma(hm[1], (double)j, hm[2]));
+        const double ny = fma(hm[3], (double)i, fma(hm[4], (double)j, hm[5]));
+        double v = spline_global_rt<TS>((const TS*)a.img, a.W, a.H, nx, ny, a.order, inb);
         if (!inb) continue;
         if (a.round_f32) v = (double)(float)v;
         if (a.residus) {

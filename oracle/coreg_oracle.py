@@ -482,32 +482,25 @@ class WcslibTan:
                     [float(hdr.get("PC2_1", 0.0)), float(hdr.get("PC2_2", 1.0))]], float(hdr.get("LONPOLE", 180.0)))
 
 
-_WCS_KEYS = ("NAXIS1", "NAXIS2", "CRPIX1", "CRPIX2", "CRVAL1", "CRVAL2", "CDELT1", "CDELT2", "PC1_1", "PC1_2", "PC2_1",
-             "PC2_2", "CUNIT1", "CUNIT2", "LONPOLE", "CTYPE1")
-
-
-def same_wcs(h1, h2):
-    return all(h1.get(k) == h2.get(k) for k in _WCS_KEYS)
-
-
-def wcslib_roundtrip_perimeter(hdr, x, y):
-    """Overwrite, in place, the perimeter of the coordinate arrays (x, y) [naxis2][naxis1] of the map `hdr` -> `hdr`
-    with the values wcslib's pixel -> sky -> ang2pipi -> pixel chain returns (scalar, libm)."""
-    w = WcslibTan.from_header(hdr)
-    ny, nx = x.shape
-
-    def one(i, j):
-        lng, lat = w.p2s(float(i), float(j))
+def wcslib_refine_near_bounds(hdr_from, hdr_to, x, y, tol=1e-6):
+    """Re-evaluate, in place, with wcslib's own arithmetic (scalar, libm) every coordinate of the map `hdr_from` pixels ->
+    `hdr_to` pixels that lies within `tol` px of the bounds 0 / NAXIS-1 of `hdr_to`: there the sign of wcslib's rounding
+    noise decides the bounds rule of map_coordinates, and nothing but wcslib's arithmetic reproduces it.  Structured
+    cases (whole border rows / columns): the zero lag of the sub-map path (identity), CDELT-only lags at zero CRVAL lag
+    (one axis invariant)."""
+    nx, ny = int(hdr_to["NAXIS1"]), int(hdr_to["NAXIS2"])
+    with np.errstate(invalid="ignore"):
+        near = (np.abs(x) < tol) | (np.abs(x - (nx - 1)) < tol) | (np.abs(y) < tol) | (np.abs(y - (ny - 1)) < tol)
+    jj, ii = np.nonzero(near)
+    if jj.size == 0:
+        return 0
+    wf, wt = WcslibTan.from_header(hdr_from), WcslibTan.from_header(hdr_to)
+    for j, i in zip(jj.tolist(), ii.tolist()):
+        lng, lat = wf.p2s(float(i), float(j))
         lng = float(ang2pipi(np.float64(lng)))
         lat = float(ang2pipi(np.float64(lat)))
-        x[j, i], y[j, i] = w.s2p(lng, lat)
-
-    for i in range(nx):
-        one(i, 0)
-        one(i, ny - 1)
-    for j in range(1, ny - 1):
-        one(0, j)
-        one(nx - 1, j)
+        x[j, i], y[j, i] = wt.s2p(lng, lat)
+    return int(jj.size)
 
 
 class InvalidTransformError(ValueError):
@@ -689,10 +682,10 @@ def extract_coordinates_pixels(header_initial_to_project, header_target_projecti
     w_to = make_wcs(header_target_projection)
     lon, lat = extract_EUI_coordinates(header_initial_to_project)
     x, y = w_to.world_to_pixel(lon, lat)
-    if isinstance(w_to, TanWCS) and same_wcs(header_initial_to_project, header_target_projection):
-        # identity up to wcslib's rounding noise: its sign decides the border pixels (see WcslibTan)
+    if isinstance(w_to, TanWCS) and "NAXIS1" in header_target_projection:
+        # coordinates ON the bounds rule are decided by wcslib's rounding noise (see WcslibTan)
         x, y = np.array(x, dtype=np.float64), np.array(y, dtype=np.float64)
-        wcslib_roundtrip_perimeter(header_initial_to_project, x, y)
+        wcslib_refine_near_bounds(header_initial_to_project, header_target_projection, x, y)
     return x, y
 
 
