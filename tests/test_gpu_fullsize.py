@@ -141,3 +141,153 @@ def test_zero_lag_full_size_measured(gpu_handle, big_scene):
     d[1, 1] = 0.0
     assert d.max() == 0.0  # no other lag-point is touched
     assert np.argmax(raw) == np.argmax(got) == np.ravel_multi_index((2, 0, 0, 0, 0, 0), got.shape)
+
+
+# ---- BASELINE.json configs 3, 4, 5 at their stated sizes ---------------------------------------------------------
+def _spot(st, frame, ref, lag5):
+    from oracle import coreg_oracle as O
+    d1, d2, dc1, dc2, dr = lag5
+    return O.step(st, frame, st.data_small, ref, d1, d2, dc1, dc2, dr, 1.004)
+
+
+def test_cfg3_carrington_121x121_full_size(gpu_handle, big_scene, carr_ready):
+    """configs[2]: HRIEUV-like 2048^2 vs FSI-like 3072^2 on a 2048 x 2048 Carrington grid, lag_crval1/2 in
+    [-60, 60] x 1 arcsec (121 x 121 = 14 641 lag-points)."""
+    from oracle import coreg_oracle as O
+    small, hs, large, hl, truth = big_scene
+    grid = carr_ready
+    l1 = l2 = np.arange(-60, 61, 1.0)
+    lags = (l1, l2, None, None, None)
+    full = _sweep(gpu_handle, hs, grid, lags)
+    assert full.shape == (121, 121, 1, 1, 1) and np.isfinite(full).all()
+    am = np.unravel_index(np.argmax(full), full.shape)
+    assert (l1[am[0]], l2[am[1]]) == (truth["lag_crval1"], truth["lag_crval2"])
+    # oracle spot checks: the peak, a corner of the lag plane, and (single-lag sweeps) a lag with crota and cdelt lags
+    st = H.oracle_state(small, hs, large, hl, lags, shape=list(SHAPE), lonlims=list(LON), latlims=list(LAT),
+                        solar_r=(1.004,))
+    O.set_initial_header_values(st)
+    ref = O.prepare_reference(st, "carrington", 1.004)
+    for i1, i2 in ((77, 51), (0, 120), (120, 3)):
+        want = _spot(st, "carrington", ref, (l1[i1], l2[i2], 0.0, 0.0, 0.0))
+        assert abs(full[i1, i2, 0, 0, 0] - want) <= 1e-10, (i1, i2)
+    one = _sweep(gpu_handle, hs, grid, ([-44.0], [52.0], [0.01], [-0.02], [0.3]))[0, 0, 0, 0, 0]
+    assert abs(one - _spot(st, "carrington", ref, (-44.0, 52.0, 0.01, -0.02, 0.3))) <= 1e-10
+    # LDS-window gather == global-memory gather on a strided lag subset; contiguous slices concatenate to the map
+    sub = (l1[::15], l2[::12], None, None, None)
+    a = _sweep(gpu_handle, hs, grid, sub)
+    gpu_handle.set_option("use_lds", 0)
+    try:
+        b = _sweep(gpu_handle, hs, grid, sub)
+    finally:
+        gpu_handle.set_option("use_lds", 1)
+    assert np.abs(a - b).max() <= 1e-13 and np.abs(a - full[::15, ::12]).max() <= 1e-12
+    n = full.size
+    cuts = [0, 1, 5000, 5001, 9999, n]
+    parts = [_sweep(gpu_handle, hs, grid, lags, lag_begin=lo, lag_end=hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
+    assert np.abs(np.concatenate(parts) - full.ravel()).max() <= 1e-12
+
+
+def test_tile_skip_identical_on_limb_crossing_full_size_grid(gpu_handle, big_scene):
+    """The provable whole-tile skip of k_precompute: same kept-point count and bit-identical map with the skip on and
+    off, on a 2048^2 grid that crosses the limb (lon 150..350, lat -89..89) -- for the default plan and for 256 x 4
+    and 4 x 256 tiles."""
+    from euispice_coreg_amd import _lib
+    small, hs, large, hl, truth = big_scene
+    grid = _lib.Grid((150.0, 350.0), (-89.0, 89.0), SHAPE)
+    gpu_handle.set_small(small)
+    gpu_handle.prepare_reference_carrington(large, hl, grid, 1.004, 2)
+    lags = (np.arange(5, 29, 3.0), np.arange(-21, 3, 3.0), None, None, [0.0, 0.3])
+    for tw in (0, 256, 4):
+        gpu_handle.set_option("tile_w", tw)
+        res = {}
+        try:
+            for skip in (1, 0):
+                gpu_handle.set_option("tile_skip", skip)
+                res[skip] = (_sweep(gpu_handle, hs, grid, lags), gpu_handle.last_stats()["n_active_points"])
+        finally:
+            gpu_handle.set_option("tile_skip", 1)
+            gpu_handle.set_option("tile_w", 0)
+        assert res[1][1] == res[0][1] > 0, tw
+        assert np.array_equal(res[1][0], res[0][0], equal_nan=True), tw
+    am = np.unravel_index(np.nanargmax(res[1][0]), res[1][0].shape)
+    assert (lags[0][am[0]], lags[1][am[1]], am[4]) == (truth["lag_crval1"], truth["lag_crval2"], 1)
+
+
+def test_cfg4_spice_like_61x61x21_full_size(gpu_handle):
+    """configs[3]: SPICE-like raster 192 x 832 (CDELT 4.0 x 1.098 arcsec, header in DEGREES) vs the FSI-like 3072^2
+    reference, helioprojective sub-map semantics, lag_crval1/2 in [-30, 30] arcsec, lag_crota in [-1, 1] x 0.1 deg:
+    61 x 61 x 21 = 78 141 lag-points."""
+    from euispice_coreg_amd import synthetic
+    from oracle import coreg_oracle as O
+    small, hs, large, hl, truth = synthetic.make_scene(small_shape=(832, 192), small_cdelt=(4.0, 1.098),
+                                                       small_unit="deg", large_n=3072)
+    l1 = l2 = np.arange(-30, 31, 1.0) / 3600.0  # header units (alignment.py:819-837 converts arcsec lags)
+    lr = np.round(np.arange(-10, 11) * 0.1, 10)
+    lags = (l1, l2, None, None, lr)
+    full = H.gpu_helio(gpu_handle, small, hs, large, hl, lags)
+    assert full.shape == (61, 61, 1, 1, 21, 1) and np.isfinite(full).all()
+    am = np.unravel_index(np.argmax(full), full.shape)
+    assert (am[0] - 30, am[1] - 30) == (truth["lag_crval1"], truth["lag_crval2"]) and abs(lr[am[4]] - 0.3) < 1e-9
+    st = H.oracle_state(small, hs, large, hl, lags, unit_lag="deg")
+    O.set_initial_header_values(st)
+    sub = O.create_submap_of_large_data(st)
+    for i1, i2, i5 in ((47, 21, 13), (0, 60, 0), (30, 30, 10), (58, 2, 20)):  # (30, 30, 10) is the zero lag
+        want = _spot(st, "helioprojective", sub, (l1[i1], l2[i2], 0.0, 0.0, lr[i5]))
+        assert abs(full[i1, i2, 0, 0, i5, 0] - want) <= 1e-7, (i1, i2, i5)
+    one = H.gpu_helio(gpu_handle, small, hs, large, hl, ([l1[40]], [l2[9]], [2e-6], [-1e-6], [0.4]), prepare=False)
+    assert abs(one.ravel()[0] - _spot(st, "helioprojective", sub, (l1[40], l2[9], 2e-6, -1e-6, 0.4))) <= 1e-7
+    subl = (l1[::12], l2[::10], None, None, lr[::5])
+    a = H.gpu_helio(gpu_handle, small, hs, large, hl, subl, prepare=False)
+    gpu_handle.set_option("use_lds", 0)
+    try:
+        b = H.gpu_helio(gpu_handle, small, hs, large, hl, subl, prepare=False)
+    finally:
+        gpu_handle.set_option("use_lds", 1)
+    assert np.abs(a - b).max() <= 1e-13 and np.abs(a - full[::12, ::10, :, :, ::5]).max() <= 1e-12
+    n = full.size
+    cuts = [0, 7, 30000, 30001, n]
+    parts = [H.gpu_helio(gpu_handle, small, hs, large, hl, lags, lag_begin=lo, lag_end=hi, prepare=False)
+             for lo, hi in zip(cuts[:-1], cuts[1:])]
+    assert np.abs(np.concatenate(parts) - full.ravel()).max() <= 1e-12
+
+
+def test_cfg5_five_d_sweep_4096_grid_full_size(gpu_handle, big_scene):
+    """configs[4]: 5-D sweep on a 4096 x 4096 Carrington grid: lag_crval1/2 in [-20, 20], lag_crota in [-0.5, 0.5] x
+    0.1, lag_cdelt1/2 in [-0.02, 0.02] x 0.01 -> 41 x 41 x 5 x 5 x 11 = 462 275 lag-points (about 2 s of GPU time)."""
+    from euispice_coreg_amd import _lib
+    from oracle import coreg_oracle as O
+    small, hs, large, hl, truth = big_scene
+    shape = (4096, 4096)
+    grid = _lib.Grid(LON, LAT, shape)
+    gpu_handle.set_small(small)
+    gpu_handle.prepare_reference_carrington(large, hl, grid, 1.004, 2)
+    l1 = l2 = np.arange(-20, 21, 1.0)
+    lc = np.round(np.arange(-2, 3) * 0.01, 10)
+    lr = np.round(np.arange(-5, 6) * 0.1, 10)
+    lags = (l1, l2, lc, lc, lr)
+    full = _sweep(gpu_handle, hs, grid, lags)
+    assert full.shape == (41, 41, 5, 5, 11) and np.isfinite(full).all()
+    am = np.unravel_index(np.argmax(full), full.shape)
+    assert (l1[am[0]], l2[am[1]], lc[am[2]], lc[am[3]]) == (truth["lag_crval1"], truth["lag_crval2"], 0.0, 0.0)
+    assert abs(lr[am[4]] - truth["lag_crota"]) < 1e-9
+    st = H.oracle_state(small, hs, large, hl, lags, shape=list(shape), lonlims=list(LON), latlims=list(LAT),
+                        solar_r=(1.004,))
+    O.set_initial_header_values(st)
+    ref = O.prepare_reference(st, "carrington", 1.004)
+    for idx in ((37, 11, 2, 2, 8), (0, 40, 0, 4, 10), (20, 20, 3, 1, 0)):
+        want = _spot(st, "carrington", ref, (l1[idx[0]], l2[idx[1]], lc[idx[2]], lc[idx[3]], lr[idx[4]]))
+        assert abs(full[idx] - want) <= 1e-10, idx
+    subl = (l1[::8], l2[::10], lc[::2], lc[1::3], lr[::5])
+    a = _sweep(gpu_handle, hs, grid, subl)
+    gpu_handle.set_option("use_lds", 0)
+    try:
+        b = _sweep(gpu_handle, hs, grid, subl)
+    finally:
+        gpu_handle.set_option("use_lds", 1)
+    assert np.abs(a - b).max() <= 1e-13
+    assert np.abs(a - full[::8, ::10, ::2, 1::3, ::5]).max() <= 1e-12
+    # slices of the raveled 5-D index (a rank's share on 8 GPUs is one of these)
+    n = full.size
+    lo = 3 * (-(-n // 8))
+    part = _sweep(gpu_handle, hs, grid, lags, lag_begin=lo, lag_end=lo + 4000)
+    assert np.abs(part - full.ravel()[lo:lo + 4000]).max() <= 1e-12
