@@ -156,6 +156,8 @@ def test_cfg3_carrington_121x121_full_size(gpu_handle, big_scene, carr_ready):
     from oracle import coreg_oracle as O
     small, hs, large, hl, truth = big_scene
     grid = carr_ready
+    gpu_handle.set_small(small)  # (the helioprojective tests above have replaced the session handle's images)
+    gpu_handle.prepare_reference_carrington(large, hl, grid, 1.004, 2)
     l1 = l2 = np.arange(-60, 61, 1.0)
     lags = (l1, l2, None, None, None)
     full = _sweep(gpu_handle, hs, grid, lags)
