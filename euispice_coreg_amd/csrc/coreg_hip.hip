@@ -1498,6 +1498,17 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
         L.n_batches = slots.n_batches;
         const Affine2 inv = car_native_to_pix(hc);
         L.inv = {inv.m00, inv.m01, inv.m10, inv.m11, inv.b0, inv.b1};
+        {
+            // curvature margin of k_sweep's corner boxes: over a tile of angular half-size s the map deviates from the
+            // box of its corners by at most ~ C s^2 / 2 radians, C = 1 + tan(latitude) <= 13 below 85 deg
+            const int th = kTilePts / plan.tile_w;
+            const double step = std::max(std::fabs(hdr_target->cdelt1), std::fabs(hdr_target->cdelt2)) *
+                                hdr_target->unit_to_deg * kDeg2Rad;
+            const double s_half = 0.5 * step * std::hypot((double)plan.tile_w, (double)th);
+            const double px_per_rad = 1.0 / (std::min(std::fabs(hc.cdelt1), std::fabs(hc.cdelt2)) * hc.unit_to_deg *
+                                             kDeg2Rad);
+            L.inv.box_margin = 1.0 + 0.5 * 13.0 * s_half * s_half * px_per_rad;
+        }
         const size_t pbase = params.size();
         params.resize(pbase + 9 * ns);
         for (size_t s = 0; s < ns; ++s) {

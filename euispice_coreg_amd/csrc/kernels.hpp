@@ -52,6 +52,7 @@ struct LaunchU {
     double m00, m01, m10, m11, b0, b1;  // MODE_CAR: native (phi, theta) [rad] -> 0-based pixel
     int order_rt;                       // ORDER == ORDER_RT kernels: the spline order (0..5)
     int pad_;
+    double box_margin;                  // MODE_CAR: pixels by which a tile's image may leave the box of its mapped corners
 };
 
 struct CarrDev {
@@ -113,6 +114,18 @@ __device__ __forceinline__ void apply_car(const H9& m, const LaunchU& u, double 
     sincos(phi, &sp, &cp);
     sincos(theta, &st, &ct);
     const double n0 = ct * cp, n1 = ct * sp, n2 = st;
+    const double q0 = fma(m.h[0], n0, fma(m.h[1], n1, m.h[2] * n2));
+    const double q1 = fma(m.h[3], n0, fma(m.h[4], n1, m.h[5] * n2));
+    const double q2 = fma(m.h[6], n0, fma(m.h[7], n1, m.h[8] * n2));
+    const double p = atan2(q1, q0);
+    const double t = atan2(q2, sqrt(fma(q0, q0, q1 * q1)));
+    ox = fma(u.m00, p, fma(u.m01, t, u.b0));
+    oy = fma(u.m10, p, fma(u.m11, t, u.b1));
+}
+// the same from the unit vector (n0, n1, n2) of the target pixel, which k_precompute stores for MODE_CAR (the two sincos
+// of apply_car are lag-independent)
+__device__ __forceinline__ void apply_car_vec(const H9& m, const LaunchU& u, double n0, double n1, double n2, double& ox,
+                                              double& oy) {
     const double q0 = fma(m.h[0], n0, fma(m.h[1], n1, m.h[2] * n2));
     const double q1 = fma(m.h[3], n0, fma(m.h[4], n1, m.h[5] * n2));
     const double q2 = fma(m.h[6], n0, fma(m.h[7], n1, m.h[8] * n2));
@@ -208,11 +221,13 @@ __device__ inline void spline_weights_rt(int order, double c, int& start, double
             w[2] = 1.0 - w[0] - w[1];
             break;
         }
+        // (orders 3..5: scipy divides by 6, 24, 12, 120; a float64 division costs ~30 instructions on this GPU, so the
+        // divisions are multiplications by the rounded reciprocal here: weights equal to scipy's to ~1 ulp)
         case 3: {
             const double z = 1.0 - y;
-            w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
-            w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) / 6.0;
-            w[0] = z * z * z / 6.0;
+            w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) * (1.0 / 6.0);
+            w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) * (1.0 / 6.0);
+            w[0] = z * z * z * (1.0 / 6.0);
             w[3] = 1.0 - w[0] - w[1] - w[2];
             break;
         }
@@ -220,27 +235,27 @@ __device__ inline void spline_weights_rt(int order, double c, int& start, double
             double t = y * y;
             w[2] = t * (t * 0.25 - 0.625) + 115.0 / 192.0;
             const double y1 = 1.0 + y;
-            w[1] = y1 * (y1 * (y1 * (5.0 - y1) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+            w[1] = y1 * (y1 * (y1 * (5.0 - y1) * (1.0 / 6.0) - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
             const double z = 1.0 - y;
-            w[3] = z * (z * (z * (5.0 - z) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+            w[3] = z * (z * (z * (5.0 - z) * (1.0 / 6.0) - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
             const double y2 = 0.5 - y;
             t = y2 * y2;
-            w[0] = t * t / 24.0;
+            w[0] = t * t * (1.0 / 24.0);
             w[4] = 1.0 - w[0] - w[1] - w[2] - w[3];
             break;
         }
         default: {  // 5
             double t = y * y;
-            w[2] = t * (t * (0.25 - y / 12.0) - 0.5) + 0.55;
+            w[2] = t * (t * (0.25 - y * (1.0 / 12.0)) - 0.5) + 0.55;
             const double z = 1.0 - y;
             t = z * z;
-            w[3] = t * (t * (0.25 - z / 12.0) - 0.5) + 0.55;
+            w[3] = t * (t * (0.25 - z * (1.0 / 12.0)) - 0.5) + 0.55;
             const double y1 = y + 1.0;
-            w[1] = y1 * (y1 * (y1 * (y1 * (y1 / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+            w[1] = y1 * (y1 * (y1 * (y1 * (y1 * (1.0 / 24.0) - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
             const double z1 = z + 1.0;
-            w[4] = z1 * (z1 * (z1 * (z1 * (z1 / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+            w[4] = z1 * (z1 * (z1 * (z1 * (z1 * (1.0 / 24.0) - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
             t = z * z;
-            w[0] = z * t * t / 120.0;
+            w[0] = z * t * t * (1.0 / 120.0);
             w[5] = 1.0 - w[0] - w[1] - w[2] - w[3] - w[4];
             break;
         }
@@ -270,6 +285,46 @@ __device__ inline double spline_global_rt(const TS* __restrict__ img, int W, int
         acc = fma(row, wy[a], acc);
     }
     return acc;
+}
+
+// The same sample from an LDS window whose apron (order/2 + 1 samples below, order - order/2 + 1 above, mirrored by the
+// staging loop) covers every tap of an in-bounds coordinate: lds[(gy - oy) * pitch + (gx - ox)] = image(mirror(gy, gx)).
+typedef const __attribute__((address_space(3))) double* LdsF64;
+// N x N taps, one row at a time: the N reads of a row are issued together (a tap-by-tap loop under a run-time order
+// serialises one LDS round trip per tap)
+template <int N>
+__device__ __forceinline__ double gather_rows_lds(LdsF64 p, int pitch, const double* wx, const double* wy) {
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+        double t[N];
+#pragma unroll
+        for (int b = 0; b < N; ++b) t[b] = p[a * pitch + b];
+        double row = 0.0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) row = fma(t[b], wx[b], row);
+        acc = fma(row, wy[a], acc);
+    }
+    return acc;
+}
+__device__ inline double spline_lds_rt(unsigned win, int pitch, int ox, int oy, double nx, double ny, int order) {
+    int sx, sy;
+    double wx[6], wy[6];
+    spline_weights_rt(order, nx, sx, wx);
+    spline_weights_rt(order, ny, sy, wy);
+#if defined(__HIP_DEVICE_COMPILE__)
+    LdsF64 p = (LdsF64)win + ((sy - oy) * pitch + (sx - ox));
+#else
+    LdsF64 p = (LdsF64)(uintptr_t)win + ((sy - oy) * pitch + (sx - ox));  // (host pass: never executed)
+#endif
+    switch (order) {  // (uniform)
+        case 0: return gather_rows_lds<1>(p, pitch, wx, wy);
+        case 1: return gather_rows_lds<2>(p, pitch, wx, wy);
+        case 2: return gather_rows_lds<3>(p, pitch, wx, wy);
+        case 3: return gather_rows_lds<4>(p, pitch, wx, wy);
+        case 4: return gather_rows_lds<5>(p, pitch, wx, wy);
+        default: return gather_rows_lds<6>(p, pitch, wx, wy);
+    }
 }
 
 // One sample of map_coordinates(order, mode='constant', prefilter=False) from global memory.
@@ -495,7 +550,7 @@ __global__ void __launch_bounds__(256) k_precompute(const PrecomputeArgs a) {
             av = (double)((const TA*)a.ref)[(size_t)gj * a.gw + gi];
             if (MODE == MODE_TRANSLATE) {
                 valid = carr_term(a.carr, gi, gj, b0, b1);
-            } else if (MODE == MODE_CAR) {
+            } else if (MODE == MODE_CAR) {  // native (phi, theta) [rad] of the target pixel
                 b0 = fma(a.car_fwd.m00, (double)gi, fma(a.car_fwd.m01, (double)gj, a.car_fwd.b0));
                 b1 = fma(a.car_fwd.m10, (double)gi, fma(a.car_fwd.m11, (double)gj, a.car_fwd.b1));
             } else {
@@ -517,6 +572,16 @@ __global__ void __launch_bounds__(256) k_precompute(const PrecomputeArgs a) {
             pt.b1 = b1;
             pt.a = a.residus ? av : av - pivot;
             pt.pad = a.residus ? 1.0 / sqrt(av) : 0.0;  // alignment.py:545 norm = sqrt(data_large)
+            if (MODE == MODE_CAR) {
+                // unit vector of the pixel (the lag-independent half of apply_car); the bounding box below stays in
+                // (phi, theta); method 'residus' recomputes 1/sqrt(a) in the sweep
+                double sp, cp, st, ct;
+                sincos(b0, &sp, &cp);
+                sincos(b1, &st, &ct);
+                pt.b0 = ct * cp;
+                pt.b1 = ct * sp;
+                pt.pad = st;
+            }
             a.pts[tbase + off + rank] = pt;
             mn0 = fmin(mn0, b0);
             mx0 = fmax(mx0, b0);
@@ -751,7 +816,8 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
             uy = pyw + b1;
         } else {
             double mx, my;
-            apply_map<MODE>(hm, cu, b0, b1, mx, my);
+            if (MODE == MODE_CAR) apply_car_vec(hm, cu, b0, b1, isa, mx, my);  // (b0, b1, isa) = unit vector
+            else apply_map<MODE>(hm, cu, b0, b1, mx, my);
             ux = mx + pxw;
             uy = my + pyw;
         }
@@ -798,7 +864,7 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
             bm = v;  // the window holds (pixel - pivot)
         }
         if (RESID) {
-            const double d = (av - (ROUND ? v : v + pivot_b)) * isa;
+            const double d = (av - (ROUND ? v : v + pivot_b)) * (MODE == MODE_CAR ? 1.0 / sqrt(av) : isa);
             if (isfinite(d)) {
                 acc.n += 1;
                 acc.b += d;
@@ -819,15 +885,20 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
         nx = px0 + b0;  // self.x + term, utils/rectify.py:362
         ny = py0 + b1;
     } else {
-        apply_map<MODE>(hm, cu, b0, b1, nx, ny);
+        if (MODE == MODE_CAR) apply_car_vec(hm, cu, b0, b1, isa, nx, ny);  // (b0, b1, isa) = unit vector
+        else apply_map<MODE>(hm, cu, b0, b1, nx, ny);
     }
     if (INTERIOR || ((nx >= 0.0) & (nx <= wmax) & (ny >= 0.0) & (ny <= hmax))) {
         int sx, sy;
         double wx[N], wy[N];
         double v = 0.0;
         if constexpr (ORDER == ORDER_RT) {
-            bool inb;
-            v = spline_global_rt<TS>(img, W, H, nx, ny, cu.order_rt, inb);
+            if constexpr (LDS) {
+                v = spline_lds_rt(win, pitch, ox, oy, nx, ny, cu.order_rt);
+            } else {
+                bool inb;
+                v = spline_global_rt<TS>(img, W, H, nx, ny, cu.order_rt, inb);
+            }
         } else if constexpr (LDS) {
             // tap addresses first, so that the reads are in flight while the weights are computed
             const double fx = floor(nx + (ORDER == 2 ? 0.5 : 0.0)), fy = floor(ny + (ORDER == 2 ? 0.5 : 0.0));
@@ -876,7 +947,7 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
         }
         if (RESID) {
             const double braw = (ROUND || !LDS) ? v : v + pivot_b;  // undo the pivot folded into the LDS window
-            const double d = (av - braw) * isa;
+            const double d = (av - braw) * (MODE == MODE_CAR ? 1.0 / sqrt(av) : isa);
             if (isfinite(d)) {
                 acc.n += 1;
                 acc.b += d;
@@ -1003,6 +1074,16 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
                 mny = fmin(mny, cy);
                 mxy = fmax(mxy, cy);
             }
+            if (MODE == MODE_CAR) {
+                // a rotation of the sphere followed by (atan2, asin) is not projective: the images of the corners do
+                // not bound the tile's image; the host supplies a curvature margin (sweep_car).  A tile that
+                // straddles the +-pi cut of atan2 maps its corners to both ends of the map: such a box is never
+                // "interior" and does not fit the LDS, so the visit takes the per-point global path.
+                mnx -= a.car_inv.box_margin;
+                mxx += a.car_inv.box_margin;
+                mny -= a.car_inv.box_margin;
+                mxy += a.car_inv.box_margin;
+            }
         }
         for (int o = 32; o > 0; o >>= 1) {
             mnx = fmin(mnx, __shfl_xor(mnx, o));
@@ -1027,20 +1108,23 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
         if (!(mxx >= 0.0) || !(mnx <= (double)(W - 1)) || !(mxy >= 0.0) || !(mny <= (double)(H - 1))) continue;
         // every (point, lag) of this visit inside the image?  (uniform; the box covers all non-padding lanes)
         const bool interior = (mnx >= 0.0) & (mxx <= (double)(W - 1)) & (mny >= 0.0) & (mxy <= (double)(H - 1));
-        // integer window with the mirrored apron: taps of in-bounds samples lie in [floor(c)-1, floor(c)+2]
-        const int ox = max((int)floor(fmax(mnx, 0.0)) - 1, -1);
-        const int oy = max((int)floor(fmax(mny, 0.0)) - 1, -1);
-        const int ex = min((int)floor(fmin(mxx, (double)(W - 1))) + 2, W);
-        const int ey = min((int)floor(fmin(mxy, (double)(H - 1))) + 2, H);
+        // integer window with the mirrored apron: taps of in-bounds samples lie in [floor(c)-1, floor(c)+2] (orders 1, 2);
+        // run-time orders: [floor(c) - order/2 - 1, floor(c) + order - order/2 + 1]
+        const int ap_lo = ORDER == ORDER_RT ? a.car_inv.order_rt / 2 + 1 : 1;
+        const int ap_hi = ORDER == ORDER_RT ? a.car_inv.order_rt - a.car_inv.order_rt / 2 + 1 : 2;
+        const int ox = max((int)floor(fmax(mnx, 0.0)) - ap_lo, ORDER == ORDER_RT ? -ap_lo : -1);
+        const int oy = max((int)floor(fmax(mny, 0.0)) - ap_lo, ORDER == ORDER_RT ? -ap_lo : -1);
+        const int ex = min((int)floor(fmin(mxx, (double)(W - 1))) + ap_hi, ORDER == ORDER_RT ? W - 1 + ap_hi : W);
+        const int ey = min((int)floor(fmin(mxy, (double)(H - 1))) + ap_hi, ORDER == ORDER_RT ? H - 1 + ap_hi : H);
         const int ww = ex - ox + 1, wh = ey - oy + 1;
         const int pitch = ww | 1;  // odd pitch: measured best for the ~2-pixel lag lattice (rejected layouts)
         const long long need = (long long)pitch * wh;
-        const bool in_lds = ORDER != ORDER_RT && a.use_lds && (need <= (long long)a.lds_elems);
+        const bool in_lds = a.use_lds && (need <= (long long)a.lds_elems);
 
         const Pt* __restrict__ pts = a.pts + (size_t)tile * kTilePts;
 
         bool swept = false;
-        if constexpr (ORDER != ORDER_RT) {
+        {
           if (in_lds) {
             swept = true;
             // Stage the window.  The loads are L2 round trips: kStage rows per wave are in flight at a time (one wave
@@ -1053,12 +1137,14 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
             for (int r0 = wave_u; r0 < wh; r0 += kWaves * kStage) {
                 for (int c0 = 0; c0 < ww; c0 += 64) {
                     const int c = c0 + lane;
-                    const int gx = mirror_idx(ox + min(c, ww - 1), W);
+                    // (the apron of the run-time orders can reach several samples past the edge: general reflection)
+                    const int gx = ORDER == ORDER_RT ? mirror_far(ox + min(c, ww - 1), W) : mirror_idx(ox + min(c, ww - 1), W);
                     TS v[kStage];
 #pragma unroll
                     for (int k = 0; k < kStage; ++k) {
                         const int r = min(r0 + k * kWaves, wh - 1);
-                        const TS* __restrict__ row = img + (size_t)mirror_idx(oy + r, H) * W;
+                        const int gy = ORDER == ORDER_RT ? mirror_far(oy + r, H) : mirror_idx(oy + r, H);
+                        const TS* __restrict__ row = img + (size_t)gy * W;
                         v[k] = row[gx];
                     }
                     if (c < ww) {
@@ -1074,18 +1160,23 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
                 }
             }
             __syncthreads();
-            if (interior) {
-                if (!pad_lane) {
-                    // window-relative lane constants (exact: a small integer is subtracted)
-                    const double offx = (ORDER == 2 ? 0.5 : 0.0) - (double)((ORDER == 2 ? 1 : 0) + ox);
-                    const double offy = (ORDER == 2 ? 0.5 : 0.0) - (double)((ORDER == 2 ? 1 : 0) + oy);
-                    const double pxw = MODE == MODE_TRANSLATE ? px0 + offx : offx;
-                    const double pyw = MODE == MODE_TRANSLATE ? py0 + offy : offy;
-                    tile_points<MODE, ORDER, TS, true, ROUND, RESID, true>(acc, win, img, pitch, ox, oy, W, H, px0, py0,
-                                                                           pxw, pyw, hm, a.car_inv, pts, p_begin, p_end, pivot_b,
-                                                                           pg);
+            bool done = false;
+            if constexpr (ORDER != ORDER_RT) {
+                if (interior) {
+                    done = true;
+                    if (!pad_lane) {
+                        // window-relative lane constants (exact: a small integer is subtracted)
+                        const double offx = (ORDER == 2 ? 0.5 : 0.0) - (double)((ORDER == 2 ? 1 : 0) + ox);
+                        const double offy = (ORDER == 2 ? 0.5 : 0.0) - (double)((ORDER == 2 ? 1 : 0) + oy);
+                        const double pxw = MODE == MODE_TRANSLATE ? px0 + offx : offx;
+                        const double pyw = MODE == MODE_TRANSLATE ? py0 + offy : offy;
+                        tile_points<MODE, ORDER, TS, true, ROUND, RESID, true>(acc, win, img, pitch, ox, oy, W, H, px0,
+                                                                               py0, pxw, pyw, hm, a.car_inv, pts, p_begin,
+                                                                               p_end, pivot_b, pg);
+                    }
                 }
-            } else {
+            }
+            if (!done) {
                 tile_points<MODE, ORDER, TS, true, ROUND, RESID>(acc, win, img, pitch, ox, oy, W, H, px0, py0, 0.0, 0.0, hm,
                                                                  a.car_inv, pts, p_begin, p_end, pivot_b, pg);
             }
