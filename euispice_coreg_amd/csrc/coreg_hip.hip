@@ -410,7 +410,13 @@ Plan choose_plan(coreg_handle* h, const Geometry& g, int m1, int n2, long long l
             }
         }
     }
-    return best_cost < std::numeric_limits<double>::max() ? best : fallback;
+    const Plan& r = best_cost < std::numeric_limits<double>::max() ? best : fallback;
+    if (std::getenv("COREG_DEBUG_PLAN"))
+        std::fprintf(stderr, "[coreg plan] tile %d x %d, lag patch %d x %d, window estimate %.0f of %lld elements; "
+                     "geometry d/di (%.3f, %.3f) d/dj (%.3f, %.3f) lag1 (%.3f, %.3f) lag2 (%.3f, %.3f)\n", r.tile_w,
+                     kTilePts / r.tile_w, r.sw, r.sh, r.window, lds_elems, g.dx_di, g.dy_di, g.dx_dj, g.dy_dj, g.ax, g.ay,
+                     g.bx, g.by);
+    return r;
 }
 
 // indices of the smallest, the most central and the largest value of a lag axis (any order, NaNs ignored)

@@ -184,3 +184,17 @@ def test_library_wcslib_chain_is_bit_exact_on_border_pixels(name):
     nx, ny = h["NAXIS1"], h["NAXIS2"]
     drop = ~((x >= 0) & (x <= nx - 1) & (y >= 0) & (y <= ny - 1))
     assert np.array_equal(drop, g[name + "/dropped"])
+
+
+def test_hand_issued_lds_reads_are_not_touched_before_their_wait():
+    """kernels.hpp Taps<N>: reads and s_waitcnt sit in separate inline-asm statements; the disassembly of the built
+    library must show no use of a tap register in between (csrc/check_isa.py, also run by build())."""
+    import subprocess
+    import sys
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("ROCm LLVM tools not installed")
+    from euispice_coreg_amd import _lib
+    chk = os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc", "check_isa.py")
+    p = subprocess.run([sys.executable, chk, _lib.LIB_PATH], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "hand-issued LDS read groups" in p.stdout
