@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
@@ -177,24 +178,87 @@ int device_mean(coreg_handle* h, const T* v, long long n, double* mean_dev) {
 }
 
 // host -> device through pinned staging: worker threads fill the staging buffer segment by segment while the DMA
-// engine drains the previous segment (a plain hipMemcpy from pageable memory runs at a fraction of the link rate)
-void parallel_memcpy(void* dst, const void* src, size_t bytes) {
-    const size_t min_per_thread = (size_t)2 << 20;
-    unsigned nt = (unsigned)std::min<size_t>(8, std::max<size_t>(1, bytes / min_per_thread));
-    const unsigned hw = std::thread::hardware_concurrency();
-    if (hw > 0) nt = std::min(nt, hw);
-    if (nt <= 1) {
-        std::memcpy(dst, src, bytes);
-        return;
+// engine drains the previous segment (a plain hipMemcpy from pageable memory runs at a fraction of the link rate).
+// The workers are a small persistent pool (creating threads per segment costs as much as the copy itself).
+class CopyPool {
+public:
+    static CopyPool& get() {
+        static CopyPool p;
+        return p;
     }
-    std::vector<std::thread> th;
-    const size_t per = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
-    for (unsigned t = 0; t < nt; ++t) {
-        const size_t lo = std::min(bytes, (size_t)t * per), hi = std::min(bytes, lo + per);
-        if (hi > lo) th.emplace_back([=] { std::memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
+    void copy(void* dst, const void* src, size_t bytes) {
+        const size_t min_per_thread = (size_t)512 << 10;
+        const unsigned nt = (unsigned)std::min<size_t>(workers_.size() + 1, std::max<size_t>(1, bytes / min_per_thread));
+        if (nt <= 1) {
+            std::memcpy(dst, src, bytes);
+            return;
+        }
+        std::lock_guard<std::mutex> use(use_);  // one parallel copy at a time
+        const size_t per = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            dst_ = (char*)dst;
+            src_ = (const char*)src;
+            bytes_ = bytes;
+            per_ = per;
+            n_parts_ = nt;
+            next_ = 1;  // part 0 is the caller's
+            pending_ = nt - 1;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        std::memcpy(dst, src, std::min(per, bytes));
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
     }
-    for (auto& x : th) x.join();
-}
+
+private:
+    CopyPool() {
+        const char* e = std::getenv("COREG_UPLOAD_THREADS");
+        int want = e ? std::atoi(e) : 0;
+        if (want <= 0) want = 12;
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw > 0) want = std::min<int>(want, (int)hw);
+        for (int i = 1; i < std::min(want, 64); ++i) workers_.emplace_back([this] { run(); });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void run() {
+        unsigned long long seen = 0;
+        for (;;) {
+            unsigned part;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && next_ < n_parts_); });
+                if (stop_) return;
+                part = next_++;
+                if (next_ >= n_parts_) seen = epoch_;
+            }
+            const size_t lo = std::min(bytes_, (size_t)part * per_), hi = std::min(bytes_, lo + per_);
+            if (hi > lo) std::memcpy(dst_ + lo, src_ + lo, hi - lo);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, use_;
+    std::condition_variable cv_, done_;
+    char* dst_ = nullptr;
+    const char* src_ = nullptr;
+    size_t bytes_ = 0, per_ = 0;
+    unsigned n_parts_ = 0, next_ = 0, pending_ = 0;
+    unsigned long long epoch_ = 0;
+    bool stop_ = false;
+};
+void parallel_memcpy(void* dst, const void* src, size_t bytes) { CopyPool::get().copy(dst, src, bytes); }
 
 int staged_upload(coreg_handle* h, void* dev, const void* host, size_t bytes) {
     // two staging buffers used alternately, each guarded by an event recorded behind its last copy: filling the
@@ -205,8 +269,14 @@ int staged_upload(coreg_handle* h, void* dev, const void* host, size_t bytes) {
     else HIPCHK(hipEventSynchronize(h->ev_img[k]));  // the upload that last used this buffer has left it
     HIPCHK(h->pin_img[k].reserve(bytes));
     char* pin = (char*)h->pin_img[k].p;
-    const size_t seg = (size_t)8 << 20;
-    for (size_t off = 0; off < bytes; off += seg) {
+    // segments: small at first so that the DMA engine starts early, then larger
+    static const size_t seg_max = [] {
+        const char* e = std::getenv("COREG_UPLOAD_SEGMENT_MIB");
+        const int v = e ? std::atoi(e) : 0;
+        return (size_t)(v > 0 ? v : 6) << 20;
+    }();
+    size_t seg = (size_t)2 << 20;
+    for (size_t off = 0; off < bytes; off += seg, seg = std::min(seg * 2, seg_max)) {
         const size_t len = std::min(seg, bytes - off);
         parallel_memcpy(pin + off, (const char*)host + off, len);
         HIPCHK(hipMemcpyAsync((char*)dev + off, pin + off, len, hipMemcpyHostToDevice, h->stream));
