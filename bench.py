@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement after the timed region")
     ap.add_argument("--cpu-sample", type=int, default=0, help="lag-points in the CPU sample (0 = 48 per core)")
     ap.add_argument("--use-lds", type=int, default=1)
+    ap.add_argument("--shard", choices=["auto", "lags", "points"], default="auto",
+                    help="N > 1: cut the lag plane in blocks (+ one all-gather) or the target grid in point shares "
+                         "(+ one all-reduce of the six sums per lag); auto = points below 512 lag-points per GPU")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -186,9 +189,16 @@ def main():
     lag2 = np.arange(-30, 30, 1, dtype=np.float64)
     lags = (lag1, lag2, None, None, None)
     L = lag1.size * lag2.size
-    lo1, hi1, lo2, hi2 = parallel.block_bounds(lag1.size, lag2.size, world, rank)
+    by_points = world > 1 and (args.shard == "points" or
+                               (args.shard == "auto" and parallel.use_point_sharding(L, world)))
+    if by_points:  # every rank sweeps ALL lag-points over its share of the grid
+        lo1, hi1, lo2, hi2 = 0, lag1.size, 0, lag2.size
+    else:
+        lo1, hi1, lo2, hi2 = parallel.block_bounds(lag1.size, lag2.size, world, rank)
     have_lags = hi1 > lo1 and hi2 > lo2
     perm_np, chunk = parallel.block_gather_index((lag1.size, lag2.size, 1, 1, 1), world)
+    if by_points:
+        perm_np, chunk = np.arange(L, dtype=np.int64), L
     n_streams = max(1, args.streams)
 
     if dry:
@@ -217,12 +227,16 @@ def main():
             # inputs resident in HBM before the timed region
             hk.set_small(small_m)
             hk.prepare_reference_carrington(large, hl, grid, SOLAR_R, ORDER)
+            if by_points:
+                hk.set_point_shard(rank, world)
             handles.append(hk)
         h = handles[0]
         my_lags = _lib.LagSet(lag1[lo1:hi1], lag2[lo2:hi2], None, None, None) if have_lags else None
 
     mine = [torch.full((chunk,), float("nan"), dtype=torch.float64, device=dev) for _ in range(n_streams)]
-    gathered = [torch.empty((chunk * world,), dtype=torch.float64, device=dev) if use_dist else m for m in mine]
+    gathered = [torch.empty((chunk * world,), dtype=torch.float64, device=dev) if use_dist and not by_points else m
+                for m in mine]
+    sums = [None] * n_streams  # point sharding: the six sums per lag slot, all-reduced (sized after the first sweep)
     perm = torch.from_numpy(perm_np).to(dev)
     sync()
     result = [None]
@@ -234,7 +248,11 @@ def main():
         if dry:
             if have_lags:
                 mine[k][:block.size] = torch.from_numpy(block)
-            if use_dist:
+            if by_points:  # stand-in for the sums: every rank contributes 1/world of the final values
+                t = mine[k] / world
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                result[0] = t
+            elif use_dist:
                 parts = [torch.empty(chunk, dtype=torch.float64) for _ in range(world)]
                 dist.all_gather(parts, mine[k])
                 result[0] = torch.cat(parts)[perm]
@@ -244,7 +262,19 @@ def main():
         with torch.cuda.stream(streams[k]):
             if have_lags:
                 handles[k].sweep_carrington(hs, grid, SOLAR_R, my_lags, order=ORDER, out_dev_ptr=mine[k].data_ptr())
-            if use_dist:
+            if by_points:
+                if sums[k] is None:
+                    sums[k] = torch.empty(handles[k].sums_size(), dtype=torch.float64, device="cuda")
+                if backend == "nccl":
+                    handles[k].copy_sums(sums[k].data_ptr())
+                    dist.all_reduce(sums[k], op=dist.ReduceOp.SUM)  # the ONE collective of this mode
+                    handles[k].finalize_sums(sums[k].data_ptr(), L, out_dev_ptr=mine[k].data_ptr())
+                else:
+                    t = torch.from_numpy(handles[k].copy_sums())
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                    handles[k].finalize_sums(t.numpy(), L, out_dev_ptr=mine[k].data_ptr())
+                result[0] = mine[k]
+            elif use_dist:
                 if backend == "nccl":
                     dist.all_gather_into_tensor(gathered[k], mine[k])  # the ONE collective of the path
                     result[0] = gathered[k][perm]
@@ -381,7 +411,8 @@ def main():
                                    "lags arange(-30,30,1) arcsec, small 2048^2 HRIEUV-like, ref 3072^2 FSI-like, "
                                    "order 2, solar_r 1.004",
                        "lag_points": L, "grid": list(GRID_SHAPE),
-                       "parallelism": f"lag-plane blocks x{world} + 1 all-gather ({backend})",
+                       "parallelism": (f"grid point shares x{world} + 1 all-reduce of the six sums per lag ({backend})"
+                                       if by_points else f"lag-plane blocks x{world} + 1 all-gather ({backend})"),
                        "resident": True, "sweeps_in_flight": n_streams,
                        "small_stored_f32": bool(stats["small_is_f32"]), "use_lds": bool(stats["used_lds"])},
             "one_sweep_in_flight": None if one_in_flight is None else

@@ -89,6 +89,9 @@ SYMBOLS = [
       C.c_int]),
     ("coreg_sweep_helioprojective", C.c_int,
      [_P, _WP, _WP, C.POINTER(Lags), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P, C.c_int]),
+    ("coreg_sums_size", C.c_int, [_P, C.POINTER(C.c_int64)]),
+    ("coreg_copy_sums", C.c_int, [_P, _P, C.c_int]),
+    ("coreg_finalize_sums", C.c_int, [_P, _P, C.c_int, _P, C.c_int]),
     ("coreg_last_stats", C.c_int, [_P, C.POINTER(Stats)]),
     ("coreg_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("coreg_shift_header", C.c_int,
@@ -353,6 +356,40 @@ class CoregHandle:
                                                         int(method), int(cdelt_semantics), int(lag_begin), lag_end,
                                                         _P(ptr), on_dev))
         return out
+
+    # -- multi-GPU point sharding (see include/coreg_hip.h, coreg_finalize_sums)
+    def set_point_shard(self, rank, world):
+        self.set_option("shard_world", int(world))
+        self.set_option("shard_rank", int(rank))
+
+    def sums_size(self) -> int:
+        n = C.c_int64(0)
+        self._chk(self._lib.coreg_sums_size(self._h, C.byref(n)))
+        return int(n.value)
+
+    def copy_sums(self, dst_ptr=None):
+        """The six sums per lag slot of the pending point-sharded sweep: into a device buffer (`dst_ptr`), or returned
+        as a host array."""
+        if dst_ptr is not None:
+            self._chk(self._lib.coreg_copy_sums(self._h, _P(int(dst_ptr)), 1))
+            return None
+        out = np.empty(self.sums_size(), dtype=np.float64)
+        self._chk(self._lib.coreg_copy_sums(self._h, out.ctypes.data, 0))
+        return out
+
+    def finalize_sums(self, sums, n_out, out_dev_ptr=None):
+        """Reduced sums (host array, or an int device pointer) -> coefficients of the pending sweep's lag slice."""
+        if isinstance(sums, np.ndarray):
+            sums = np.ascontiguousarray(sums, dtype=np.float64)
+            sptr, s_dev = sums.ctypes.data, 0
+        else:
+            sptr, s_dev = int(sums), 1
+        if out_dev_ptr is None:
+            out = np.empty(int(n_out), dtype=np.float64)
+            self._chk(self._lib.coreg_finalize_sums(self._h, _P(sptr), s_dev, out.ctypes.data, 0))
+            return out
+        self._chk(self._lib.coreg_finalize_sums(self._h, _P(sptr), s_dev, _P(int(out_dev_ptr)), 1))
+        return None
 
     def last_stats(self) -> dict:
         s = Stats()

@@ -117,6 +117,20 @@ struct coreg_handle {
     DevBuf border_dev;
     PinBuf pin_border;
     int64_t opt_border_fix = 1;
+    // multi-GPU point sharding (coreg_set_option "shard_world" / "shard_rank"): a sweep covers this rank's share of the
+    // tile groups and leaves the six sums per lag slot in `sums`; coreg_finalize_sums turns the all-reduced sums into
+    // coefficients
+    int64_t opt_shard_world = 1, opt_shard_rank = 0;
+    DevBuf sums;
+    long long sums_slots = 0;  // slots of the pending sharded sweep (all its launches)
+    struct PendingFinalize {
+        long long slot_off, n_slots, lag_begin;
+        const long long* outidx_dev;
+        int residus;
+    };
+    std::vector<PendingFinalize> pending_fin;
+    DevBuf fin_outidx;        // copy of the output indices of the pending sharded sweep
+    long long pending_n_out = 0;
 
     // options
     int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1;
@@ -575,6 +589,12 @@ void build_slots(const LagDims& d, long long c, long long begin, long long end, 
 int pick_groups(coreg_handle* h, int n_batches, int n_tiles) {
     // the compacted points are cut in n_groups EQUAL shares (k_tile_list), so n_groups * n_batches workgroups of equal
     // work: 256 groups make every round of 256 CUs full; fewer when there are many lag batches
+    if (h->opt_shard_world > 1) {
+        // point sharding: every rank takes a multiple of 8 groups (the XCD-aware block mapping of k_sweep), as close
+        // to one full round of 256 workgroups as the batch count allows
+        const long long per_rank = 8 * std::max<long long>(1, std::llround(256.0 / (8.0 * n_batches)));
+        return (int)std::min<long long>(per_rank * h->opt_shard_world, 1000 / (8 * h->opt_shard_world) * 8 * h->opt_shard_world);
+    }
     long long g = h->opt_n_groups > 0 ? h->opt_n_groups : (4096 + n_batches - 1) / n_batches;
     (void)n_tiles;
     g = std::max<long long>(8, std::min<long long>(h->opt_n_groups > 0 ? 1000 : 256, ((g + 7) / 8) * 8));
@@ -637,11 +657,15 @@ struct BorderFix {  // lag-points of a launch whose border pixels are decided by
 
 int launch_sweep(coreg_handle* h, int mode, int order, int method, const double* params_dev,
                  const long long* outidx_dev, int n_batches, int n_tiles, long long lag_begin, double* out_dev,
-                 const LaunchU* car_inv = nullptr, const BorderFix* fix = nullptr) {
+                 const LaunchU* car_inv = nullptr, const BorderFix* fix = nullptr, long long sums_off = 0) {
     const long long n_slots = (long long)n_batches * kBlock;
     const int n_groups = pick_groups(h, n_batches, n_tiles);
-    const bool fixing = fix && !fix->items.empty();
-    HIPCHK(h->partials.reserve((size_t)(n_groups + (fixing ? 1 : 0)) * kNumSums * n_slots * sizeof(double)));
+    const bool sharded = h->opt_shard_world > 1;
+    const int g_per = sharded ? n_groups / (int)h->opt_shard_world : n_groups;  // groups swept by this launch
+    const int g_lo = sharded ? g_per * (int)h->opt_shard_rank : 0;
+    // (the border correction is a property of the lag-point, not of a share of the grid: rank 0 carries it)
+    const bool fixing = fix && !fix->items.empty() && (!sharded || h->opt_shard_rank == 0);
+    HIPCHK(h->partials.reserve((size_t)(g_per + (fixing ? 1 : 0)) * kNumSums * n_slots * sizeof(double)));
 
     SweepArgs a;
     a.img = h->small.p;
@@ -658,6 +682,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     a.n_slots = n_slots;
     a.n_batches = n_batches;
     a.n_groups = n_groups;
+    a.group_lo = g_lo;
     a.partials = h->partials.as<double>();
     a.pivots = h->pivots.as<double>();
     a.use_lds = h->opt_use_lds ? 1 : 0;
@@ -669,7 +694,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     if (car_inv) a.car_inv = *car_inv;
     a.car_inv.order_rt = order;
 
-    const dim3 grid((unsigned)((long long)n_groups * n_batches)), block(kSweepThreads);
+    const dim3 grid((unsigned)((long long)g_per * n_batches)), block(kSweepThreads);
     EventPair* ev = next_event(h, h->ev_sweep, h->ev_sweep_used);
     if (!ev) return fail(h, COREG_EHIP, "hipEventCreate failed");
 #define SW(M, O, TS, R, Q)                                                                                          \
@@ -726,7 +751,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
 
     if (fixing) {
         // one more slab: zero, except minus the dropped border pixels' totals at the identity lag's slot
-        double* slab = h->partials.as<double>() + (size_t)n_groups * kNumSums * n_slots;
+        double* slab = h->partials.as<double>() + (size_t)g_per * kNumSums * n_slots;
         HIPCHK(hipMemsetAsync(slab, 0, (size_t)kNumSums * n_slots * sizeof(double), h->stream));
         BorderFixArgs b;
         b.img = h->small.p;
@@ -754,7 +779,23 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
 
     FinalizeArgs f;
     f.partials = h->partials.as<double>();
-    f.n_groups = n_groups + (fixing ? 1 : 0);
+    f.n_groups = g_per + (fixing ? 1 : 0);
+    f.part_stride = n_slots;
+    f.sums_out = nullptr;
+    f.sums_stride = f.sums_off = 0;
+    if (sharded) {
+        // leave this launch's six sums per slot in h->sums (reserved by the caller for all launches of the sweep)
+        f.sums_out = h->sums.as<double>();
+        f.sums_stride = h->sums_slots;
+        f.sums_off = sums_off;
+        coreg_handle::PendingFinalize pf;
+        pf.slot_off = sums_off;
+        pf.n_slots = n_slots;
+        pf.lag_begin = lag_begin;
+        pf.outidx_dev = nullptr;  // set by coreg_finalize_sums from fin_outidx
+        pf.residus = method == COREG_METHOD_RESIDUS ? 1 : 0;
+        h->pending_fin.push_back(pf);
+    }
     f.n_slots = n_slots;
     f.out_index = outidx_dev;
     f.lag_begin = lag_begin;
@@ -955,6 +996,22 @@ int upload_plan(coreg_handle* h, const std::vector<double>& params, const std::v
     return COREG_OK;
 }
 
+// point-sharded sweep (coreg_set_option "shard_world" > 1): room for the six sums of every slot of every launch, and a
+// private copy of the slots' output indices for coreg_finalize_sums
+int prepare_sharded(coreg_handle* h, size_t total_slots, long long n_out, long long lag_begin) {
+    h->pending_fin.clear();
+    h->sums_slots = 0;
+    h->pending_n_out = n_out;
+    (void)lag_begin;
+    if (h->opt_shard_world <= 1) return COREG_OK;
+    h->sums_slots = (long long)total_slots;
+    HIPCHK(h->sums.reserve(std::max<size_t>(1, total_slots) * kNumSums * sizeof(double)));
+    HIPCHK(h->fin_outidx.reserve(std::max<size_t>(1, total_slots) * sizeof(long long)));
+    HIPCHK(hipMemcpyAsync(h->fin_outidx.p, h->out_index.p, total_slots * sizeof(long long), hipMemcpyDeviceToDevice,
+                          h->stream));
+    return COREG_OK;
+}
+
 }  // namespace
 
 // =====================================================================================================================
@@ -1003,7 +1060,7 @@ void coreg_destroy(coreg_handle* h) {
     DevBuf* bufs[] = {&h->small, &h->ref, &h->pivots, &h->red_sum, &h->red_cnt, &h->t_sin_lon, &h->t_cos_lon,
                       &h->t_cos_lat, &h->t_sin_lat, &h->pts, &h->tile_count, &h->tile_list, &h->tile_cum, &h->group_first,
                       &h->tile_info, &h->tile_bbox, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
-                      &h->tmp_img, &h->up_f64, &h->up_flag, &h->border_dev};
+                      &h->tmp_img, &h->up_f64, &h->up_flag, &h->border_dev, &h->sums, &h->fin_outidx};
     for (DevBuf* b : bufs) b->release();
     h->pin_params.release();
     h->pin_outidx.release();
@@ -1062,6 +1119,13 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         h->opt_n_groups = value;
     } else if (n == "skew") {
         (void)value;  // accepted for compatibility: the LDS row skew was measured to lose and is gone
+    } else if (n == "shard_world") {
+        if (value < 1 || value > 64) return fail(h, COREG_EINVAL, "shard_world must be in [1, 64]");
+        h->opt_shard_world = value;
+        if (h->opt_shard_rank >= value) h->opt_shard_rank = 0;
+    } else if (n == "shard_rank") {
+        if (value < 0 || value >= h->opt_shard_world) return fail(h, COREG_EINVAL, "shard_rank must be in [0, shard_world)");
+        h->opt_shard_rank = value;
     } else if (n == "border_fix") {
         h->opt_border_fix = value ? 1 : 0;  // 0: the zero lag keeps every border pixel (exact identity map)
     } else if (n == "tile_skip") {
@@ -1450,6 +1514,7 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
     }
     if (launches.empty()) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
     RETCHK(upload_plan(h, params, outidx));
+    RETCHK(prepare_sharded(h, outidx.size(), n_out, lag_begin));
     for (const Launch& L : launches) {
         set_carr_common(&cd, L.cc);
         pa.carr = cd;
@@ -1471,7 +1536,8 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
         RETCHK(launch_precompute<MODE_TRANSLATE>(h, pa, n_tiles, pick_groups(h, L.n_batches, n_tiles)));
         // SoA block of this launch starts at 2 * slot_off doubles (every earlier launch contributed 2 per slot)
         RETCHK(launch_sweep(h, MODE_TRANSLATE, order, method, h->lane_params.as<double>() + 2 * L.slot_off,
-                            h->out_index.as<long long>() + L.slot_off, L.n_batches, n_tiles, lag_begin, out_dev));
+                            h->out_index.as<long long>() + L.slot_off, L.n_batches, n_tiles, lag_begin, out_dev, nullptr,
+                            nullptr, (long long)L.slot_off));
     }
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }
@@ -1597,6 +1663,7 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
     }
     if (launches.empty()) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
     RETCHK(upload_plan(h, params, outidx));
+    RETCHK(prepare_sharded(h, outidx.size(), n_out, lag_begin));
 
     PrecomputeArgs pa;
     std::memset(&pa, 0, sizeof(pa));
@@ -1620,7 +1687,7 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
         last_groups = ng;
         RETCHK(launch_sweep(h, MODE_CAR, order, method, h->lane_params.as<double>() + 9 * L.slot_off,
                             h->out_index.as<long long>() + L.slot_off, L.n_batches, n_tiles, lag_begin, out_dev,
-                            &L.inv));
+                            &L.inv, nullptr, (long long)L.slot_off));
     }
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }
@@ -1772,6 +1839,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     // 1/(1 + eps) = 1 - eps + eps^2 is exact to float64 below ~4e-6 (eps^3 < 1e-16); wider fields divide exactly
     const int sweep_mode = (h->opt_h_series && eps_max < 4.0e-6) ? MODE_HOMOGRAPHY_SERIES : MODE_HOMOGRAPHY;
     RETCHK(upload_plan(h, params, outidx));
+    RETCHK(prepare_sharded(h, outidx.size(), n_out, lag_begin));
 
     PrecomputeArgs pa;
     std::memset(&pa, 0, sizeof(pa));
@@ -1792,6 +1860,66 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     RETCHK(launch_sweep(h, sweep_mode, order, method, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
                         n_tiles, lag_begin, out_dev, nullptr, &fix));
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+}
+
+int coreg_sums_size(coreg_handle* h, int64_t* n_doubles) {
+    if (!h || !n_doubles) return COREG_EINVAL;
+    *n_doubles = (int64_t)h->sums_slots * kNumSums;
+    return COREG_OK;
+}
+
+int coreg_copy_sums(coreg_handle* h, double* dst, int dst_on_device) {
+    if (!h || !dst) return COREG_EINVAL;
+    if (h->sums_slots <= 0 || h->pending_fin.empty()) return fail(h, COREG_ESTATE, "no point-sharded sweep is pending");
+    RETCHK(bind_device(h));
+    const size_t bytes = (size_t)h->sums_slots * kNumSums * sizeof(double);
+    HIPCHK(hipMemcpyAsync(dst, h->sums.p, bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                          h->stream));
+    if (!dst_on_device) HIPCHK(hipStreamSynchronize(h->stream));
+    return COREG_OK;
+}
+
+int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device, double* corr_out, int out_on_device) {
+    if (!h || !sums) return COREG_EINVAL;
+    if (h->sums_slots <= 0 || h->pending_fin.empty()) return fail(h, COREG_ESTATE, "no point-sharded sweep is pending");
+    if (!corr_out && h->pending_n_out > 0) return fail(h, COREG_EINVAL, "corr_out is null");
+    RETCHK(bind_device(h));
+    const long long n_out = h->pending_n_out;
+    const size_t bytes = (size_t)h->sums_slots * kNumSums * sizeof(double);
+    if ((const void*)sums != h->sums.p)
+        HIPCHK(hipMemcpyAsync(h->sums.p, sums, bytes, sums_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                              h->stream));
+    double* out_dev = corr_out;
+    if (!out_on_device) {
+        HIPCHK(h->out_dev.reserve((size_t)std::max<long long>(n_out, 1) * sizeof(double)));
+        out_dev = h->out_dev.as<double>();
+    }
+    if (n_out > 0) {
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, h->stream, out_dev,
+                           (long long)n_out, std::numeric_limits<double>::quiet_NaN());
+        HIPCHK(hipGetLastError());
+    }
+    for (const coreg_handle::PendingFinalize& pf : h->pending_fin) {
+        FinalizeArgs f;
+        f.partials = h->sums.as<double>() + pf.slot_off;
+        f.n_groups = 1;
+        f.n_slots = pf.n_slots;
+        f.part_stride = h->sums_slots;
+        f.out_index = h->fin_outidx.as<long long>() + pf.slot_off;
+        f.lag_begin = pf.lag_begin;
+        f.out = out_dev;
+        f.residus = pf.residus;
+        f.n_required = (long long)h->gW * h->gH;
+        f.sums_out = nullptr;
+        f.sums_stride = f.sums_off = 0;
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned)((pf.n_slots + 63) / 64)), dim3(64 * kFinLanes), 0, h->stream, f);
+    }
+    HIPCHK(hipGetLastError());
+    if (!out_on_device && n_out > 0) {
+        HIPCHK(hipMemcpyAsync(corr_out, out_dev, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return COREG_OK;
 }
 
 int coreg_last_stats(coreg_handle* h, coreg_stats* out) {

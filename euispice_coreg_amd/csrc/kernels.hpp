@@ -713,8 +713,9 @@ struct SweepArgs {
     const double* lane_params;  // SoA [NP][n_slots]; TRANSLATE: X0, Y0; HOMOGRAPHY: h0..h8
     long long n_slots;          // n_batches * 256
     int n_batches;
-    int n_groups;  // multiple of 8
-    double* partials;  // [n_groups][kNumSums][n_slots]
+    int n_groups;  // multiple of 8: the compacted points are cut in n_groups equal shares
+    int group_lo;  // first group this launch sweeps (multi-GPU point sharding: a rank's share of the groups; else 0)
+    double* partials;  // [groups of this launch][kNumSums][n_slots]
     const double* pivots;  // device: [0] mean(reference) (already subtracted in aval), [1] mean(small image)
     int use_lds;
     int lds_elems;     // capacity of the dynamic LDS window in float64 elements
@@ -1010,7 +1011,7 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
     const int slot8 = b & 7;
     const int q = b >> 3;
     const int batch = q % a.n_batches;
-    const int group = (q / a.n_batches) * 8 + slot8;
+    const int group = a.group_lo + (q / a.n_batches) * 8 + slot8;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pg = __builtin_amdgcn_readfirstlane(threadIdx.x / kBlock);  // point-group of this wave (uniform)
@@ -1212,7 +1213,7 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
             sbb += st[4 * kBlock];
             sab += st[5 * kBlock];
         }
-        double* out = a.partials + (size_t)group * kNumSums * a.n_slots + slot;
+        double* out = a.partials + (size_t)(group - a.group_lo) * kNumSums * a.n_slots + slot;
         out[0] = sn;
         out[a.n_slots] = sa;
         out[2 * a.n_slots] = sb;
@@ -1305,6 +1306,12 @@ struct FinalizeArgs {
     double* out;  // [lag_end - lag_begin]
     int residus;          // 1: np.std((A - B) / sqrt(A)) over ALL grid points (alignment.py:544-547)
     long long n_required;  // residus: number of grid points G; fewer contributions -> NaN (no mask in that method)
+    // multi-GPU point sharding: instead of the coefficient, write the six sums of this rank's groups to
+    // sums_out[k * sums_stride + sums_off + slot] (all-reduced over the ranks, then finalised by a second call with
+    // n_groups = 1 and partials = the reduced sums)
+    double* sums_out;
+    long long sums_stride, sums_off;
+    long long part_stride;  // distance between the six sums of a slab (n_slots, or sums_stride when reading reduced sums)
 };
 constexpr int kFinLanes = 16;  // threads per lag slot in k_finalize
 __global__ void __launch_bounds__(64 * kFinLanes) k_finalize(const FinalizeArgs a) {
@@ -1317,9 +1324,9 @@ __global__ void __launch_bounds__(64 * kFinLanes) k_finalize(const FinalizeArgs 
     for (int k = 0; k < kNumSums; ++k) s[k] = 0.0;
     if (slot < a.n_slots) {
         for (int g = j; g < a.n_groups; g += kFinLanes) {
-            const double* p = a.partials + (size_t)g * kNumSums * a.n_slots + slot;
+            const double* p = a.partials + (size_t)g * kNumSums * a.part_stride + slot;
 #pragma unroll
-            for (int k = 0; k < kNumSums; ++k) s[k] += p[(size_t)k * a.n_slots];
+            for (int k = 0; k < kNumSums; ++k) s[k] += p[(size_t)k * a.part_stride];
         }
     }
     if (j > 0) {
@@ -1328,12 +1335,17 @@ __global__ void __launch_bounds__(64 * kFinLanes) k_finalize(const FinalizeArgs 
     }
     __syncthreads();
     if (j != 0 || slot >= a.n_slots) return;
-    const long long idx = a.out_index[slot];
-    if (idx < 0) return;
     for (int g = 0; g < kFinLanes - 1; ++g) {
 #pragma unroll
         for (int k = 0; k < kNumSums; ++k) s[k] += red[g][k][ls];
     }
+    if (a.sums_out) {
+#pragma unroll
+        for (int k = 0; k < kNumSums; ++k) a.sums_out[(size_t)k * a.sums_stride + a.sums_off + slot] = s[k];
+        return;
+    }
+    const long long idx = a.out_index[slot];
+    if (idx < 0) return;
     const double n = s[0];
     double r = __builtin_nan("");
     if (a.residus) {

@@ -314,6 +314,10 @@ class Alignment:
         sem = _lib.CDELT_INTENDED if self.cdelt_semantics == "intended" else _lib.CDELT_REFERENCE
         solar_rs = np.atleast_1d(np.asarray(self.lag_solar_r, dtype=np.float64))
         lo, hi, chunk = parallel.shard_bounds(lags.size, world, rank)
+        # few lag-points per GPU: shard the grid instead of the lags (one all-reduce of the six sums per lag)
+        by_points = parallel.use_point_sharding(lags.size, world)
+        if by_points:
+            lo, hi = 0, lags.size
         out = np.full(lags.shape + (len(solar_rs),), np.nan)
         for kk, solar_r in enumerate(solar_rs):
             if self.coordinate_frame == "final_carrington":
@@ -322,14 +326,17 @@ class Alignment:
                 if tag is None or tag != h.reference_tag:
                     h.prepare_reference_carrington(self._large_pixels(), self.hdr_large, grid, solar_r, self.order)
                     h.reference_tag = tag
-                part = h.sweep_carrington(self.hdr_small, grid, solar_r, lags, order=self.order, method=method,
-                                          cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
+                def run(g=grid, sr=solar_r):
+                    return h.sweep_carrington(self.hdr_small, g, sr, lags, order=self.order, method=method,
+                                              cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
             elif self.coordinate_frame == "initial_carrington":
                 # the reference map on its own grid, float32 (alignment.py:372); neither the parallel nor the serial
                 # branch of the reference builds a sub-map for this frame (:649, :765)
                 h.set_reference_on_grid(np.asarray(self._large_pixels(), dtype=np.float32))
-                part = h.sweep_helioprojective(self.hdr_large, self.hdr_small, lags, order=self.order, method=method,
-                                               cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
+
+                def run():
+                    return h.sweep_helioprojective(self.hdr_large, self.hdr_small, lags, order=self.order,
+                                                   method=method, cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
             else:
                 if self.parallelism:
                     h.prepare_reference_helioprojective(self._large_pixels(), self.hdr_large, self.hdr_small,
@@ -338,10 +345,15 @@ class Alignment:
                 else:
                     h.set_reference_on_grid(np.asarray(self._large_pixels(), dtype=np.float64))  # quirk Q1: float64
                     target = self.hdr_large
-                part = h.sweep_helioprojective(target, self.hdr_small, lags, order=self.order, method=method,
-                                               cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
-            if world > 1:
-                part = parallel.allgather_lag_slices(part, lags.size).cpu().numpy()
+                def run(t=target):
+                    return h.sweep_helioprojective(t, self.hdr_small, lags, order=self.order, method=method,
+                                                   cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
+            if by_points:
+                part = parallel.point_sharded_sweep(h, run, lags.size)
+            else:
+                part = run()
+                if world > 1:
+                    part = parallel.allgather_lag_slices(part, lags.size).cpu().numpy()
             out[..., kk] = np.asarray(part).reshape(lags.shape)
         self.last_stats = h.last_stats()
         return out

@@ -5,6 +5,10 @@ partition `np.array_split`-style fan-out the reference applies to its worker pro
 (hdrshift/alignment.py:677-687) -- every rank sweeps its slice on its own GPU with full replicas of both images,
 and ONE all-gather of the per-lag coefficients (a few KB) assembles the correlation map on every rank.
 There is no other data-path collective.
+
+Sweeps with few lag-points per GPU (less than two 256-lag batches each) shard the GRID instead (SURVEY 8e fallback):
+every rank sweeps all the lag-points over its share of the target grid's points and ONE all-reduce(SUM) of the six
+Pearson sums per lag slot replaces the all-gather (`point_sharded_sweep`).
 """
 from __future__ import annotations
 
@@ -107,3 +111,38 @@ def allgather_lag_slices(local, n_lags: int, group=None):
     # rank r's valid part is [r*chunk, r*chunk + len_r): with chunk = ceil(n/world) the concatenation of the valid
     # parts is simply the first n_lags elements when only the LAST non-empty slice is ragged -- which is the case here
     return out[:n_lags]
+
+
+POINT_SHARD_MAX_LAGS_PER_RANK = 512  # below two full 256-lag batches per GPU the grid is sharded instead of the lags
+
+
+def use_point_sharding(n_lags: int, world: int) -> bool:
+    return world > 1 and n_lags < POINT_SHARD_MAX_LAGS_PER_RANK * world
+
+
+def point_sharded_sweep(handle, run_sweep, n_out, group=None, out_dev_ptr=None):
+    """Grid-sharded sweep: `run_sweep()` must call handle.sweep_*(...) over the WHOLE lag range wanted; this rank's
+    share of the grid is selected here, the six sums per lag slot are all-reduced (the one collective of this mode) and
+    finalised.  Returns the coefficients (numpy, C-order lag slice) or fills `out_dev_ptr`."""
+    import torch
+    import torch.distributed as dist
+    rank, world = world_info(group)
+    handle.set_point_shard(rank, world)
+    try:
+        run_sweep()
+        if world == 1:
+            return handle.finalize_sums(handle.copy_sums(), n_out, out_dev_ptr)
+        backend = dist.get_backend(group)
+        n = handle.sums_size()
+        if backend == "nccl":
+            buf = torch.empty(n, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+            handle.copy_sums(buf.data_ptr())  # stream-ordered on the handle's stream
+            handle.synchronize()
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.current_stream().synchronize()
+            return handle.finalize_sums(buf.data_ptr(), n_out, out_dev_ptr)
+        buf = torch.from_numpy(handle.copy_sums())
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        return handle.finalize_sums(buf.numpy(), n_out, out_dev_ptr)
+    finally:
+        handle.set_point_shard(0, 1)

@@ -185,6 +185,20 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                                 const coreg_lags* lags, int order, int method, int cdelt_semantics,
                                 int64_t lag_begin, int64_t lag_end, double* corr_out, int out_on_device);
 
+/* Multi-GPU sharding of the GRID instead of the lag range, for sweeps with few lag-points per GPU (SURVEY 8e fallback):
+ * with coreg_set_option(h, "shard_world", W) and ("shard_rank", r) a sweep call covers ALL its lag-points over rank
+ * r's share of the target grid's points (tile groups r*G/W .. (r+1)*G/W of k_sweep's work partition, identical on
+ * every rank) and, instead of coefficients, leaves the six sums n, Sa, Sb, Saa, Sbb, Sab of every lag slot on the
+ * device (corr_out of the sweep call is only NaN-filled).  The caller adds the ranks' sums element-wise -- one
+ * all-reduce(SUM) of coreg_sums_size() doubles, the data-path collective of this mode (the reference's counterpart
+ * is the lock + shared-memory scatter of alignment.py:502-506) -- and hands the result back:
+ *   coreg_sums_size      number of doubles of the pending sums
+ *   coreg_copy_sums      copy them out (device or host destination)
+ *   coreg_finalize_sums  reduced sums in (device or host) -> Pearson coefficients / residus, C-order lag slice out */
+int coreg_sums_size(coreg_handle* h, int64_t* n_doubles);
+int coreg_copy_sums(coreg_handle* h, double* dst, int dst_on_device);
+int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device, double* corr_out, int out_on_device);
+
 /* Waits for an in-flight device-output sweep (those return without synchronising the stream). */
 int coreg_last_stats(coreg_handle* h, coreg_stats* out);
 

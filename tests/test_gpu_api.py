@@ -135,3 +135,15 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert out["argmax_lag_arcsec"] == out["injected_shift_arcsec"][:2] == [17.0, -9.0]
     assert len(out["per_rank"]) == 2 and all(r["kernel_ms"] > 0 and r["lags"] == 1800 for r in out["per_rank"])
     assert 0.0 < out["roofline"]["frac"] <= 1.0
+
+
+def test_bench_two_ranks_point_sharded_gloo():
+    """The same with the grid sharded instead of the lag plane: every rank sweeps all 3600 lag-points over its share of
+    the grid's points, one all-reduce of the six sums per lag."""
+    from tests.test_api_cpu import _run_bench
+    out = _run_bench({"COREG_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "4", "--warmup", "2",
+                     "--no-cpu-baseline", "--shard", "points", timeout=900)
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["value"] > 0
+    assert "all-reduce" in out["config"]["parallelism"]
+    assert out["argmax_lag_arcsec"] == out["injected_shift_arcsec"][:2] == [17.0, -9.0]
+    assert all(r["kernel_ms"] > 0 and r["lags"] == 3600 for r in out["per_rank"])

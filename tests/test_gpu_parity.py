@@ -468,3 +468,64 @@ def test_tile_skip_is_exact_on_a_coarse_limb_crossing_grid(gpu_handle):
         assert np.array_equal(res[(tw, 1)][0], res[(tw, 0)][0], equal_nan=True)
     want = H.oracle_carrington(small, hs, large, hl, lags, shape, lonlims=lon, latlims=lat)
     H.assert_corr_close(res[(0, 1)][0], want, 1e-10, "coarse limb-crossing grid")
+
+
+def test_point_sharded_sweeps_add_up_to_the_unsharded_map(gpu_handle):
+    """Multi-GPU mode for few lag-points per GPU (SURVEY 8e fallback): every rank sweeps ALL the lags over its share of
+    the grid's points and the six sums per lag are added (one all-reduce).  Emulated here on one GPU: the W ranks'
+    sums, added on the host and finalised, equal the unsharded map -- Carrington with several (cdelt, crota)
+    launches, helioprojective through the zero lag (whose border correction only rank 0 carries), method 'residus'."""
+    from euispice_coreg_amd import _lib
+    small, hs, large, hl, _ = H.scene()
+    lags = _lags(5, 4, cdelt1=[0.0, 0.02], crota=[0.0, 0.3])
+    ls = _lib.LagSet(*lags)
+    grid = _lib.Grid(H.CARR_LON, H.CARR_LAT, (72, 64))
+    full = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, (72, 64)).ravel()
+    for W in (2, 3, 8):
+        total = None
+        try:
+            for r in range(W):
+                gpu_handle.set_point_shard(r, W)
+                nanmap = gpu_handle.sweep_carrington(hs, grid, 1.004, ls)
+                assert np.isnan(nanmap).all()  # a sharded sweep returns no coefficients by itself
+                s = gpu_handle.copy_sums()
+                total = s if total is None else total + s
+            got = gpu_handle.finalize_sums(total, ls.size)
+        finally:
+            gpu_handle.set_point_shard(0, 1)
+        assert np.abs(got - full).max() <= 1e-12, W
+    # a slice of the lag range, sharded
+    try:
+        total = None
+        for r in range(2):
+            gpu_handle.set_point_shard(r, 2)
+            gpu_handle.sweep_carrington(hs, grid, 1.004, ls, lag_begin=7, lag_end=61)
+            s = gpu_handle.copy_sums()
+            total = s if total is None else total + s
+        got = gpu_handle.finalize_sums(total, 61 - 7)
+    finally:
+        gpu_handle.set_point_shard(0, 1)
+    assert np.abs(got - full[7:61]).max() <= 1e-12
+    # helioprojective, lag axes through exactly zero (sub-map semantics), both methods
+    small, hs, large, hl, _ = H.scene(small_n=50, large_n=96, seed=3)
+    lags = (np.array([-4.0, 0.0, 4.0]), np.array([0.0, -3.0]), None, None, [0.0, 0.5])
+    ls = _lib.LagSet(*lags)
+    for method in (0, 1):
+        gpu_handle.set_small(small if method == 0 else np.nan_to_num(small, nan=100.0))
+        gpu_handle.prepare_reference_helioprojective(large, hl, hs, 2)
+        full = gpu_handle.sweep_helioprojective(hs, hs, ls, method=method)
+        try:
+            total = None
+            for r in range(4):
+                gpu_handle.set_point_shard(r, 4)
+                gpu_handle.sweep_helioprojective(hs, hs, ls, method=method)
+                s = gpu_handle.copy_sums()
+                total = s if total is None else total + s
+            got = gpu_handle.finalize_sums(total, ls.size)
+        finally:
+            gpu_handle.set_point_shard(0, 1)
+        assert np.allclose(got, full, rtol=0, atol=1e-12, equal_nan=True), method
+    # calling the finaliser without a pending sharded sweep is an error
+    with pytest.raises(_lib.CoregError):
+        gpu_handle.sweep_helioprojective(hs, hs, ls)
+        gpu_handle.finalize_sums(np.zeros(6), 1)
