@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--use-lds", type=int, default=1)
     ap.add_argument("--shard", choices=["auto", "lags", "points"], default="auto",
                     help="N > 1: cut the lag plane in blocks (+ one all-gather) or the target grid in point shares "
-                         "(+ one all-reduce of the six sums per lag); auto = points below 512 lag-points per GPU")
+                         "(+ one all-reduce of the six sums per lag); auto = points below 128 lag-points per GPU")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

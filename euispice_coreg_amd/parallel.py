@@ -6,7 +6,8 @@ partition `np.array_split`-style fan-out the reference applies to its worker pro
 and ONE all-gather of the per-lag coefficients (a few KB) assembles the correlation map on every rank.
 There is no other data-path collective.
 
-Sweeps with few lag-points per GPU (less than two 256-lag batches each) shard the GRID instead (SURVEY 8e fallback):
+Sweeps with very few lag-points per GPU (less than half a 256-lag batch each, where lag sharding would leave most
+lanes idle) shard the GRID instead (SURVEY 8e fallback):
 every rank sweeps all the lag-points over its share of the target grid's points and ONE all-reduce(SUM) of the six
 Pearson sums per lag slot replaces the all-gather (`point_sharded_sweep`).
 """
@@ -113,7 +114,11 @@ def allgather_lag_slices(local, n_lags: int, group=None):
     return out[:n_lags]
 
 
-POINT_SHARD_MAX_LAGS_PER_RANK = 512  # below two full 256-lag batches per GPU the grid is sharded instead of the lags
+# Below half a 256-lag batch per GPU the grid is sharded instead of the lags.  (Measured, profiles/r02_slice_timing.log:
+# on the headline sweep, 450 lag-points per GPU at N = 8, lag blocks are FASTER than point shares -- 0.51 against
+# 0.59 ms per step before the collective -- because two rounds of 512 smaller workgroups balance better than one
+# round of 240 large ones; point shares pay when a rank would otherwise hold a fraction of one batch.)
+POINT_SHARD_MAX_LAGS_PER_RANK = 128
 
 
 def use_point_sharding(n_lags: int, world: int) -> bool:
