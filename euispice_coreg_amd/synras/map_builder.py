@@ -7,8 +7,9 @@ geometry that `AlignmentSpice` can use as its reference.
 MI355X form: raster steps that share an imager frame are resampled in ONE launch of the library's gather kernel over
 the whole SPICE pixel grid (TAN -> sky -> TAN is an exact homography) and their columns are copied
 out; each imager frame is decoded and uploaded once.  Without astropy: SPICE header arithmetic in
-utils/spice_header.py (pinned against astropy / wcslib golden vectors).  The sunpy branch and level-3 inputs are not
-implemented.
+utils/spice_header.py (pinned against astropy / wcslib golden vectors).  Level-2 windows (x, y, wavelength, time) and
+level-3 coefficient maps (coefficient, x, y, time; map_builder.py:290-346) are both handled by locating the HPLN / HPLT /
+time axes by CTYPE.  The sunpy branch is not implemented.
 """
 from __future__ import annotations
 
@@ -163,8 +164,9 @@ class ComposedMapBuilder(MapBuilder):
             # map_builder.py:163-189, literally: imager pixel size, same roll angle, reference pixel at the centre of
             # the composed map, pointing at the sky position of the SPICE window's central pixel
             hc = self.hdr_composed
-            w_xy = wcs_tan.TanWcs(dict(self.hdr_spice_, NAXIS1=int(hdr_spice["NAXIS1"]), NAXIS2=int(hdr_spice["NAXIS2"])))
-            x_mid, y_mid = (int(hdr_spice["NAXIS1"]) - 1) / 2, (int(hdr_spice["NAXIS2"]) - 1) / 2
+            sx, sy = self._spice_shape  # naxis1, naxis2 of map_builder.py:254-255 (level 2) / :293-294 (level 3)
+            w_xy = wcs_tan.TanWcs(dict(self.hdr_spice_, NAXIS1=sx, NAXIS2=sy))
+            x_mid, y_mid = (sx - 1) / 2, (sy - 1) / 2
             lon_mid, lat_mid = w_xy.pixel_to_world(np.array([x_mid]), np.array([y_mid]))
             hc["CDELT1"] = float(hdrutil.convert(hdr_im0["CDELT1"], hdr_im0["CUNIT1"], hc["CUNIT1"]))
             hc["CDELT2"] = float(hdrutil.convert(hdr_im0["CDELT2"], hdr_im0["CUNIT2"], hc["CUNIT2"]))
@@ -195,22 +197,28 @@ class ComposedMapBuilder(MapBuilder):
 class SPICEComposedMapBuilder(ComposedMapBuilder):
 
     def _prepare_spectro_data(self, hdr_spice, keep_original_imager_pixel_size, level):
-        """map_builder.py:251-349, level 2: the 2-D geometry of the composed map and the time of each of its columns.
-        Returns (target header with NAXIS1/2, seconds after the reference epoch per column, that epoch, header of the
-        first imager)."""
-        if level != 2:
-            raise NotImplementedError("level-3 SPICE inputs (map_builder.py:290-346) are not implemented")
+        """map_builder.py:251-349: the 2-D geometry of the composed map and the time of each of its columns.  Level 2:
+        axes (x, y, wavelength, time), the reference drops the wavelength axis (:254); level 3: axes (coefficient, x, y,
+        time), it drops the coefficient axis (:297-299).  Either way what is left is the (HPLN, HPLT, time) WCS, found
+        here by CTYPE.  Returns (target header with NAXIS1/2, seconds after the reference epoch per column, that epoch,
+        header of the first imager)."""
+        if level not in (2, 3):
+            raise ValueError("level must be 2 or 3")
+        lon_ax, lat_ax = spice_header._axes(hdr_spice)
+        if (level == 2 and (lon_ax, lat_ax) != (1, 2)) or (level == 3 and (lon_ax, lat_ax) != (2, 3)):
+            raise ValueError(f"level {level} SPICE header expected, found HPLN/HPLT on axes {lon_ax}, {lat_ax}")
         flat = spice_header.celestial_header(hdr_spice)
         self.hdr_spice_ = flat
         col_seconds, t_ref = spice_header.column_times(hdr_spice)
         hdr_im = self.headers[0]
         target = flat.copy()
-        nx, ny = int(hdr_spice["NAXIS1"]), int(hdr_spice["NAXIS2"])
+        nx, ny = int(hdr_spice["NAXIS%d" % lon_ax]), int(hdr_spice["NAXIS%d" % lat_ax])
+        self._spice_shape = (nx, ny)
         if keep_original_imager_pixel_size:
             # sample positions x = k * r1, y = l * r2 in SPICE pixels (np.arange(0, NAXIS, r), map_builder.py:262-276)
             # == an ordinary header with PC'_ij = PC_ij * r_j and CRPIX'_j = 1 + (CRPIX_j - 1) / r_j
-            r1 = hdr_im["CDELT1"] / hdr_spice["CDELT1"]
-            r2 = hdr_im["CDELT2"] / hdr_spice["CDELT2"]
+            r1 = hdr_im["CDELT1"] / hdr_spice["CDELT%d" % lon_ax]  # (level 3: CDELT2 / CDELT3, map_builder.py:311-313)
+            r2 = hdr_im["CDELT2"] / hdr_spice["CDELT%d" % lat_ax]
             xs, ys = np.arange(0, nx, r1), np.arange(0, ny, r2)
             pc = [[float(flat.get(f"PC{i}_{j}", 1.0 if i == j else 0.0)) for j in (1, 2)] for i in (1, 2)]
             for i in (1, 2):

@@ -102,3 +102,54 @@ def test_threshold_time_and_in_memory_header(raster):
     assert abs(C.hdr_composed["CDELT1"] * 3600 - 4.44) < 1e-9 and abs(C.hdr_composed["CDELT2"] * 3600 - 4.44) < 1e-9
     assert C.hdr_composed["CRPIX1"] == (C.data_composed.shape[1] + 1) / 2
     assert np.isfinite(C.data_composed).mean() > 0.9
+
+
+def _as_level3(h4, ncoef=4):
+    """The same window as a level-3 coefficient map: axes (coefficient, x, y, time), map_builder.py:290-346."""
+    h = {k: v for k, v in h4.items() if not any(k.startswith(p) for p in ("CRPIX", "CRVAL", "CDELT", "CUNIT", "CTYPE",
+                                                                          "PC", "NAXIS"))}
+    h.update(NAXIS=4, NAXIS1=ncoef, NAXIS2=h4["NAXIS1"], NAXIS3=h4["NAXIS2"], NAXIS4=1, CTYPE1="COEFF", CUNIT1="",
+             CRPIX1=1.0, CRVAL1=1.0, CDELT1=1.0, CTYPE4="UTC")
+    for new, old in ((2, 1), (3, 2)):
+        for k in ("CRPIX", "CRVAL", "CDELT", "CUNIT", "CTYPE"):
+            h[f"{k}{new}"] = h4[f"{k}{old}"]
+    for k in ("CRPIX", "CRVAL", "CDELT", "CUNIT"):
+        h[f"{k}4"] = h4[f"{k}4"]
+    m = {1: 2, 2: 3, 4: 4}
+    for i in (1, 2, 4):
+        for j in (1, 2, 4):
+            if f"PC{i}_{j}" in h4:
+                h[f"PC{m[i]}_{m[j]}"] = h4[f"PC{i}_{j}"]
+    h["PC1_1"] = 1.0
+    return h
+
+
+def test_level3_input_gives_the_level2_raster(raster, tmp_path):
+    """A level-3 coefficient map of the same window (axes coefficient, x, y, time; map_builder.py:290-346) has the same
+    (HPLN, HPLT, time) geometry as its level-2 parent: same synthetic raster, same composed header."""
+    from euispice_coreg_amd.synras.map_builder import SPICEComposedMapBuilder
+    from euispice_coreg_amd.utils import fits_io
+    p_spice, paths, frames, h4, d = raster
+    h3 = _as_level3(h4)
+    p3 = str(d / "solo_L3_spice-n-ras_20220317T094045_V01.fits")
+    fits_io.write_images(p3, [(np.zeros((1, h4["NAXIS2"], h4["NAXIS1"], 4), dtype=np.float32), h3)])
+    C2 = SPICEComposedMapBuilder(p_spice, paths, threshold_time=200.0, window_spectro=0)
+    n2 = C2.process(str(tmp_path), "l2.fits", print_filename=False, return_synras_name=True)
+    C3 = SPICEComposedMapBuilder(p3, paths, threshold_time=200.0, window_spectro=0)
+    n3 = C3.process(str(tmp_path), "l3.fits", print_filename=False, level=3, return_synras_name=True)
+    d2, hd2 = fits_io.read_image(n2, 0)
+    d3, hd3 = fits_io.read_image(n3, 0)
+    assert d3.shape == (h4["NAXIS2"], h4["NAXIS1"]) and np.array_equal(d2, d3, equal_nan=True)
+    for k in ("CRVAL1", "CRVAL2", "CDELT1", "CDELT2", "CRPIX1", "CRPIX2", "PC1_2", "PC2_1"):
+        assert hd2[k] == hd3[k], k
+    # keep_original_imager_pixel_size uses CDELT2 / CDELT3 of the level-3 header (map_builder.py:311-313)
+    C3.process(str(tmp_path), "l3k.fits", print_filename=False, level=3, keep_original_imager_pixel_size=True)
+    C2.process(str(tmp_path), "l2k.fits", print_filename=False, keep_original_imager_pixel_size=True)
+    a, ha = fits_io.read_image(str(tmp_path / "l3k.fits"), 0)
+    b, hb = fits_io.read_image(str(tmp_path / "l2k.fits"), 0)
+    assert np.array_equal(a, b, equal_nan=True) and ha["CRVAL1"] == hb["CRVAL1"] and ha["CRPIX2"] == hb["CRPIX2"]
+    # a level-2 header passed as level 3 is refused, and the in-memory form is level-2 only, as in the reference
+    with pytest.raises(ValueError):
+        C2.process(str(tmp_path), "x.fits", print_filename=False, level=3)
+    with pytest.raises(NotImplementedError):
+        C3.process_from_header(h3, level=3)
