@@ -133,7 +133,7 @@ struct coreg_handle {
     long long pending_n_out = 0;
 
     // options
-    int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1;
+    int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
 
     coreg_stats stats;
     bool stats_pending = false;   // a device-output sweep is in flight: timings are collected on demand
@@ -453,6 +453,7 @@ struct Plan {
     int tile_w = 32;      // grid tile = tile_w x (kTilePts / tile_w) points
     int sw = 16, sh = 16; // lag patch of a workgroup: sw CRVAL1 lags x sh CRVAL2 lags (sw * sh <= 256)
     double window = 0;    // estimated LDS window (elements)
+    double win_w = 0, win_h = 0;  // its estimated width / height in pixels
 };
 
 // Tile shape and lag patch chosen together: fewest lag batches (= least padded lane slots) among the combinations
@@ -482,6 +483,8 @@ Plan choose_plan(coreg_handle* h, const Geometry& g, int m1, int n2, long long l
                 fallback.sw = sw2;
                 fallback.sh = sh;
                 fallback.window = win;
+                fallback.win_w = ex + 1.0;
+                fallback.win_h = ey;
             }
             if (win > 0.94 * (double)lds_elems) continue;
             const double cost = (double)cols * rows * (1.0 + 0.08 * win / (double)lds_elems);
@@ -491,14 +494,16 @@ Plan choose_plan(coreg_handle* h, const Geometry& g, int m1, int n2, long long l
                 best.sw = sw2;
                 best.sh = sh;
                 best.window = win;
+                best.win_w = ex + 1.0;
+                best.win_h = ey;
             }
         }
     }
     const Plan& r = best_cost < std::numeric_limits<double>::max() ? best : fallback;
     if (std::getenv("COREG_DEBUG_PLAN"))
-        std::fprintf(stderr, "[coreg plan] tile %d x %d, lag patch %d x %d, window estimate %.0f of %lld elements; "
+        std::fprintf(stderr, "[coreg plan] tile %d x %d, lag patch %d x %d, window estimate %.0f (%.1f x %.1f) of %lld elements; "
                      "geometry d/di (%.3f, %.3f) d/dj (%.3f, %.3f) lag1 (%.3f, %.3f) lag2 (%.3f, %.3f)\n", r.tile_w,
-                     kTilePts / r.tile_w, r.sw, r.sh, r.window, lds_elems, g.dx_di, g.dy_di, g.dx_dj, g.dy_dj, g.ax, g.ay,
+                     kTilePts / r.tile_w, r.sw, r.sh, r.window, r.win_w, r.win_h, lds_elems, g.dx_di, g.dy_di, g.dx_dj, g.dy_dj, g.ax, g.ay,
                      g.bx, g.by);
     return r;
 }
@@ -646,6 +651,24 @@ void fill_precompute_common(coreg_handle* h, PrecomputeArgs* a, int tile_w) {
 
 // one sweep-kernel launch + finalize over n_batches * 256 slots whose parameters (SoA [np][n_slots]) and output
 // indices are already on the device
+long long lds_window_elems(const coreg_handle* h);
+
+// Compile-time LDS window pitch for the Carrington order-2 sweep: the smallest instantiated pitch that holds the planned
+// window (width + slack) within the LDS.  All of them are 25 mod 32, the residue that spreads the ~2 px lag lattice best
+// over the 32 bank pairs in the conflict simulation.  0 = pitch chosen per visit.
+int pick_pitch(const coreg_handle* h, const Plan& plan, long long lds_elems) {
+    if (h->opt_pitch == 0 || !h->opt_use_lds) return 0;
+    static const int kPitches[] = {89, 121, 153, 185, 217};
+    if (h->opt_pitch > 0) {
+        for (int p : kPitches)
+            if (p == h->opt_pitch) return p;
+        return 0;
+    }
+    for (int p : kPitches)
+        if ((double)p >= plan.win_w + 2.0 && (double)p * plan.win_h <= 0.985 * (double)lds_elems) return p;
+    return 0;
+}
+
 struct BorderFix {  // lag-points of a launch whose border pixels are decided by wcslib's rounding noise
     struct Item {
         long long slot;  // slot of the launch
@@ -657,7 +680,8 @@ struct BorderFix {  // lag-points of a launch whose border pixels are decided by
 
 int launch_sweep(coreg_handle* h, int mode, int order, int method, const double* params_dev,
                  const long long* outidx_dev, int n_batches, int n_tiles, long long lag_begin, double* out_dev,
-                 const LaunchU* car_inv = nullptr, const BorderFix* fix = nullptr, long long sums_off = 0) {
+                 const LaunchU* car_inv = nullptr, const BorderFix* fix = nullptr, long long sums_off = 0,
+                 int pitch_sel = 0) {
     const long long n_slots = (long long)n_batches * kBlock;
     const int n_groups = pick_groups(h, n_batches, n_tiles);
     const bool sharded = h->opt_shard_world > 1;
@@ -697,7 +721,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     const dim3 grid((unsigned)((long long)g_per * n_batches)), block(kSweepThreads);
     EventPair* ev = next_event(h, h->ev_sweep, h->ev_sweep_used);
     if (!ev) return fail(h, COREG_EHIP, "hipEventCreate failed");
-#define SW(M, O, TS, R, Q)                                                                                          \
+#define SWP(M, O, TS, R, Q, P)                                                                                       \
     do {                                                                                                              \
         {                                                                                                             \
             /* per instantiation and device: raise the dynamic-LDS limit once, not per launch (handles of several  */ \
@@ -706,15 +730,16 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
             std::lock_guard<std::mutex> lock(g_attr_mutex);                                                           \
             size_t& ab = attr_bytes[h->device % kMaxDevices];                                                         \
             if (lds_bytes > 48 * 1024 && lds_bytes > ab) {                                                            \
-                HIPCHK(hipFuncSetAttribute((const void*)(k_sweep<M, O, TS, R, Q>),                                    \
+                HIPCHK(hipFuncSetAttribute((const void*)(k_sweep<M, O, TS, R, Q, P>),                                 \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));              \
                 ab = lds_bytes;                                                                                       \
             }                                                                                                         \
         }                                                                                                             \
         HIPCHK(hipEventRecord(ev->a, h->stream));                                                                     \
-        hipLaunchKernelGGL((k_sweep<M, O, TS, R, Q>), grid, block, lds_bytes, h->stream, a);                          \
+        hipLaunchKernelGGL((k_sweep<M, O, TS, R, Q, P>), grid, block, lds_bytes, h->stream, a);                       \
         HIPCHK(hipEventRecord(ev->b, h->stream));                                                                     \
     } while (0)
+#define SW(M, O, TS, R, Q) SWP(M, O, TS, R, Q, 0)
 #define SW_Q(M, O, TS, R)                                        \
     do {                                                         \
         if (method == COREG_METHOD_RESIDUS) SW(M, O, TS, R, true); \
@@ -726,7 +751,27 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
         else SW_Q(M, O, double, R);             \
     } while (0)
     // TRANSLATE = Carrington (float64 samples); HOMOGRAPHY[_SERIES] = helioprojective (samples rounded to float32)
-    if (mode == MODE_TRANSLATE) {
+    if (mode == MODE_TRANSLATE && order == 2 && h->small_f32 && method != COREG_METHOD_RESIDUS && pitch_sel > 0) {
+        // the common Carrington sweep with a compile-time window pitch (pick_pitch)
+        switch (pitch_sel) {
+            case 89: SWP(MODE_TRANSLATE, 2, float, false, false, 89); break;
+            case 121: SWP(MODE_TRANSLATE, 2, float, false, false, 121); break;
+            case 153: SWP(MODE_TRANSLATE, 2, float, false, false, 153); break;
+            case 185: SWP(MODE_TRANSLATE, 2, float, false, false, 185); break;
+            case 217: SWP(MODE_TRANSLATE, 2, float, false, false, 217); break;
+            default: SW(MODE_TRANSLATE, 2, float, false, false); break;
+        }
+    } else if ((mode == MODE_HOMOGRAPHY_SERIES || mode == MODE_HOMOGRAPHY) && order == 2 && h->small_f32 &&
+               method != COREG_METHOD_RESIDUS && (pitch_sel == 89 || pitch_sel == 121)) {
+        // the common helioprojective sweeps likewise
+        if (mode == MODE_HOMOGRAPHY_SERIES) {
+            if (pitch_sel == 89) SWP(MODE_HOMOGRAPHY_SERIES, 2, float, true, false, 89);
+            else SWP(MODE_HOMOGRAPHY_SERIES, 2, float, true, false, 121);
+        } else {
+            if (pitch_sel == 89) SWP(MODE_HOMOGRAPHY, 2, float, true, false, 89);
+            else SWP(MODE_HOMOGRAPHY, 2, float, true, false, 121);
+        }
+    } else if (mode == MODE_TRANSLATE) {
         if (order == 2) SW_T(MODE_TRANSLATE, 2, false);
         else if (order == 1) SW_T(MODE_TRANSLATE, 1, false);
         else SW_T(MODE_TRANSLATE, ORDER_RT, false);
@@ -742,6 +787,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
         else if (order == 1) SW_T(MODE_HOMOGRAPHY, 1, true);
         else SW_T(MODE_HOMOGRAPHY, ORDER_RT, true);
     }
+#undef SWP
 #undef SW_Q
 #undef SW_T
 #undef SW
@@ -1128,6 +1174,8 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         h->opt_shard_rank = value;
     } else if (n == "border_fix") {
         h->opt_border_fix = value ? 1 : 0;  // 0: the zero lag keeps every border pixel (exact identity map)
+    } else if (n == "pitch") {
+        h->opt_pitch = value;  // -1: automatic compile-time window pitch, 0: per-visit pitch, else one of pick_pitch's
     } else if (n == "tile_skip") {
         h->opt_tile_skip = value ? 1 : 0;  // 0: k_precompute evaluates every grid point (tests compare both)
     } else if (n == "h_series") {
@@ -1537,7 +1585,8 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
         // SoA block of this launch starts at 2 * slot_off doubles (every earlier launch contributed 2 per slot)
         RETCHK(launch_sweep(h, MODE_TRANSLATE, order, method, h->lane_params.as<double>() + 2 * L.slot_off,
                             h->out_index.as<long long>() + L.slot_off, L.n_batches, n_tiles, lag_begin, out_dev, nullptr,
-                            nullptr, (long long)L.slot_off));
+                            nullptr, (long long)L.slot_off,
+                            pick_pitch(h, plan, h->opt_use_lds ? lds_window_elems(h) : 0)));
     }
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }
@@ -1858,7 +1907,8 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     if (!fix.items.empty()) RETCHK(upload_border_pixels(h, fix.pixels));
     RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles, pick_groups(h, n_batches, n_tiles)));
     RETCHK(launch_sweep(h, sweep_mode, order, method, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
-                        n_tiles, lag_begin, out_dev, nullptr, &fix));
+                        n_tiles, lag_begin, out_dev, nullptr, &fix, 0,
+                        pick_pitch(h, plan, h->opt_use_lds ? lds_window_elems(h) : 0)));
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }
 

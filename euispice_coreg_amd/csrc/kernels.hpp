@@ -767,6 +767,20 @@ struct Taps<3> {
                      : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
                        "+v"(t[8]));
     }
+    // compile-time window pitch P (elements): the three rows are immediate offsets of ONE address register, which
+    // saves the two row-address additions per sample
+    template <int P>
+    __device__ __forceinline__ void issue_before_imm(unsigned a0, double& fx, double& fy) {
+        static_assert(P > 0 && (2 * P + 2) * 8 < 65536, "LDS immediate offsets are 16 bits");
+        asm volatile(
+            "ds_read_b64 %0, %11\n\tds_read_b64 %1, %11 offset:8\n\tds_read_b64 %2, %11 offset:16\n\t"
+            "ds_read_b64 %3, %11 offset:%12\n\tds_read_b64 %4, %11 offset:%13\n\tds_read_b64 %5, %11 offset:%14\n\t"
+            "ds_read_b64 %6, %11 offset:%15\n\tds_read_b64 %7, %11 offset:%16\n\tds_read_b64 %8, %11 offset:%17"
+            : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+              "=&v"(t[8]), "+v"(fx), "+v"(fy)
+            : "v"(a0), "n"(P * 8), "n"(P * 8 + 8), "n"(P * 8 + 16), "n"(2 * P * 8), "n"(2 * P * 8 + 8),
+              "n"(2 * P * 8 + 16));
+    }
 };
 template <>
 struct Taps<2> {
@@ -800,7 +814,7 @@ struct Taps<2> {
 // pxw, pyw (interior LDS visits): TRANSLATE: lane origin + (0.5 for order 2) - (first tap's offset + window origin), so
 // that trunc(pxw + b0) is the window column of the first tap and fract() gives the spline argument; other modes: the
 // same constant to add to the mapped coordinate.
-template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false>
+template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false, int PITCH = 0>
 __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                           int ox, int oy, int W, int H, double wmax, double hmax, double px0, double py0,
                                           double pxw, double pyw, const H9& hm, const LaunchU& cu, double b0, double b1, double av,
@@ -823,12 +837,23 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
             uy = my + pyw;
         }
         const int c0 = (int)ux, r0 = (int)uy;
-        const unsigned a0 = win + 8u * (unsigned)(__mul24(r0, pitch) + c0);
+        const unsigned a0 = win + 8u * (unsigned)(__mul24(r0, PITCH > 0 ? PITCH : pitch) + c0);
         const unsigned a1 = a0 + 8u * (unsigned)pitch;
         const unsigned a2 = a1 + 8u * (unsigned)pitch;
         Taps<N> tp;
         double wx[N], wy[N];
-        if (ORDER == 2) {
+        if constexpr (ORDER == 2 && PITCH > 0) {
+            double fx = __builtin_amdgcn_fract(ux), fy = __builtin_amdgcn_fract(uy);
+            tp.template issue_before_imm<PITCH>(a0, fx, fy);
+            const double gx = 1.0 - fx, gy = 1.0 - fy;
+            wx[0] = gx * gx;
+            wx[2] = fx * fx;
+            wx[1] = (2.0 - wx[0]) - wx[2];
+            wy[0] = gy * gy;
+            wy[2] = fy * fy;
+            wy[1] = (2.0 - wy[0]) - wy[2];
+            tp.wait_after(wx[0], wx[1], wx[2], wy[0], wy[1], wy[2]);
+        } else if (ORDER == 2) {
             // f = fract(u) = t + 1/2: the weights of scipy's quadratic B-spline, w0 = (1/2 - t)^2 / 2, w1 = 3/4 - t^2,
             // w2 = (1/2 + t)^2 / 2, are g^2 / 2, 1/2 + f g, f^2 / 2 with g = 1 - f.  Evaluated DOUBLED (5 operations per
             // axis instead of 6); the window of an interior visit holds the pixels times 1/4 (exact), which puts the
@@ -967,7 +992,7 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
 
 // Walk this point-group's share of the compacted points of one tile: chunks of kChunk points, chunk c belongs to
 // point-group (c % kPointGroups).  Point data are wave-uniform: the loads below use uniform addresses (scalar loads).
-template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false>
+template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false, int PITCH = 0>
 __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                             int ox, int oy, int W, int H, double px0, double py0, double pxw,
                                             double pyw, const H9& hm, const LaunchU& cu, const Pt* __restrict__ pts, int p_begin, int p_end,
@@ -983,22 +1008,24 @@ __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __
         for (int k = 0; k < kChunk; ++k) pt[k] = q[k];
 #pragma unroll
         for (int k = 0; k < kChunk; ++k)
-            point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0,
-                                                                    py0, pxw, pyw, hm, cu, pt[k].b0, pt[k].b1, pt[k].a,
-                                                                    pt[k].pad, pivot_b);
+            point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR, PITCH>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax,
+                                                                           px0, py0, pxw, pyw, hm, cu, pt[k].b0, pt[k].b1,
+                                                                           pt[k].a, pt[k].pad, pivot_b);
     }
     // ragged tail (< kChunk points): owned by the point-group next in the rotation
     if (pg == n_full % kPointGroups) {
         for (int p = n_full * kChunk; p < p_end; ++p) {
             const Pt pt = pts[p];
-            point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0,
-                                                                    py0, pxw, pyw, hm, cu, pt.b0, pt.b1, pt.a, pt.pad,
-                                                                    pivot_b);
+            point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR, PITCH>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax,
+                                                                           px0, py0, pxw, pyw, hm, cu, pt.b0, pt.b1, pt.a,
+                                                                           pt.pad, pivot_b);
         }
     }
 }
 
-template <int MODE, int ORDER, typename TS, bool ROUND, bool RESID>
+// PITCH > 0: the LDS window has this compile-time row pitch (the host picks one that holds the planned window and whose
+// residue mod 32 spreads the lag lattice over the banks best); 0: pitch = window width | 1, chosen per visit
+template <int MODE, int ORDER, typename TS, bool ROUND, bool RESID, int PITCH = 0>
 __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double* lds = (double*)lds_raw;
@@ -1118,9 +1145,20 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
         const int ex = min((int)floor(fmin(mxx, (double)(W - 1))) + ap_hi, ORDER == ORDER_RT ? W - 1 + ap_hi : W);
         const int ey = min((int)floor(fmin(mxy, (double)(H - 1))) + ap_hi, ORDER == ORDER_RT ? H - 1 + ap_hi : H);
         const int ww = ex - ox + 1, wh = ey - oy + 1;
-        const int pitch = ww | 1;  // odd pitch: measured best for the ~2-pixel lag lattice (rejected layouts)
+        // Odd pitch, and not any odd pitch: with lags ~2 px apart, rows r and r + 2 of the window hold neighbouring lag
+        // rows, so 2 * pitch must not be close to a multiple of 32 bank pairs.  Measured on the headline sweep with
+        // compile-time pitches (ms per step): 113 (17 mod 32) 4.26, 115 (19) 3.90, 117 (21) 3.39, 119 (23) 3.39,
+        // 121 (25) 3.34, 123 (27) 3.35 -- the ranking the bank-conflict simulation gives.  The
+        // per-visit pitch is therefore moved up to the next odd value whose residue lies in [5, 11] or [21, 27] when
+        // the window still fits.
+        int pitch = PITCH > 0 ? PITCH : (ww | 1);
+        if (PITCH == 0) {
+            const int r = pitch & 31;
+            const int up = r < 5 ? 5 - r : ((r > 11 && r < 21) ? 21 - r : (r > 27 ? 37 - r : 0));
+            if ((long long)(pitch + up) * wh <= (long long)a.lds_elems) pitch += up;
+        }
         const long long need = (long long)pitch * wh;
-        const bool in_lds = a.use_lds && (need <= (long long)a.lds_elems);
+        const bool in_lds = a.use_lds && (need <= (long long)a.lds_elems) && (PITCH == 0 || ww <= PITCH);
 
         const Pt* __restrict__ pts = a.pts + (size_t)tile * kTilePts;
 
@@ -1171,9 +1209,9 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
                         const double offy = (ORDER == 2 ? 0.5 : 0.0) - (double)((ORDER == 2 ? 1 : 0) + oy);
                         const double pxw = MODE == MODE_TRANSLATE ? px0 + offx : offx;
                         const double pyw = MODE == MODE_TRANSLATE ? py0 + offy : offy;
-                        tile_points<MODE, ORDER, TS, true, ROUND, RESID, true>(acc, win, img, pitch, ox, oy, W, H, px0,
-                                                                               py0, pxw, pyw, hm, a.car_inv, pts, p_begin,
-                                                                               p_end, pivot_b, pg);
+                        tile_points<MODE, ORDER, TS, true, ROUND, RESID, true, PITCH>(acc, win, img, pitch, ox, oy, W, H,
+                                                                                      px0, py0, pxw, pyw, hm, a.car_inv,
+                                                                                      pts, p_begin, p_end, pivot_b, pg);
                     }
                 }
             }
