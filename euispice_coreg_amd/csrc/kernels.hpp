@@ -802,6 +802,45 @@ struct Taps<2> {
     }
 };
 
+// Quadratic B-spline sample from the LDS window at the window-relative coordinate (ux, uy) = coordinate + 1/2 - 1 -
+// window origin: trunc(u) is the window index of the first tap, f = fract(u) = t + 1/2 the spline argument.  The weights
+// of scipy's quadratic B-spline, w0 = (1/2 - t)^2 / 2, w1 = 3/4 - t^2, w2 = (1/2 + t)^2 / 2, are g^2 / 2, 1/2 + f g,
+// f^2 / 2 with g = 1 - f; they are evaluated DOUBLED (5 operations per axis instead of 6) and the window of an order-2
+// visit holds the pixels times 1/4 (exact), which puts the factor 2 x 2 back.  The nine reads are issued before the
+// weight arithmetic and waited for after it.
+template <int PITCH>
+__device__ __forceinline__ double gather_o2(unsigned win, int pitch, double ux, double uy) {
+    const int c0 = (int)ux, r0 = (int)uy;
+    const unsigned a0 = win + 8u * (unsigned)(__mul24(r0, PITCH > 0 ? PITCH : pitch) + c0);
+    Taps<3> tp;
+    double fx = __builtin_amdgcn_fract(ux), fy = __builtin_amdgcn_fract(uy);
+    if constexpr (PITCH > 0) {
+        tp.template issue_before_imm<PITCH>(a0, fx, fy);
+    } else {
+        const unsigned a1 = a0 + 8u * (unsigned)pitch;
+        const unsigned a2 = a1 + 8u * (unsigned)pitch;
+        tp.issue_before(a0, a1, a2, fx, fy);
+    }
+    double wx[3], wy[3];
+    const double gx = 1.0 - fx, gy = 1.0 - fy;
+    wx[0] = gx * gx;
+    wx[2] = fx * fx;
+    wx[1] = (2.0 - wx[0]) - wx[2];
+    wy[0] = gy * gy;
+    wy[2] = fy * fy;
+    wy[1] = (2.0 - wy[0]) - wy[2];
+    tp.wait_after(wx[0], wx[1], wx[2], wy[0], wy[1], wy[2]);
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double row = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) row = fma(tp.t[r * 3 + c], wx[c], row);
+        v = fma(row, wy[r], v);
+    }
+    return v;
+}
+
 // One (grid point, lag) of alignment.py:519-531 for this lane's lag.  Everything is under the lane's own
 // predicate (EXEC mask): lanes whose coordinate violates the bounds rule, or whose sample is not finite,
 // simply skip -- no selects, no clamped addresses.
@@ -836,51 +875,27 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
             ux = mx + pxw;
             uy = my + pyw;
         }
-        const int c0 = (int)ux, r0 = (int)uy;
-        const unsigned a0 = win + 8u * (unsigned)(__mul24(r0, PITCH > 0 ? PITCH : pitch) + c0);
-        const unsigned a1 = a0 + 8u * (unsigned)pitch;
-        const unsigned a2 = a1 + 8u * (unsigned)pitch;
-        Taps<N> tp;
-        double wx[N], wy[N];
-        if constexpr (ORDER == 2 && PITCH > 0) {
-            double fx = __builtin_amdgcn_fract(ux), fy = __builtin_amdgcn_fract(uy);
-            tp.template issue_before_imm<PITCH>(a0, fx, fy);
-            const double gx = 1.0 - fx, gy = 1.0 - fy;
-            wx[0] = gx * gx;
-            wx[2] = fx * fx;
-            wx[1] = (2.0 - wx[0]) - wx[2];
-            wy[0] = gy * gy;
-            wy[2] = fy * fy;
-            wy[1] = (2.0 - wy[0]) - wy[2];
-            tp.wait_after(wx[0], wx[1], wx[2], wy[0], wy[1], wy[2]);
-        } else if (ORDER == 2) {
-            // f = fract(u) = t + 1/2: the weights of scipy's quadratic B-spline, w0 = (1/2 - t)^2 / 2, w1 = 3/4 - t^2,
-            // w2 = (1/2 + t)^2 / 2, are g^2 / 2, 1/2 + f g, f^2 / 2 with g = 1 - f.  Evaluated DOUBLED (5 operations per
-            // axis instead of 6); the window of an interior visit holds the pixels times 1/4 (exact), which puts the
-            // factor 2 x 2 back.
-            double fx = __builtin_amdgcn_fract(ux), fy = __builtin_amdgcn_fract(uy);
-            tp.issue_before(a0, a1, a2, fx, fy);
-            const double gx = 1.0 - fx, gy = 1.0 - fy;
-            wx[0] = gx * gx;
-            wx[2] = fx * fx;
-            wx[1] = (2.0 - wx[0]) - wx[2];
-            wy[0] = gy * gy;
-            wy[2] = fy * fy;
-            wy[1] = (2.0 - wy[0]) - wy[2];
-            tp.wait_after(wx[0], wx[1], wx[2], wy[0], wy[1], wy[2]);
+        double v = 0.0;
+        if constexpr (ORDER == 2) {
+            v = gather_o2<PITCH>(win, pitch, ux, uy);
         } else {
+            const int c0 = (int)ux, r0 = (int)uy;
+            const unsigned a0 = win + 8u * (unsigned)(__mul24(r0, pitch) + c0);
+            const unsigned a1 = a0 + 8u * (unsigned)pitch;
+            const unsigned a2 = a1 + 8u * (unsigned)pitch;
+            Taps<N> tp;
+            double wx[N], wy[N];
             tp.issue(a0, a1, a2);
             spline_weights_t<ORDER>(__builtin_amdgcn_fract(ux), wx);
             spline_weights_t<ORDER>(__builtin_amdgcn_fract(uy), wy);
             tp.wait();
-        }
-        double v = 0.0;
 #pragma unroll
-        for (int r = 0; r < N; ++r) {
-            double row = 0.0;
+            for (int r = 0; r < N; ++r) {
+                double row = 0.0;
 #pragma unroll
-            for (int c = 0; c < N; ++c) row = fma(tp.t[r * N + c], wx[c], row);
-            v = fma(row, wy[r], v);
+                for (int c = 0; c < N; ++c) row = fma(tp.t[r * N + c], wx[c], row);
+                v = fma(row, wy[r], v);
+            }
         }
         double bm;
         if (ROUND) {
@@ -925,6 +940,10 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
                 bool inb;
                 v = spline_global_rt<TS>(img, W, H, nx, ny, cu.order_rt, inb);
             }
+        } else if constexpr (LDS && ORDER == 2) {
+            // the arithmetic of the interior path under this lane's bounds predicate: (pxw, pyw) = 1/2 - 1 - window
+            // origin turn the coordinate into the window-relative one
+            v = gather_o2<PITCH>(win, pitch, nx + pxw, ny + pyw);
         } else if constexpr (LDS) {
             // tap addresses first, so that the reads are in flight while the weights are computed
             const double fx = floor(nx + (ORDER == 2 ? 0.5 : 0.0)), fy = floor(ny + (ORDER == 2 ? 0.5 : 0.0));
@@ -1169,8 +1188,8 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
             // Stage the window.  The loads are L2 round trips: kStage rows per wave are in flight at a time (one wave
             // would otherwise wait out ~20 dependent load -> store round trips per visit).
             constexpr int kStage = 8;
-            // interior visits of the quadratic spline use doubled weights on both axes (see point_lag)
-            const double scale = (interior && ORDER == 2) ? 0.25 : 1.0;
+            // the quadratic spline uses doubled weights on both axes (see gather_o2)
+            const double scale = ORDER == 2 ? 0.25 : 1.0;
             // (the row index is wave-uniform: with it in an SGPR the row addresses are scalar arithmetic)
             const int wave_u = __builtin_amdgcn_readfirstlane(wave);
             for (int r0 = wave_u; r0 < wh; r0 += kWaves * kStage) {
@@ -1216,8 +1235,12 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
                 }
             }
             if (!done) {
-                tile_points<MODE, ORDER, TS, true, ROUND, RESID>(acc, win, img, pitch, ox, oy, W, H, px0, py0, 0.0, 0.0, hm,
-                                                                 a.car_inv, pts, p_begin, p_end, pivot_b, pg);
+                // (order 2: window-relative offsets for gather_o2, exact small numbers)
+                const double offx = ORDER == 2 ? 0.5 - (double)(1 + ox) : 0.0;
+                const double offy = ORDER == 2 ? 0.5 - (double)(1 + oy) : 0.0;
+                tile_points<MODE, ORDER, TS, true, ROUND, RESID, false, PITCH>(acc, win, img, pitch, ox, oy, W, H, px0, py0,
+                                                                               offx, offy, hm, a.car_inv, pts, p_begin,
+                                                                               p_end, pivot_b, pg);
             }
           }
         }
