@@ -114,6 +114,8 @@ struct coreg_handle {
     // zero-lag border decision of the helioprojective sub-map path (geometry.hpp WcslibTan): grid pixels the
     // reference's wcslib round trip drops, cached per header
     std::map<std::vector<double>, std::vector<int>> border_cache;
+    std::map<std::vector<double>, std::vector<unsigned char>> flags_cache;
+    DevBuf border_flags, fix_partial;
     DevBuf border_dev;
     PinBuf pin_border;
     int64_t opt_border_fix = 1;
@@ -673,6 +675,7 @@ struct BorderFix {  // lag-points of a launch whose border pixels are decided by
     struct Item {
         long long slot;  // slot of the launch
         int first, n;    // its pixels in h->border_dev: [first, first + n)
+        long long flags_off;  // odd spline order: offset of its per-pixel tap-shift flags in h->border_flags, or -1
     };
     std::vector<Item> items;
     std::vector<int> pixels;  // concatenated linear grid indices (host copy of h->border_dev)
@@ -799,6 +802,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
         // one more slab: zero, except minus the dropped border pixels' totals at the identity lag's slot
         double* slab = h->partials.as<double>() + (size_t)g_per * kNumSums * n_slots;
         HIPCHK(hipMemsetAsync(slab, 0, (size_t)kNumSums * n_slots * sizeof(double), h->stream));
+        std::vector<ParityFixArgs> parity_items;
         BorderFixArgs b;
         b.img = h->small.p;
         b.W = h->sW;
@@ -817,8 +821,40 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
             b.dropped = h->border_dev.as<int>() + it.first;
             b.n_dropped = it.n;
             b.hom = params_dev;  // SoA [9][n_slots]: the (snapped) map of the slot gives the sample coordinates
+            if (it.flags_off >= 0) {
+                // odd spline order: re-decide the tap set of every pixel of this lag-point (k_parity_fix), after
+                // k_border_fix has set the slab entry (same stream)
+                ParityFixArgs p;
+                p.img = b.img;
+                p.W = b.W;
+                p.H = b.H;
+                p.ref = b.ref;
+                p.ref_f32 = b.ref_f32;
+                p.flags = h->border_flags.as<unsigned char>() + it.flags_off;
+                p.gw = h->gW;
+                p.gh = h->gH;
+                p.order = order;
+                p.round_f32 = b.round_f32;
+                p.residus = b.residus;
+                p.pivots = b.pivots;
+                p.hom = params_dev;
+                p.n_slots = n_slots;
+                p.slot = it.slot;
+                p.n_partial = 256;
+                if (h->fix_partial.reserve((size_t)p.n_partial * kNumSums * sizeof(double)) != hipSuccess)
+                    return fail(h, COREG_EHIP, "hipMalloc failed (parity fix)");
+                p.partial = h->fix_partial.as<double>();
+                p.slab = slab;
+                parity_items.push_back(p);
+            }
+            if (it.n == 0) continue;
             if (h->small_f32) hipLaunchKernelGGL((k_border_fix<float>), dim3(1), dim3(256), 0, h->stream, b);
             else hipLaunchKernelGGL((k_border_fix<double>), dim3(1), dim3(256), 0, h->stream, b);
+        }
+        for (const ParityFixArgs& p : parity_items) {
+            if (h->small_f32) hipLaunchKernelGGL((k_parity_fix<float>), dim3(p.n_partial), dim3(256), 0, h->stream, p);
+            else hipLaunchKernelGGL((k_parity_fix<double>), dim3(p.n_partial), dim3(256), 0, h->stream, p);
+            hipLaunchKernelGGL(k_parity_fix_final, dim3(1), dim3(64), 0, h->stream, p);
         }
         HIPCHK(hipGetLastError());
     }
@@ -942,6 +978,55 @@ void wcslib_dropped_border_pixels(coreg_handle* h, const coreg_wcs2d& target, co
         hit = h->border_cache.emplace(std::move(key), std::move(dropped)).first;
     }
     out->insert(out->end(), hit->second.begin(), hit->second.end());
+}
+
+// Odd spline orders: for every grid pixel, does the reference's round trip come back BELOW the integer along an
+// invariant axis (bit 0: rows / y, bit 1: columns / x)?  Then floor(c) -- the first tap of an odd-order spline -- is one
+// less than at the exact integer the sweep used (k_parity_fix).  W x H evaluations of the wcslib chain, in threads;
+// cached per header pair.
+const std::vector<unsigned char>& wcslib_tap_shift_flags(coreg_handle* h, const coreg_wcs2d& target,
+                                                         const coreg_wcs2d& shifted, AxisInvariance inv) {
+    const int gw = h->gW, gh = h->gH;
+    std::vector<double> key = {target.crpix1, target.crpix2, target.crval1, target.crval2, target.cdelt1, target.cdelt2,
+                               target.pc1_1, target.pc1_2, target.pc2_1, target.pc2_2, target.unit_to_deg, target.lonpole,
+                               shifted.crpix1, shifted.crpix2, shifted.cdelt1, shifted.cdelt2, shifted.pc1_1,
+                               shifted.pc1_2, shifted.pc2_1, shifted.pc2_2, (double)gw, (double)gh, (double)h->sW,
+                               (double)h->sH, inv.rows ? 1.0 : 0.0, inv.cols ? 1.0 : 0.0};
+    auto hit = h->flags_cache.find(key);
+    if (hit != h->flags_cache.end()) return hit->second;
+    WcslibTan wf, wt;
+    wf.init(target);
+    wt.init(shifted);
+    std::vector<unsigned char> flags((size_t)gw * gh, 0);
+    const double wmax = (double)(h->sW - 1), hmax = (double)(h->sH - 1);
+    auto work = [&](int j0, int j1) {
+        for (int j = j0; j < j1; ++j)
+            for (int i = 0; i < gw; ++i) {
+                double x, y;
+                wcslib_pixel_to_pixel(wf, wt, (double)i, (double)j, &x, &y);
+                unsigned char f = 0;
+                if (inv.rows && y < (double)j) f |= 1;
+                if (inv.cols && x < (double)i) f |= 2;
+                // the bounds rule drops the pixel altogether (border pixels only; k_border_fix has taken it out)
+                if (!((x >= 0.0) && (x <= wmax) && (y >= 0.0) && (y <= hmax))) f |= 4;
+                flags[(size_t)j * gw + i] = f;
+            }
+    };
+    unsigned nt = std::min<unsigned>(12, std::max(1u, std::thread::hardware_concurrency()));
+    if ((long long)gw * gh < 4096) nt = 1;
+    if (nt <= 1) {
+        work(0, gh);
+    } else {
+        std::vector<std::thread> th;
+        const int step = (gh + (int)nt - 1) / (int)nt;
+        for (unsigned t = 0; t < nt; ++t) {
+            const int lo = std::min(gh, (int)t * step), hi = std::min(gh, lo + step);
+            if (hi > lo) th.emplace_back(work, lo, hi);
+        }
+        for (auto& x : th) x.join();
+    }
+    if (h->flags_cache.size() >= 4) h->flags_cache.clear();
+    return h->flags_cache.emplace(std::move(key), std::move(flags)).first->second;
 }
 
 int upload_border_pixels(coreg_handle* h, const std::vector<int>& pixels) {
@@ -1106,7 +1191,7 @@ void coreg_destroy(coreg_handle* h) {
     DevBuf* bufs[] = {&h->small, &h->ref, &h->pivots, &h->red_sum, &h->red_cnt, &h->t_sin_lon, &h->t_cos_lon,
                       &h->t_cos_lat, &h->t_sin_lat, &h->pts, &h->tile_count, &h->tile_list, &h->tile_cum, &h->group_first,
                       &h->tile_info, &h->tile_bbox, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
-                      &h->tmp_img, &h->up_f64, &h->up_flag, &h->border_dev, &h->sums, &h->fin_outidx};
+                      &h->tmp_img, &h->up_f64, &h->up_flag, &h->border_dev, &h->sums, &h->fin_outidx, &h->border_flags, &h->fix_partial};
     for (DevBuf* b : bufs) b->release();
     h->pin_params.release();
     h->pin_outidx.release();
@@ -1810,6 +1895,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     HomographyFamily fam;
     fam.init(*hdr_target, *hdr_small, lags->crval1, d.n1, lags->crval2, d.n2);
     BorderFix fix;
+    std::vector<std::vector<unsigned char>> flags_host;  // per noise-decided lag-point (odd spline orders only)
     const int i1_lo = (int)(lag_begin / row), i1_hi = (int)((lag_end - 1) / row);
     const double nanv = std::numeric_limits<double>::quiet_NaN();
     for (long long c = 0; c < d.nc; ++c) {
@@ -1845,7 +1931,12 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                         it.first = (int)fix.pixels.size();
                         wcslib_dropped_border_pixels(h, *hdr_target, hl, inv, &fix.pixels);
                         it.n = (int)fix.pixels.size() - it.first;
-                        if (it.n > 0) fix.items.push_back(it);
+                        it.flags_off = -1;
+                        if (order & 1) {
+                            it.flags_off = (long long)flags_host.size() * h->gW * h->gH;
+                            flags_host.push_back(wcslib_tap_shift_flags(h, *hdr_target, hl, inv));  // (copy: the cache may evict)
+                        }
+                        if (it.n > 0 || it.flags_off >= 0) fix.items.push_back(it);
                     }
                 }
             }
@@ -1905,6 +1996,14 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     pa.f1lo = std::floor(fy0) - 3.0;
     pa.f1hi = std::ceil(fy1) + 3.0;
     if (!fix.items.empty()) RETCHK(upload_border_pixels(h, fix.pixels));
+    if (!flags_host.empty()) {
+        const size_t each = (size_t)h->gW * h->gH;
+        HIPCHK(h->border_flags.reserve(each * flags_host.size()));
+        HIPCHK(hipStreamSynchronize(h->stream));  // (pageable source, rare path: blocking copies are fine)
+        for (size_t k = 0; k < flags_host.size(); ++k)
+            HIPCHK(hipMemcpy(h->border_flags.as<unsigned char>() + k * each, flags_host[k].data(), each,
+                             hipMemcpyHostToDevice));
+    }
     RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles, pick_groups(h, n_batches, n_tiles)));
     RETCHK(launch_sweep(h, sweep_mode, order, method, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
                         n_tiles, lag_begin, out_dev, nullptr, &fix, 0,

@@ -1357,6 +1357,97 @@ __global__ void __launch_bounds__(256) k_border_fix(const BorderFixArgs a) {
     }
 }
 
+// ---- odd spline orders at noise-decided lag-points ---------------------------------------------------------------------
+// Odd orders take floor(c) as their first tap (scipy ni_interpolation.c).  Where the map keeps an image axis invariant
+// the coordinate along it comes back from wcslib as integer + eps, and the SIGN of eps decides which taps are used --
+// hence which neighbour's NaN poisons the sample (geometry.hpp WcslibTan; host: per-pixel flags, bit 0: y' < j on an
+// invariant row axis, bit 1: x' < i on an invariant column axis, bit 2: the pixel falls to the bounds rule).  The sweep evaluated those pixels at the exact
+// integer; this pass re-decides them: wherever the finiteness of the sample differs between the exact coordinate and
+// the coordinate nudged below the integer, the pixel's contribution is added or taken out.  Two stages (per-block
+// partial sums, then one block adds them in a fixed order INTO the extra slab that k_border_fix has set).
+struct ParityFixArgs {
+    const void* img;
+    int W, H;
+    const void* ref;
+    int ref_f32;
+    const unsigned char* flags;  // [gh][gw]
+    int gw, gh;
+    int order;
+    int round_f32, residus;
+    const double* pivots;
+    const double* hom;
+    long long n_slots, slot;
+    double* partial;  // [gridDim.x][kNumSums]
+    double* slab;     // [kNumSums][n_slots]
+    int n_partial;
+};
+template <typename TS>
+__global__ void __launch_bounds__(256) k_parity_fix(const ParityFixArgs a) {
+    __shared__ double red[256];
+    const double pivot_a = a.pivots[0], pivot_b = a.pivots[1];
+    double hm[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) hm[k] = a.hom[(long long)k * a.n_slots + a.slot];
+    double s[kNumSums];
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) s[k] = 0.0;
+    const long long n = (long long)a.gw * a.gh;
+    const double nudge = 9.5367431640625e-07;  // 2^-20: below the integer, far above any rounding of the coordinate
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
+        const unsigned f = a.flags[idx];
+        if (f == 0 || (f & 4)) continue;  // nothing to re-decide / dropped by the bounds rule (k_border_fix)
+        const double araw = a.ref_f32 ? (double)((const float*)a.ref)[idx] : ((const double*)a.ref)[idx];
+        if (!isfinite(araw)) continue;
+        const int i = (int)(idx % a.gw), j = (int)(idx / a.gw);
+        const double nx = fma(hm[0], (double)i, fma(hm[1], (double)j, hm[2]));
+        const double ny = fma(hm[3], (double)i, fma(hm[4], (double)j, hm[5]));
+        bool inb0, inb1;
+        double v0 = spline_global_rt<TS>((const TS*)a.img, a.W, a.H, nx, ny, a.order, inb0);  // what the sweep used
+        double v1 = spline_global_rt<TS>((const TS*)a.img, a.W, a.H, (f & 2) ? nx - nudge : nx, (f & 1) ? ny - nudge : ny,
+                                         a.order, inb1);                                      // what the reference uses
+        if (!inb0 || !inb1) continue;  // border pixels on the bounds rule: k_border_fix
+        if (a.round_f32) {
+            v0 = (double)(float)v0;
+            v1 = (double)(float)v1;
+        }
+        const bool fin0 = isfinite(v0), fin1 = isfinite(v1);
+        if (fin0 == fin1) continue;
+        const double sign = fin1 ? 1.0 : -1.0, v = fin1 ? v1 : v0;
+        if (a.residus) {
+            const double d = (araw - v) * (1.0 / sqrt(araw));
+            if (isfinite(d)) {
+                s[0] += sign;
+                s[2] += sign * d;
+                s[4] += sign * d * d;
+            }
+        } else {
+            const double av = araw - pivot_a, bm = v - pivot_b;
+            s[0] += sign;
+            s[1] += sign * av;
+            s[2] += sign * bm;
+            s[3] += sign * av * av;
+            s[4] += sign * bm * bm;
+            s[5] += sign * av * bm;
+        }
+    }
+    for (int k = 0; k < kNumSums; ++k) {
+        red[threadIdx.x] = s[k];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * kNumSums + k] = red[0];
+        __syncthreads();
+    }
+}
+__global__ void k_parity_fix_final(const ParityFixArgs a) {
+    if (blockIdx.x != 0 || threadIdx.x >= kNumSums) return;
+    double t = 0.0;
+    for (int b = 0; b < a.n_partial; ++b) t += a.partial[(size_t)b * kNumSums + threadIdx.x];
+    a.slab[(size_t)threadIdx.x * a.n_slots + a.slot] += t;
+}
+
 // ---- finalize: add the tile-group slabs in a fixed order, Pearson coefficient (c_correlate.py:39-72) -------------
 struct FinalizeArgs {
     const double* partials;

@@ -482,6 +482,30 @@ class WcslibTan:
                     [float(hdr.get("PC2_1", 0.0)), float(hdr.get("PC2_2", 1.0))]], float(hdr.get("LONPOLE", 180.0)))
 
 
+MAX_INTEGER_REFINE = 60000  # pure-Python loop: pixels re-evaluated for odd spline orders (see below)
+
+
+def wcslib_refine_near_integers(hdr_from, hdr_to, x, y, tol=1e-6):
+    """Odd spline orders take floor(c) as their first tap (scipy ni_interpolation.c), so where the map returns a
+    coordinate within `tol` of an INTEGER -- every pixel of a noise-decided lag-point, see `wcslib_refine_near_bounds` --
+    the sign of wcslib's rounding noise decides WHICH taps are used, i.e. which neighbour's NaN poisons the sample.
+    Same remedy: wcslib's own arithmetic for those coordinates.  Limited to MAX_INTEGER_REFINE pixels (the loop is pure
+    Python); larger noise-decided grids keep the numpy coordinates for odd orders and are not pinned (none of the
+    tests or BASELINE configs has one: the default order is 2)."""
+    with np.errstate(invalid="ignore"):
+        near = (np.abs(x - np.rint(x)) < tol) | (np.abs(y - np.rint(y)) < tol)
+    jj, ii = np.nonzero(near)
+    if jj.size == 0 or jj.size > MAX_INTEGER_REFINE:
+        return 0
+    wf, wt = WcslibTan.from_header(hdr_from), WcslibTan.from_header(hdr_to)
+    for j, i in zip(jj.tolist(), ii.tolist()):
+        lng, lat = wf.p2s(float(i), float(j))
+        lng = float(ang2pipi(np.float64(lng)))
+        lat = float(ang2pipi(np.float64(lat)))
+        x[j, i], y[j, i] = wt.s2p(lng, lat)
+    return int(jj.size)
+
+
 def wcslib_refine_near_bounds(hdr_from, hdr_to, x, y, tol=1e-6):
     """Re-evaluate, in place, with wcslib's own arithmetic (scalar, libm) every coordinate of the map `hdr_from` pixels ->
     `hdr_to` pixels that lies within `tol` px of the bounds 0 / NAXIS-1 of `hdr_to`: there the sign of wcslib's rounding
@@ -676,9 +700,10 @@ def extract_EUI_coordinates(hdr, wrap=True):
     return lon, lat
 
 
-def extract_coordinates_pixels(header_initial_to_project, header_target_projection):
+def extract_coordinates_pixels(header_initial_to_project, header_target_projection, order=None):
     """Pixel coordinates, in `header_target_projection`, of every pixel of
-    `header_initial_to_project`.  alignment.py:1038-1069 (non-sunpy branch)."""
+    `header_initial_to_project`.  alignment.py:1038-1069 (non-sunpy branch).  `order`: the spline order the
+    coordinates will be sampled with (decides which coordinates are sensitive to wcslib's rounding noise)."""
     w_to = make_wcs(header_target_projection)
     lon, lat = extract_EUI_coordinates(header_initial_to_project)
     x, y = w_to.world_to_pixel(lon, lat)
@@ -686,6 +711,8 @@ def extract_coordinates_pixels(header_initial_to_project, header_target_projecti
         # coordinates ON the bounds rule are decided by wcslib's rounding noise (see WcslibTan)
         x, y = np.array(x, dtype=np.float64), np.array(y, dtype=np.float64)
         wcslib_refine_near_bounds(header_initial_to_project, header_target_projection, x, y)
+        if order is not None and int(order) % 2 == 1:
+            wcslib_refine_near_integers(header_initial_to_project, header_target_projection, x, y)
     return x, y
 
 
@@ -955,7 +982,7 @@ def create_submap_of_large_data(st: SweepState):
     """alignment.py:987-1016: large image resampled on the small header's own pixel grid, fp32;
     hdr_large := copy of hdr_small."""
     hdr_cut = dict(st.hdr_small)
-    x_cut, y_cut = extract_coordinates_pixels(hdr_cut, st.hdr_large)
+    x_cut, y_cut = extract_coordinates_pixels(hdr_cut, st.hdr_large, st.order)
     image_large_cut = np.zeros_like(x_cut, dtype="float32")
     interpol2d(st.data_large.copy(), x=x_cut, y=y_cut, dst=image_large_cut, order=st.order, fill=np.nan)
     st.hdr_large = dict(hdr_cut)
@@ -964,7 +991,7 @@ def create_submap_of_large_data(st: SweepState):
 
 def interpolate_on_large_data_grid(st: SweepState, data, hdr):
     """alignment.py:1018-1029: small image resampled on hdr_large's pixel grid, fp32."""
-    x_large, y_large = extract_coordinates_pixels(st.hdr_large, hdr)
+    x_large, y_large = extract_coordinates_pixels(st.hdr_large, hdr, st.order)
     image_small_shft = np.zeros_like(x_large, dtype="float32")
     interpol2d(data.copy(), x=x_large, y=y_large, order=st.order, fill=np.nan, dst=image_small_shft)
     return image_small_shft

@@ -355,8 +355,10 @@ def test_zero_lag_border_pixels_follow_wcslib(gpu_handle):
     wcslib's own arithmetic on the host and takes the dropped ones out of the six sums (k_border_fix): parity with
     the oracle at 1e-7 on 50-pixel images, where every border pixel weighs 1e-3 of the coefficient, for both
     orders, both methods, a rolled and an unrolled header and float32 / float64 pixels."""
-    # (order 1 on a NaN-free image: with NaNs, odd orders are noise-decided at EVERY pixel of such a lag, see DESIGN.md)
-    for seed, crota, order, f32, nanf in ((3, 3.0, 2, True, 0.01), (4, 0.0, 1, False, 0.0), (5, -27.5, 2, False, 0.01)):
+    # (odd orders take floor(c) as their first tap: there the noise also decides, for EVERY pixel of such a lag-point,
+    # which neighbour's NaN poisons the sample -- reproduced through per-pixel flags and k_parity_fix)
+    for seed, crota, order, f32, nanf in ((3, 3.0, 2, True, 0.01), (4, 0.0, 1, False, 0.02), (5, -27.5, 2, False, 0.01),
+                                          (6, 3.0, 3, True, 0.02), (7, 118.0, 1, True, 0.01)):
         small, hs, large, hl, _ = H.scene(small_n=50, large_n=96, seed=seed, float32_exact=f32, nan_frac=nanf)
         hs = dict(hs)
         rho = np.deg2rad(crota)
