@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Build-time check of the hand-issued LDS gathers of k_sweep (kernels.hpp, struct Taps).
 
-The nine (four) `ds_read_b64` of a sample and their `s_waitcnt lgkmcnt(0)` live in two separate inline-asm statements so
-that the spline weights are computed under the LDS latency.  The compiler does not track memory operations inside
+The nine (four) `ds_read_b64` of a sample and their `s_waitcnt lgkmcnt(N)` live in two separate inline-asm statements so
+that the spline weights -- and, in the software-pipelined interior loop, the previous sample's arithmetic -- run under
+the LDS latency (N = 9: the next sample's reads stay in flight; LDS operations return in order).  The compiler does not track memory operations inside
 inline asm: were it to place a copy, a spill or any other use of a tap register between the reads and the wait, that
 instruction would see stale data.  This script disassembles the built library and fails if any instruction between a
 group of hand-issued reads and the wait that follows it names one of the group's destination registers.
@@ -64,17 +65,25 @@ def check(text):
             if j - i in (4, 9):  # Taps<2> / Taps<3>
                 n_groups += 1
                 k = j
+                younger = 0  # LDS reads issued after this group (software-pipelined loop: the next sample's)
                 while k < len(lines):
                     t = lines[k].strip().split("//")[0].strip()
-                    if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
-                        break
+                    m2 = re.match(r"s_waitcnt .*lgkmcnt\((\d+)\)", t)
+                    if m2 and int(m2.group(1)) <= younger:
+                        break  # in-order return: this group's reads have landed
+                    if t.startswith("ds_read"):
+                        younger += 1
                     if t and not t.startswith(("s_nop", ";")):
                         ops = t.split(None, 1)[1] if " " in t else ""
                         if regs(ops) & dst:
                             bad.append((kernel, t))
                     if t.startswith(("s_endpgm", "s_branch", "s_cbranch")):
-                        bad.append((kernel, "control flow before the wait: " + t))
-                        break
+                        # a short FORWARD conditional branch (the EXEC-masked accumulation of the previous sample in
+                        # the software-pipelined loop) only skips instructions that are checked here anyway
+                        m3 = re.match(r"s_cbranch_\w+\s+(\d+)", t)
+                        if not (m3 and int(m3.group(1)) < 64):
+                            bad.append((kernel, "control flow before the wait: " + t))
+                            break
                     k += 1
             i = j
             continue
