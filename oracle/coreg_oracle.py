@@ -482,7 +482,7 @@ class WcslibTan:
                     [float(hdr.get("PC2_1", 0.0)), float(hdr.get("PC2_2", 1.0))]], float(hdr.get("LONPOLE", 180.0)))
 
 
-MAX_INTEGER_REFINE = 60000  # pure-Python loop: pixels re-evaluated for odd spline orders (see below)
+MAX_INTEGER_REFINE = 300000  # pure-Python loop: pixels re-evaluated for odd spline orders (see below)
 
 
 def wcslib_refine_near_integers(hdr_from, hdr_to, x, y, tol=1e-6):
