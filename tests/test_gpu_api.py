@@ -147,3 +147,43 @@ def test_bench_two_ranks_point_sharded_gloo():
     assert "all-reduce" in out["config"]["parallelism"]
     assert out["argmax_lag_arcsec"] == out["injected_shift_arcsec"][:2] == [17.0, -9.0]
     assert all(r["kernel_ms"] > 0 and r["lags"] == 3600 for r in out["per_rank"])
+
+
+def test_alignment_two_ranks_gloo_both_sharding_modes(tmp_path):
+    """`Alignment` under torch.distributed (two ranks sharing the one GPU, gloo): a 5 x 5 lag set is below the
+    point-sharding threshold (grid shares + one all-reduce of the six sums per lag), a 24 x 24 one above it (lag slices +
+    one all-gather); both must give the single-process map on every rank."""
+    import os
+    import subprocess
+    import sys
+    from tests.test_api_cpu import ROOT
+    script = tmp_path / "worker.py"
+    script.write_text(
+        "import os, sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch.distributed as dist\n"
+        "from euispice_coreg_amd import parallel\n"
+        "from euispice_coreg_amd.hdrshift import Alignment\n"
+        "from tests import helpers as H\n"
+        "small, hs, large, hl, _ = H.scene()\n"
+        "def run(l1, l2, **kw):\n"
+        "    A = Alignment((large, hl), (small, hs), lag_crval1=l1, lag_crval2=l2, lag_cdelt1=None, lag_cdelt2=None,\n"
+        "                  lag_crota=[0.0, 0.3], parallelism=True)\n"
+        "    return A.align_using_carrington(lonlims=H.CARR_LON, latlims=H.CARR_LAT, shape=(72, 64), return_type='corr')\n"
+        "small_set = (17.0 + 2.0 * (np.arange(5) - 2), -9.0 + 2.0 * (np.arange(5) - 2))\n"
+        "big_set = (17.0 + 1.0 * (np.arange(24) - 12), -9.0 + 1.0 * (np.arange(24) - 12))\n"
+        "single = [run(*small_set), run(*big_set)]\n"
+        "dist.init_process_group('gloo')\n"
+        "rank, world = parallel.world_info()\n"
+        "assert parallel.use_point_sharding(50, world) and not parallel.use_point_sharding(24 * 24 * 2, world)\n"
+        "multi = [run(*small_set), run(*big_set)]\n"
+        "for a, b in zip(single, multi):\n"
+        "    assert a.shape == b.shape and np.nanmax(np.abs(a - b)) <= 1e-12, np.nanmax(np.abs(a - b))\n"
+        "dist.barrier(); dist.destroy_process_group()\n"
+        "print('rank', rank, 'ok')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29571", str(script)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2
