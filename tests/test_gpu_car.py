@@ -135,3 +135,27 @@ def test_car_invalid_target_header_is_an_error(gpu_handle):
     hl = dict(hl, CRVAL2=-20.0)  # LONPOLE = 0 south of the equator: astropy cannot build WCS(hdr_large) either
     with pytest.raises(_lib.CoregError):
         _sweep(gpu_handle, small, hs, large, hl, ([0.0], [0.0], None, None, None))
+
+
+@pytest.mark.parametrize("dlat,use_lds,tile_w", [(0.6, 1, 0), (0.6, 0, 0), (-0.8, 1, 256), (0.6, 1, 4)])
+def test_car_maps_with_different_reference_latitudes(gpu_handle, dlat, use_lds, tile_w):
+    """The map to align is referenced at a different latitude than the target map (oblique relation between the two
+    plate-carree grids: the per-lag map is a sphere rotation followed by atan2 / asin, not projective, so a tile's image
+    is not bounded by its mapped corners -- the sweep widens the corner boxes by a curvature margin).  Parity with the
+    oracle, NaN pattern included, for square, 256 x 4 and 4 x 256 tiles and for the global-memory gather."""
+    from euispice_coreg_amd import synthetic
+    small, hs, large, hl, _ = synthetic.make_car_scene(small_shape=(96, 128), large_shape=(180, 240), seed=11,
+                                                       crota=0.4, nan_frac=0.004)
+    hs = dict(hs, CRVAL2=hs["CRVAL2"] + dlat)
+    lags = (np.arange(-0.02, 0.03, 0.01), np.arange(-0.03, 0.02, 0.01), None, None, [0.0, 0.5])
+    gpu_handle.set_option("use_lds", use_lds)
+    gpu_handle.set_option("tile_w", tile_w)
+    try:
+        got = _sweep(gpu_handle, small, hs, large, hl, lags)
+    finally:
+        gpu_handle.set_option("use_lds", 1)
+        gpu_handle.set_option("tile_w", 0)
+    want = H.oracle_helio(small.astype(np.float64), hs, large.astype(np.float64), hl, lags, parallelism=False,
+                          unit_lag="deg")
+    assert np.isfinite(want).any()
+    H.assert_corr_close(got, want, 1e-7, f"CAR dlat={dlat} lds={use_lds} tile_w={tile_w}")
