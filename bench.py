@@ -8,18 +8,23 @@ lag-points), crota/cdelt fixed, solar_r 1.004, order 2, method 'correlation'; se
 2048^2 image to align and FSI-like 3072^2 reference (euispice_coreg_amd/synthetic.py).
 
 A "step" = one full sweep (all 3600 lag-points) through the C ABI with both images already RESIDENT in HBM
-(upload + once-only reference preparation happen before the timed region; `config.resident` says so, and the
-PCIe-inclusive rate of the same step is printed beside it as `pcie_inclusive`, never as `value`).  `--streams`
-(default 2) steps are in flight at a time, each on its own HIP stream and library context, so that the drain of one
-sweep overlaps the start of the next; every step is a complete sweep, and the rate with ONE sweep in flight is printed
-as `one_sweep_in_flight`.
+(upload + once-only reference preparation happen before the timed region; `config.resident` says so).  That is what the
+driver's contract defines `value` on (inputs resident when the timed region starts).  The metric as BASELINE.md section
+2 words it -- L / wall time of ONE call that is handed host images: upload, reference preparation, sweep, all-gather,
+map on the host -- is measured right after the timed region AT EVERY N and printed as `pcie_inclusive` (never as
+`value`).  `--streams` (default 2) steps are in flight at a time, each on its own HIP stream and library context, so that
+the drain of one sweep overlaps the start of the next; every step is a complete sweep, and the rate with ONE sweep in
+flight is printed as `one_sweep_in_flight`.
 
 N > 1: `python bench.py --gpus N` starts its own N rank processes (torch.distributed.run, one rank per GPU) as CHILDREN,
 before anything in this process has touched the GPU, and exits with their return code; launched under torchrun
-(WORLD_SIZE set) it is a rank.  The (CRVAL1, CRVAL2) lag plane is cut in N blocks (the multi-GPU form of the
+(WORLD_SIZE set) it is a rank.  The lag set is spread exactly as `hdrshift.Alignment` spreads it
+(euispice_coreg_amd.parallel.lag_sharding): the (CRVAL1, CRVAL2) lag plane is cut in N blocks (the multi-GPU form of the
 reference's np.array_split fan-out, alignment.py:677-687), every rank sweeps its block with full image replicas and
 ONE all-gather (RCCL) of the per-lag coefficients, followed by an index permutation, assembles the map on every rank.
-Total work is fixed as N grows -> "scaling": "strong".
+Total work is fixed as N grows -> "scaling": "strong".  The N > 1 line verifies itself: after the timed region rank 0
+sweeps the FULL lag set on its own GPU (`map_vs_single_gpu`), a CPU sample of 128 lag-points is evaluated by the oracle
+(`parity_vs_cpu_sample`), and `n_ranks_seen` is the size of the communicator the collective ran on.
 
 Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` and `cpu_baseline` objects.
 """
@@ -97,6 +102,24 @@ def pmc_summary():
     return vals, os.path.relpath(paths[-1], ROOT)
 
 
+def kernel_profile_ms():
+    """Average duration of the headline sweep kernel in the newest committed rocprofv3 --kernel-trace --stats summary of
+    this command with one sweep in flight (profiles/rNN_kernel_stats_streams1.csv); (None, None) when none is committed."""
+    import csv
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_stats_streams1.csv")))
+    if not paths:
+        return None, None
+    try:
+        with open(paths[-1], newline="") as f:
+            for row in csv.DictReader(f):
+                if "k_sweep" in row.get("Name", ""):
+                    return float(row["AverageNs"]) * 1e-6, os.path.relpath(paths[-1], ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
 def cpu_baseline(np, small, hs, large, hl, lags, n_sample, cores):
     """The oracle's restatement of the reference's parallelism=True path (process fan-out over np.array_split
     chunks, images in shared memory), timed on a seeded random subsample of the same 3600 lag-points."""
@@ -129,6 +152,8 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement after the timed region")
     ap.add_argument("--cpu-sample", type=int, default=0, help="lag-points in the CPU sample (0 = 48 per core)")
     ap.add_argument("--use-lds", type=int, default=1)
+    ap.add_argument("--small-f64", action="store_true",
+                    help="image to align with full float64 pixels (not float32-exact): times the TS = double kernel")
     ap.add_argument("--shard", choices=["auto", "lags", "points"], default="auto",
                     help="N > 1: cut the lag plane in blocks (+ one all-gather) or the target grid in point shares "
                          "(+ one all-reduce of the six sums per lag); auto = points below 128 lag-points per GPU")
@@ -189,8 +214,9 @@ def main():
     lag2 = np.arange(-30, 30, 1, dtype=np.float64)
     lags = (lag1, lag2, None, None, None)
     L = lag1.size * lag2.size
-    by_points = world > 1 and (args.shard == "points" or
-                               (args.shard == "auto" and parallel.use_point_sharding(L, world)))
+    # the partition Alignment would use for this lag set (parallel.lag_sharding), unless --shard forces one
+    auto_mode = parallel.lag_sharding((lag1.size, lag2.size, 1, 1, 1), world)
+    by_points = world > 1 and (args.shard == "points" or (args.shard == "auto" and auto_mode == "points"))
     if by_points:  # every rank sweeps ALL lag-points over its share of the grid
         lo1, hi1, lo2, hi2 = 0, lag1.size, 0, lag2.size
     else:
@@ -207,7 +233,7 @@ def main():
         block = (np.arange(lo1, hi1)[:, None] * lag2.size + np.arange(lo2, hi2)[None, :]).astype(np.float64).ravel()
     else:
         t0 = time.time()
-        small, hs, large, hl, truth = synthetic.make_scene()
+        small, hs, large, hl, truth = synthetic.make_scene(float32_exact=not args.small_f64)
         if rank == 0:
             log(f"[bench] scene built in {time.time() - t0:.1f} s; L = {L}")
         # `--streams S` sweeps are in flight at a time, each on its own HIP stream with its own library context: the
@@ -230,6 +256,17 @@ def main():
             if by_points:
                 hk.set_point_shard(rank, world)
             handles.append(hk)
+
+        def same_pivots(hk):
+            """Point shares: the ranks' six sums only add up about identical pivots -- rank 0's are used everywhere."""
+            if not (by_points and use_dist):
+                return
+            piv = torch.tensor(hk.get_pivots(), dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.broadcast(piv, src=0)
+            hk.set_pivots(float(piv[0]), float(piv[1]))
+
+        for hk in handles:
+            same_pivots(hk)
         h = handles[0]
         my_lags = _lib.LagSet(lag1[lo1:hi1], lag2[lo2:hi2], None, None, None) if have_lags else None
 
@@ -341,25 +378,67 @@ def main():
         per_rank = gathered_stats
     corr = result[0].cpu().numpy().reshape(lag1.size, lag2.size)
 
-    # the boundary hands over host buffers: the same step with both images uploaded (and the reference re-prepared) and
-    # the map copied back to the host every call -- reported beside `value`, never as `value`
+    # ---- BASELINE.md section 2 at every N: ONE call that is handed host images.  Every rank uploads its share of both
+    # images (the float32 pixels a BITPIX=-32 FITS file holds: 16 + 36 MiB in all; with RCCL 1/N per rank + one all-gather
+    # over xGMI, parallel.replicate_image; one rank or gloo: the whole images), prepares the reference, sweeps its block,
+    # the all-gather assembles the map and every rank copies it to the host.  Barrier on both sides, max over ranks,
+    # best of 4 after one warm-up.
     pcie = None
-    if world == 1 and not args.no_pcie and not dry:
-        full_lags = _lib.LagSet(*lags)
-        small32, large32 = small_m.astype(np.float32), large.astype(np.float32)  # what a BITPIX=-32 FITS file holds
+    if not args.no_pcie and not dry:
+        small_h = small_m if args.small_f64 else small_m.astype(np.float32)
+        large_h = large.astype(np.float32)
         times = []
+        out_host = None
         for _ in range(5):
+            if use_dist:
+                dist.barrier()
+            sync()
             t0 = time.perf_counter()
-            h.set_small(small32)
-            h.prepare_reference_carrington(large32, hl, grid, SOLAR_R, ORDER)
-            out_host = h.sweep_carrington(hs, grid, SOLAR_R, full_lags, order=ORDER)
-            times.append(time.perf_counter() - t0)
+            with torch.cuda.stream(streams[0]):
+                ts = parallel.replicate_image(small_h) if use_dist else None
+                tl = parallel.replicate_image(large_h) if use_dist else None
+                if ts is None:
+                    h.set_small(small_h)
+                    h.prepare_reference_carrington(large_h, hl, grid, SOLAR_R, ORDER)
+                else:  # (the handle runs on streams[0] = torch's current stream here: stream-ordered, no sync needed)
+                    h.set_small_from_device(ts.data_ptr(), ts.shape, small_h.dtype)
+                    h.prepare_reference_carrington_from_device(tl.data_ptr(), tl.shape, np.float32, hl, grid, SOLAR_R,
+                                                               ORDER)
+                same_pivots(h)
+            step_no[0] = 0
+            step(1)  # sweep of this rank's block (+ the one collective) on stream / handle 0
+            out_host = result[0].cpu().numpy()  # the map on the host: waits for everything above
+            el = time.perf_counter() - t0
+            if use_dist:
+                t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            times.append(el)
         best = min(times[1:])
-        pcie = {"value": L / best, "unit": "lag-points/s", "ms_per_step": 1e3 * best,
+        pcie = {"value": L / best, "unit": "lag-points/s", "ms_per_step": 1e3 * best, "n_gpus": world,
+                "image_hand_over": ("1/N of each image per rank over its own PCIe link + one all-gather over xGMI"
+                                    if (use_dist and backend == "nccl" and world > 1) else
+                                    "every rank uploads both images whole"),
                 "identical_to_resident_map": bool(np.array_equal(out_host.reshape(corr.shape), corr, equal_nan=True)),
-                "what": "SURVEY 8d wall time of one call: host float32 images in (2048^2 image to align + 3072^2 "
-                        "reference = 52 MiB, the pixels a BITPIX=-32 FITS file holds; reference re-prepared), sweep, "
-                        "host correlation map out; best of 4 after one warm-up"}
+                "what": "BASELINE.md section 2 / SURVEY 8d: wall time of one call with host images in (2048^2 image to "
+                        "align + 3072^2 reference, float32 = 52 MiB; reference re-prepared), sweep, all-gather, host "
+                        "correlation map out; barrier on both sides, max over ranks, best of 4 after one warm-up"}
+
+    # ---- N > 1: the gathered map against ONE GPU sweeping everything (rank 0, after the timed region)
+    vs_single = None
+    if world > 1 and not dry and rank == 0:
+        single = h.sweep_carrington(hs, grid, SOLAR_R, _lib.LagSet(*lags), order=ORDER).reshape(corr.shape) \
+            if not by_points else None
+        if by_points:  # the handles are in point-shard mode: a fresh context for the unsharded sweep
+            with _lib.CoregHandle(local_rank) as h1:
+                h1.set_small(small_m)
+                h1.prepare_reference_carrington(large, hl, grid, SOLAR_R, ORDER)
+                single = h1.sweep_carrington(hs, grid, SOLAR_R, _lib.LagSet(*lags), order=ORDER).reshape(corr.shape)
+        vs_single = {"max_abs_diff": float(np.nanmax(np.abs(single - corr))),
+                     "same_nan_pattern": bool(np.array_equal(np.isnan(single), np.isnan(corr))),
+                     "same_argmax": bool(np.nanargmax(single) == np.nanargmax(corr)), "tolerance": 1e-12,
+                     "what": "rank 0 sweeps all 3600 lag-points on its own GPU after the timed region; compared with "
+                             "the map the N ranks assembled"}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -376,7 +455,7 @@ def main():
             # the binding resources are float64 VALU issue and the LDS gather, co-limited
             "bound": "valu_fp64+lds", "achieved": achieved_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
             "frac": achieved_tf / FP64_VALU_PEAK_TF,
-            "kernel": "k_sweep<TRANSLATE,2,f32>", "kernel_ms": k_ms, "lags_per_launch": lags_per_launch,
+            "kernel": "k_sweep<TRANSLATE,2,%s>" % ("f32" if stats["small_is_f32"] else "f64"), "kernel_ms": k_ms, "lags_per_launch": lags_per_launch,
             "active_points": act, "flop_per_point_lag": FLOP_PER_POINT_LAG,
             "f64_instr_per_point_lag": F64_INSTR_PER_POINT_LAG,
             "traffic": None, "hbm_model": {
@@ -400,6 +479,10 @@ def main():
                 if "SQ_LDS_BANK_CONFLICT" in pmc:
                     roof["lds_conflict_cycle_frac"] = pmc["SQ_LDS_BANK_CONFLICT"] / pmc["SQ_LDS_IDX_ACTIVE"]
             roof["pmc_source"] = f"{pmc_path} (rocprofv3 --pmc means per launch of this command, committed)"
+        prof_ms, prof_path = kernel_profile_ms()
+        if prof_ms is not None:
+            roof["kernel_profile_ms"] = prof_ms
+            roof["kernel_profile_source"] = f"{prof_path} (rocprofv3 --kernel-trace --stats of this command, committed)"
         am = np.unravel_index(np.nanargmax(corr), corr.shape)
         out = {
             "metric": METRIC,
@@ -414,20 +497,37 @@ def main():
                        "parallelism": (f"grid point shares x{world} + 1 all-reduce of the six sums per lag ({backend})"
                                        if by_points else f"lag-plane blocks x{world} + 1 all-gather ({backend})"),
                        "resident": True, "sweeps_in_flight": n_streams,
-                       "small_stored_f32": bool(stats["small_is_f32"]), "use_lds": bool(stats["used_lds"])},
+                       "small_stored_f32": bool(stats["small_is_f32"]), "use_lds": bool(stats["used_lds"]),
+                       "lag_sharding": "points" if by_points else ("blocks" if world > 1 else "none")},
             "one_sweep_in_flight": None if one_in_flight is None else
             {"value": L / one_in_flight, "unit": "lag-points/s", "ms_per_step": 1e3 * one_in_flight},
             "roofline": roof,
             "per_rank": per_rank,
             "precompute_ms": float(np.mean(pre_ms)),
             "pcie_inclusive": pcie,
+            "map_vs_single_gpu": vs_single,
             "argmax_lag_arcsec": [float(lag1[am[0]]), float(lag2[am[1]])],
             "injected_shift_arcsec": [truth["lag_crval1"], truth["lag_crval2"]],
         }
         if dry:
             out["dry_run"] = True
             out["dry_run_map_ok"] = bool(np.array_equal(corr.ravel(), np.arange(L, dtype=np.float64)))
-        if not args.no_cpu_baseline and world == 1 and not dry:  # the CPU leg is timed at N = 1 only
+        if not args.no_cpu_baseline and world > 1 and not dry:
+            # N > 1: no CPU timing (that leg belongs to the N = 1 line), but the assembled map is still checked against
+            # the oracle on a seeded sample of 128 lag-points
+            log("[bench] CPU parity sample: 128 lag-points ...")
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            cores = max(1, min(avail // max(world, 1), 8))
+            _, corr_cpu, subset = cpu_baseline(np, small, hs, large, hl, lags, 128, cores)
+            d = np.abs(corr.ravel()[subset] - corr_cpu.ravel()[subset])
+            out["parity_vs_cpu_sample"] = {"max_abs_dcorr": float(np.nanmax(d)), "n": int(len(subset)),
+                                           "argmax_on_sample_equal": bool(np.nanargmax(corr.ravel()[subset]) ==
+                                                                          np.nanargmax(corr_cpu.ravel()[subset]))}
+            out["cpu_baseline"] = None
+        elif not args.no_cpu_baseline and world == 1 and not dry:  # the CPU leg is timed at N = 1 only
             # the GPU box gives one GPU's job a 16-core share whatever os.cpu_count() says
             try:
                 avail = len(os.sched_getaffinity(0))

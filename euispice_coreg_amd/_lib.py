@@ -80,6 +80,11 @@ SYMBOLS = [
     ("coreg_prepare_reference_carrington_f32", C.c_int,
      [_P, _P, C.c_int32, C.c_int32, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
     ("coreg_prepare_reference_helioprojective_f32", C.c_int, [_P, _P, C.c_int32, C.c_int32, _WP, _WP, C.c_int]),
+    ("coreg_set_small_from_device", C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32]),
+    ("coreg_prepare_reference_carrington_from_device", C.c_int,
+     [_P, _P, C.c_int, C.c_int32, C.c_int32, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
+    ("coreg_prepare_reference_helioprojective_from_device", C.c_int,
+     [_P, _P, C.c_int, C.c_int32, C.c_int32, _WP, _WP, C.c_int]),
     ("coreg_get_reference_on_grid", C.c_int, [_P, _P, C.c_int]),
     ("coreg_resample_carrington", C.c_int, [_P, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int, _P]),
     ("coreg_resample_helioprojective", C.c_int, [_P, _WP, _WP, C.c_int, _P]),
@@ -92,6 +97,8 @@ SYMBOLS = [
     ("coreg_sums_size", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("coreg_copy_sums", C.c_int, [_P, _P, C.c_int]),
     ("coreg_finalize_sums", C.c_int, [_P, _P, C.c_int, _P, C.c_int]),
+    ("coreg_get_pivots", C.c_int, [_P, C.POINTER(C.c_double)]),
+    ("coreg_set_pivots", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("coreg_last_stats", C.c_int, [_P, C.POINTER(Stats)]),
     ("coreg_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("coreg_shift_header", C.c_int,
@@ -102,6 +109,7 @@ SYMBOLS = [
     ("coreg_carrington_origin", C.c_int, [_WP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("coreg_car_map", C.c_int, [_WP, _WP, C.c_int64, _P, _P, _P, _P]),
     ("coreg_wcslib_pixel_to_pixel", C.c_int, [_WP, _WP, C.c_int64, _P, _P, _P, _P, _P, _P]),
+    ("coreg_car_tile_margin", C.c_int, [_WP, _WP, C.c_int32, C.c_double, C.POINTER(C.c_double)]),
 ]
 
 _lib = None
@@ -306,6 +314,34 @@ class CoregHandle:
             self._lib.coreg_prepare_reference_helioprojective
         self._chk(fn(self._h, large.ctypes.data, large.shape[0], large.shape[1], C.byref(wl), C.byref(ws), int(order)))
 
+    # -- the same with the pixels already on this GPU (device pointer + shape + numpy dtype float32 / float64)
+    @staticmethod
+    def _dev_dtype(dtype):
+        dt = np.dtype(dtype)
+        if dt == np.float32:
+            return COREG_F32
+        if dt == np.float64:
+            return COREG_F64
+        raise ValueError("device images must be float32 or float64")
+
+    def set_small_from_device(self, dev_ptr, shape, dtype=np.float32):
+        self._chk(self._lib.coreg_set_small_from_device(self._h, _P(int(dev_ptr)), self._dev_dtype(dtype),
+                                                        int(shape[0]), int(shape[1])))
+
+    def prepare_reference_carrington_from_device(self, dev_ptr, shape, dtype, hdr_large, grid: Grid, solar_r, order=2):
+        w = wcs_from_header(hdr_large, carrington=True)
+        self.reference_tag = None
+        self._chk(self._lib.coreg_prepare_reference_carrington_from_device(
+            self._h, _P(int(dev_ptr)), self._dev_dtype(dtype), int(shape[0]), int(shape[1]), C.byref(w),
+            C.byref(grid.c), float(solar_r), int(order)))
+
+    def prepare_reference_helioprojective_from_device(self, dev_ptr, shape, dtype, hdr_large, hdr_small, order=2):
+        wl, ws = wcs_from_header(hdr_large), wcs_from_header(hdr_small)
+        self.reference_tag = None
+        self._chk(self._lib.coreg_prepare_reference_helioprojective_from_device(
+            self._h, _P(int(dev_ptr)), self._dev_dtype(dtype), int(shape[0]), int(shape[1]), C.byref(wl), C.byref(ws),
+            int(order)))
+
     def get_reference_on_grid(self, shape, dtype):
         out = np.empty(shape, dtype=dtype)
         dt = COREG_F32 if out.dtype == np.float32 else COREG_F64
@@ -391,6 +427,16 @@ class CoregHandle:
         self._chk(self._lib.coreg_finalize_sums(self._h, _P(sptr), s_dev, _P(int(out_dev_ptr)), 1))
         return None
 
+    def get_pivots(self):
+        """(mean of the finite reference values on the grid, mean of the finite pixels of the image to align)."""
+        p = (C.c_double * 2)()
+        self._chk(self._lib.coreg_get_pivots(self._h, p))
+        return float(p[0]), float(p[1])
+
+    def set_pivots(self, pivot_ref, pivot_small):
+        p = (C.c_double * 2)(float(pivot_ref), float(pivot_small))
+        self._chk(self._lib.coreg_set_pivots(self._h, p))
+
     def last_stats(self) -> dict:
         s = Stats()
         self._chk(self._lib.coreg_last_stats(self._h, C.byref(s)))
@@ -474,6 +520,19 @@ def car_map(hdr_from, hdr_to, px, py):
     if rc != COREG_OK:
         raise CoregError(rc, "coreg_car_map: bad arguments")
     return ox, oy
+
+
+def car_tile_margin(hdr_target, hdr_shifted, tile_w, tile_abs_lat_rad):
+    """Pixels by which k_sweep widens a CAR tile's corner box (host, no GPU); None when a header has no valid pole."""
+    lib = load_library()
+    wf, wt = wcs_from_header(hdr_target), wcs_from_header(hdr_shifted)
+    m = C.c_double()
+    rc = lib.coreg_car_tile_margin(C.byref(wf), C.byref(wt), int(tile_w), float(tile_abs_lat_rad), C.byref(m))
+    if rc == 1:
+        return None
+    if rc != COREG_OK:
+        raise CoregError(rc, "coreg_car_tile_margin: bad arguments")
+    return m.value
 
 
 def wcslib_pixel_to_pixel(hdr_from, hdr_to, px, py):

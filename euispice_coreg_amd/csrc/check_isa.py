@@ -24,13 +24,22 @@ def disassemble(lib):
         fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
         subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fat],
                        check=True, capture_output=True)
-        subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--unbundle",
-                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"], check=True,
-                       capture_output=True)
-        if os.path.getsize(co) == 0:
-            raise RuntimeError("no gfx950 code object in " + lib)
-        return subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", co], check=True,
-                              capture_output=True, text=True).stdout
+        # the device targets the library was actually built for (not assumed): every one of them is disassembled
+        listing = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--list", f"--input={fat}"],
+                                 check=True, capture_output=True, text=True).stdout.split()
+        targets = [t for t in listing if t.startswith("hip") and "amdgcn" in t]
+        if not targets:
+            raise RuntimeError("no AMD GPU code object in " + lib)
+        text = []
+        for t in targets:
+            subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--unbundle", f"--targets={t}",
+                            f"--input={fat}", f"--output={co}"], check=True, capture_output=True)
+            if os.path.getsize(co) == 0:
+                raise RuntimeError(f"empty code object for {t} in {lib}")
+            arch = t.split("-")[-1].split(":")[0]
+            text.append(subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", f"--mcpu={arch}", co], check=True,
+                                       capture_output=True, text=True).stdout)
+        return "\n".join(text)
 
 
 def regs(tok):
@@ -91,8 +100,79 @@ def check(text):
     return n_groups, bad
 
 
+def sregs(tok):
+    """SGPR numbers named by an operand token such as s12, s[36:43]."""
+    out = set()
+    for m in re.finditer(r"\bs\[(\d+):(\d+)\]", tok):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bs(\d+)\b", tok):
+        out.add(int(m.group(1)))
+    return out
+
+
+def check_scalar_loads(text):
+    """The point data of k_sweep come through hand-issued `s_load_dwordx8` (kernels.hpp spt_load) whose completion the
+    compiler does not track: nothing may name the destination SGPRs before an `s_waitcnt lgkmcnt(0)` is reached -- on
+    the fall-through path and on the target of every forward branch taken before that wait."""
+    lines = text.splitlines()
+    addr_of = {}
+    for idx, ln in enumerate(lines):
+        m = re.search(r"//\s*([0-9A-Fa-f]{8,16}):", ln)
+        if m:
+            addr_of.setdefault(int(m.group(1), 16), idx)
+    n_loads, bad = 0, []
+    kernel = "?"
+    for i, ln in enumerate(lines):
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", ln)
+        if m:
+            kernel = m.group(1)
+        ins = ln.strip().split("//")[0].strip()
+        if not (ins.startswith("s_load_dwordx8") and "k_sweep" in kernel):
+            continue
+        dst = sregs(ins.split(None, 1)[1].split(",")[0])
+        n_loads += 1
+        work, seen = [i + 1], set()
+        while work:
+            k = work.pop()
+            steps = 0
+            while k < len(lines) and k not in seen and steps < 4000:
+                seen.add(k)
+                steps += 1
+                t = lines[k].strip().split("//")[0].strip()
+                if re.match(r"^[0-9a-f]+ <", lines[k]) or t.startswith("s_endpgm"):
+                    break
+                if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
+                    break
+                if t and not t.startswith((";", "s_nop")) and " " in t:
+                    if sregs(t.split(None, 1)[1]) & dst:
+                        bad.append((kernel, t))
+                        break
+                mb = re.match(r"s_(c?branch\w*)\s+(\d+)", t)
+                if mb:
+                    am = re.search(r"//\s*([0-9A-Fa-f]{8,16}):", lines[k])
+                    off = int(mb.group(2))
+                    off = off - 65536 if off >= 32768 else off
+                    if am:
+                        tgt = addr_of.get(int(am.group(1), 16) + 4 + 4 * off)
+                        if tgt is not None and off > 0:
+                            work.append(tgt)
+                        elif off <= 0 and mb.group(1) == "branch":
+                            break  # loop back edge: the wait at the end of the point was on the way
+                    if mb.group(1) == "branch":
+                        break
+                k += 1
+    return n_loads, bad
+
+
 def main(lib):
-    n, bad = check(disassemble(lib))
+    text = disassemble(lib)
+    n_s, bad_s = check_scalar_loads(text)
+    if bad_s:
+        for k, t in bad_s[:20]:
+            print("check_isa: SGPR of a pending scalar point load named before the wait:", k, "|", t, file=sys.stderr)
+        raise SystemExit(f"check_isa: {len(bad_s)} scalar-load violation(s)")
+    print(f"[check_isa] ok: {n_s} s_load_dwordx8 in k_sweep, none has its SGPRs named before an lgkmcnt(0) wait")
+    n, bad = check(text)
     if n == 0:
         raise SystemExit("check_isa: no hand-issued ds_read_b64 group found in k_sweep (disassembly format changed?)")
     if bad:

@@ -301,16 +301,20 @@ int staged_upload(coreg_handle* h, void* dev, const void* host, size_t bytes) {
     return COREG_OK;
 }
 
-// upload a float64 host image; it is kept as float32 on the device when every finite value is exactly representable
-// (FITS BITPIX=-32 / integer data cast to float64), else as float64.  The test and the conversion run on the GPU.
-int upload_image(coreg_handle* h, const double* img, size_t n, DevBuf& buf, bool* is_f32) {
-    HIPCHK(h->up_f64.reserve(n * sizeof(double)));
+// A float64 image (host: staged upload; device: the caller's buffer) is kept as float32 on the device when every finite
+// value is exactly representable (FITS BITPIX=-32 / integer data cast to float64), else as float64.  The test and the
+// conversion run on the GPU.  src_on_device: `img` is device memory, read by work enqueued on the handle's stream.
+int upload_image(coreg_handle* h, const double* img, size_t n, DevBuf& buf, bool* is_f32, bool src_on_device = false) {
     HIPCHK(h->up_flag.reserve(sizeof(int)));
-    RETCHK(staged_upload(h, h->up_f64.p, img, n * sizeof(double)));
+    const double* src = img;
+    if (!src_on_device) {
+        HIPCHK(h->up_f64.reserve(n * sizeof(double)));
+        RETCHK(staged_upload(h, h->up_f64.p, img, n * sizeof(double)));
+        src = h->up_f64.as<double>();
+    }
     HIPCHK(hipMemsetAsync(h->up_flag.p, 0, sizeof(int), h->stream));
     const int nb = (int)std::min<size_t>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_f32_exact, dim3(nb), dim3(256), 0, h->stream, h->up_f64.as<double>(), (long long)n,
-                       h->up_flag.as<int>());
+    hipLaunchKernelGGL(k_f32_exact, dim3(nb), dim3(256), 0, h->stream, src, (long long)n, h->up_flag.as<int>());
     HIPCHK(hipGetLastError());
     int flag = 0;
     HIPCHK(hipMemcpyAsync(&flag, h->up_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -318,9 +322,11 @@ int upload_image(coreg_handle* h, const double* img, size_t n, DevBuf& buf, bool
     *is_f32 = flag == 0;
     if (*is_f32) {
         HIPCHK(buf.reserve(n * sizeof(float)));
-        hipLaunchKernelGGL(k_f64_to_f32, dim3(nb), dim3(256), 0, h->stream, h->up_f64.as<double>(), (long long)n,
-                           buf.as<float>());
+        hipLaunchKernelGGL(k_f64_to_f32, dim3(nb), dim3(256), 0, h->stream, src, (long long)n, buf.as<float>());
         HIPCHK(hipGetLastError());
+    } else if (src_on_device) {
+        HIPCHK(buf.reserve(n * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(buf.p, src, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     } else {
         std::swap(buf.p, h->up_f64.p);  // the float64 copy becomes the image
         std::swap(buf.cap, h->up_f64.cap);
@@ -1047,6 +1053,11 @@ int begin_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_d
     // timings of a still-uncollected device-output sweep are dropped (its events are re-recorded below): starting the
     // next sweep never waits for the previous one
     h->stats_pending = false;
+    // sums of an earlier point-sharded sweep must not outlive it: a sweep that returns early (empty slice, no launch)
+    // would otherwise leave them for coreg_copy_sums / coreg_finalize_sums to pick up
+    h->pending_fin.clear();
+    h->sums_slots = 0;
+    h->pending_n_out = 0;
     if (!h->small.p) return fail(h, COREG_ESTATE, "coreg_set_small has not been called");
     if (!h->ref.p) return fail(h, COREG_ESTATE, "no reference image on the target grid");
     if (!corr_out && n_out > 0) return fail(h, COREG_EINVAL, "corr_out is null");
@@ -1307,6 +1318,25 @@ int coreg_set_small_f32(coreg_handle* h, const float* img, int32_t ny, int32_t n
     return device_mean<float>(h, h->small.as<float>(), (long long)n, h->pivots.as<double>() + 1);
 }
 
+int coreg_set_small_from_device(coreg_handle* h, const void* dev_img, int dtype, int32_t ny, int32_t nx) {
+    if (!h) return COREG_EINVAL;
+    if (!dev_img || ny < 1 || nx < 1 || (dtype != COREG_F32 && dtype != COREG_F64))
+        return fail(h, COREG_EINVAL, "set_small_from_device: bad argument");
+    RETCHK(bind_device(h));
+    const size_t n = (size_t)ny * nx;
+    if (dtype == COREG_F32) {
+        HIPCHK(h->small.reserve(n * sizeof(float)));
+        HIPCHK(hipMemcpyAsync(h->small.p, dev_img, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        h->small_f32 = true;
+    } else {
+        RETCHK(upload_image(h, (const double*)dev_img, n, h->small, &h->small_f32, true));
+    }
+    h->sW = nx;
+    h->sH = ny;
+    if (h->small_f32) return device_mean<float>(h, h->small.as<float>(), (long long)n, h->pivots.as<double>() + 1);
+    return device_mean<double>(h, h->small.as<double>(), (long long)n, h->pivots.as<double>() + 1);
+}
+
 int coreg_threshold_small(coreg_handle* h, int has_min, double vmin, int has_max, double vmax, long long* n_finite) {
     if (!h) return COREG_EINVAL;
     if (!h->small.p) return fail(h, COREG_ESTATE, "coreg_set_small has not been called");
@@ -1361,28 +1391,41 @@ int coreg_set_reference_on_grid(coreg_handle* h, const void* ref, int dtype, int
 
 // the reference image's pixels: float64 from the caller (tested for float32-exactness on the GPU), or the float32
 // pixels a BITPIX=-32 FITS file holds (half the PCIe bytes; the reference's float64 cast of them is exact)
-static int upload_reference_source(coreg_handle* h, const void* large, size_t n, bool src_f32, bool* f32) {
-    if (!src_f32) return upload_image(h, (const double*)large, n, h->tmp_img, f32);
-    HIPCHK(h->tmp_img.reserve(n * sizeof(float)));
-    RETCHK(staged_upload(h, h->tmp_img.p, large, n * sizeof(float)));
-    *f32 = true;
+// (src_on_device: the pixels are read where they are, by the resample kernel on the handle's stream -- no copy)
+static int upload_reference_source(coreg_handle* h, const void* large, size_t n, bool src_f32, bool* f32,
+                                   bool src_on_device, const void** img_dev) {
+    if (src_on_device) {
+        *f32 = src_f32;
+        *img_dev = large;
+        return COREG_OK;
+    }
+    if (!src_f32) {
+        RETCHK(upload_image(h, (const double*)large, n, h->tmp_img, f32));
+    } else {
+        HIPCHK(h->tmp_img.reserve(n * sizeof(float)));
+        RETCHK(staged_upload(h, h->tmp_img.p, large, n * sizeof(float)));
+        *f32 = true;
+    }
+    *img_dev = h->tmp_img.p;
     return COREG_OK;
 }
 
 static int prepare_carrington(coreg_handle* h, const void* large, bool src_f32, int32_t ny, int32_t nx,
-                              const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r, int order) {
+                              const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r, int order,
+                              bool src_on_device = false) {
     if (!h) return COREG_EINVAL;
     if (!large || !hdr || !grid || ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
     RETCHK(check_order(h, order));
     RETCHK(bind_device(h));
     bool f32;
-    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, src_f32, &f32));
+    const void* img_dev = nullptr;
+    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, src_f32, &f32, src_on_device, &img_dev));
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
     RETCHK(upload_carr_tables(h, *grid, *hdr, &a.carr));
     set_carr_common(&a.carr, carr_common(*hdr, solar_r));
     carr_origin(*hdr, &a.x0, &a.y0);
-    a.img = h->tmp_img.p;
+    a.img = img_dev;
     a.W = nx;
     a.H = ny;
     a.gw = grid->n_lon;
@@ -1410,7 +1453,8 @@ int coreg_prepare_reference_carrington_f32(coreg_handle* h, const float* large, 
 }
 
 static int prepare_helioprojective(coreg_handle* h, const void* large, bool src_f32, int32_t ny, int32_t nx,
-                                   const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order) {
+                                   const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order,
+                                   bool src_on_device = false) {
     if (!h) return COREG_EINVAL;
     if (!large || !hdr_large || !hdr_small || ny < 1 || nx < 1)
         return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
@@ -1420,11 +1464,12 @@ static int prepare_helioprojective(coreg_handle* h, const void* large, bool src_
     RETCHK(check_order(h, order));
     RETCHK(bind_device(h));
     bool f32;
-    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, src_f32, &f32));
+    const void* img_dev = nullptr;
+    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, src_f32, &f32, src_on_device, &img_dev));
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
     homography(*hdr_small, *hdr_large, a.hom.h);  // alignment.py:993: pixels of hdr_cut -> pixels of hdr_large
-    a.img = h->tmp_img.p;
+    a.img = img_dev;
     a.W = nx;
     a.H = ny;
     a.gw = hdr_small->naxis1;
@@ -1448,6 +1493,20 @@ int coreg_prepare_reference_helioprojective_f32(coreg_handle* h, const float* la
                                                 const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small,
                                                 int order) {
     return prepare_helioprojective(h, large, true, ny, nx, hdr_large, hdr_small, order);
+}
+
+int coreg_prepare_reference_carrington_from_device(coreg_handle* h, const void* dev_large, int dtype, int32_t ny,
+                                                   int32_t nx, const coreg_wcs2d* hdr_large,
+                                                   const coreg_carr_grid* grid, double solar_r, int order) {
+    if (h && dtype != COREG_F32 && dtype != COREG_F64) return fail(h, COREG_EINVAL, "prepare_reference: bad dtype");
+    return prepare_carrington(h, dev_large, dtype == COREG_F32, ny, nx, hdr_large, grid, solar_r, order, true);
+}
+
+int coreg_prepare_reference_helioprojective_from_device(coreg_handle* h, const void* dev_large, int dtype, int32_t ny,
+                                                        int32_t nx, const coreg_wcs2d* hdr_large,
+                                                        const coreg_wcs2d* hdr_small, int order) {
+    if (h && dtype != COREG_F32 && dtype != COREG_F64) return fail(h, COREG_EINVAL, "prepare_reference: bad dtype");
+    return prepare_helioprojective(h, dev_large, dtype == COREG_F32, ny, nx, hdr_large, hdr_small, order, true);
 }
 
 int coreg_get_reference_on_grid(coreg_handle* h, void* out, int dtype) {
@@ -1773,24 +1832,22 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
         L.slot_off = outidx.size();
         L.n_batches = slots.n_batches;
         const Affine2 inv = car_native_to_pix(hc);
-        L.inv = {inv.m00, inv.m01, inv.m10, inv.m11, inv.b0, inv.b1};
-        {
-            // curvature margin of k_sweep's corner boxes: over a tile of angular half-size s the map deviates from the
-            // box of its corners by at most ~ C s^2 / 2 radians, C = 1 + tan(latitude) <= 13 below 85 deg
-            const int th = kTilePts / plan.tile_w;
-            const double step = std::max(std::fabs(hdr_target->cdelt1), std::fabs(hdr_target->cdelt2)) *
-                                hdr_target->unit_to_deg * kDeg2Rad;
-            const double s_half = 0.5 * step * std::hypot((double)plan.tile_w, (double)th);
-            const double px_per_rad = 1.0 / (std::min(std::fabs(hc.cdelt1), std::fabs(hc.cdelt2)) * hc.unit_to_deg *
-                                             kDeg2Rad);
-            L.inv.box_margin = 1.0 + 0.5 * 13.0 * s_half * s_half * px_per_rad;
-        }
+        std::memset(&L.inv, 0, sizeof(L.inv));
+        L.inv.m00 = inv.m00;
+        L.inv.m01 = inv.m01;
+        L.inv.m10 = inv.m10;
+        L.inv.m11 = inv.m11;
+        L.inv.b0 = inv.b0;
+        L.inv.b1 = inv.b1;
+        L.inv.box_c = car_box_c(*hdr_target, hc, plan.tile_w);
+        L.inv.pole_sep = 0.0;  // largest over the lags of this launch (below)
         const size_t pbase = params.size();
         params.resize(pbase + 9 * ns);
         for (size_t s = 0; s < ns; ++s) {
             const bool pad = slots.outidx[s] < 0;
             const double* r = &rot[((size_t)(slots.i1[s] - i1_lo) * d.n2 + slots.i2[s]) * 9];
             for (int k = 0; k < 9; ++k) params[pbase + (size_t)k * ns + s] = pad ? nanv : r[k];
+            if (!pad && r[8] == r[8]) L.inv.pole_sep = std::max(L.inv.pole_sep, car_pole_sep(r));
         }
         outidx.insert(outidx.end(), slots.outidx.begin(), slots.outidx.end());
         launches.push_back(L);
@@ -1809,7 +1866,12 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
     pa.residus = method == COREG_METHOD_RESIDUS ? 1 : 0;
     const int n_tiles = pa.tiles_x * pa.tiles_y;
     const Affine2 fwd = car_pix_to_native(*hdr_target);
-    pa.car_fwd = {fwd.m00, fwd.m01, fwd.m10, fwd.m11, fwd.b0, fwd.b1};
+    pa.car_fwd.m00 = fwd.m00;
+    pa.car_fwd.m01 = fwd.m01;
+    pa.car_fwd.m10 = fwd.m10;
+    pa.car_fwd.m11 = fwd.m11;
+    pa.car_fwd.b0 = fwd.b0;
+    pa.car_fwd.b1 = fwd.b1;
     const double inf = std::numeric_limits<double>::infinity();
     pa.f0lo = pa.f1lo = -inf;  // no culling by position: only non-finite reference values drop out
     pa.f0hi = pa.f1hi = inf;
@@ -2035,9 +2097,12 @@ int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device,
     RETCHK(bind_device(h));
     const long long n_out = h->pending_n_out;
     const size_t bytes = (size_t)h->sums_slots * kNumSums * sizeof(double);
-    if ((const void*)sums != h->sums.p)
+    if ((const void*)sums != h->sums.p) {
         HIPCHK(hipMemcpyAsync(h->sums.p, sums, bytes, sums_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                               h->stream));
+        // a host buffer belongs to the caller again on return (with a device destination nothing below waits)
+        if (!sums_on_device) HIPCHK(hipStreamSynchronize(h->stream));
+    }
     double* out_dev = corr_out;
     if (!out_on_device) {
         HIPCHK(h->out_dev.reserve((size_t)std::max<long long>(n_out, 1) * sizeof(double)));
@@ -2071,6 +2136,24 @@ int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device,
     return COREG_OK;
 }
 
+int coreg_get_pivots(coreg_handle* h, double* pivots2) {
+    if (!h || !pivots2) return COREG_EINVAL;
+    RETCHK(bind_device(h));
+    HIPCHK(hipMemcpyAsync(pivots2, h->pivots.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return COREG_OK;
+}
+
+int coreg_set_pivots(coreg_handle* h, const double* pivots2) {
+    if (!h || !pivots2) return COREG_EINVAL;
+    if (!(pivots2[0] == pivots2[0]) || !(pivots2[1] == pivots2[1]) || std::isinf(pivots2[0]) || std::isinf(pivots2[1]))
+        return fail(h, COREG_EINVAL, "set_pivots: pivots must be finite");
+    RETCHK(bind_device(h));
+    HIPCHK(hipMemcpyAsync(h->pivots.p, pivots2, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // the caller's two doubles are free again on return
+    return COREG_OK;
+}
+
 int coreg_last_stats(coreg_handle* h, coreg_stats* out) {
     if (!h || !out) return COREG_EINVAL;
     RETCHK(bind_device(h));
@@ -2093,6 +2176,16 @@ int coreg_car_map(const coreg_wcs2d* from, const coreg_wcs2d* to, int64_t n, con
     CarMapHost m;
     if (m.init(*from, *to)) return 1;
     for (int64_t i = 0; i < n; ++i) m.apply(px[i], py[i], &ox[i], &oy[i]);
+    return COREG_OK;
+}
+
+int coreg_car_tile_margin(const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_shifted, int32_t tile_w,
+                          double tile_abs_lat_rad, double* margin_px) {
+    if (!hdr_target || !hdr_shifted || !margin_px || tile_w < 1 || tile_w > kTilePts) return COREG_EINVAL;
+    if (hdr_target->proj != COREG_PROJ_CAR || hdr_shifted->proj != COREG_PROJ_CAR) return COREG_EINVAL;
+    CarMapHost m;
+    if (m.init(*hdr_target, *hdr_shifted)) return 1;
+    *margin_px = car_tile_margin(car_box_c(*hdr_target, *hdr_shifted, tile_w), tile_abs_lat_rad + car_pole_sep(m.r));
     return COREG_OK;
 }
 

@@ -562,6 +562,18 @@ struct CarMapHost {
     }
 };
 
+// Inputs of kernels.hpp car_tile_margin for one launch of the plate-carree sweep (tile = tile_w x kTilePts / tile_w
+// target pixels): (tile half-diagonal in radians)^2 / 2 x pixels per radian of the shifted map; and the angle between
+// the native poles of the two maps from the rotation R = R_shifted^T R_target (its [2][2] element).
+inline double car_box_c(const coreg_wcs2d& target, const coreg_wcs2d& shifted, int tile_w, int tile_pts = 1024) {
+    const double step = std::max(std::fabs(target.cdelt1), std::fabs(target.cdelt2)) * target.unit_to_deg * kDeg2Rad;
+    const double s_half = 0.5 * step * std::hypot((double)tile_w, (double)(tile_pts / tile_w));
+    const double px_per_rad =
+        1.0 / (std::min(std::fabs(shifted.cdelt1), std::fabs(shifted.cdelt2)) * shifted.unit_to_deg * kDeg2Rad);
+    return 0.5 * s_half * s_half * px_per_rad;
+}
+inline double car_pole_sep(const double r[9]) { return std::acos(std::fmax(-1.0, std::fmin(1.0, r[8]))); }
+
 // ---- Carrington ---------------------------------------------------------------------------------------
 // Lag-independent-per-(roll, cdelt) part of utils/rectify.py:387-415 + :340-363.
 struct CarrCommon {

@@ -52,8 +52,23 @@ struct LaunchU {
     double m00, m01, m10, m11, b0, b1;  // MODE_CAR: native (phi, theta) [rad] -> 0-based pixel
     int order_rt;                       // ORDER == ORDER_RT kernels: the spline order (0..5)
     int pad_;
-    double box_margin;                  // MODE_CAR: pixels by which a tile's image may leave the box of its mapped corners
+    double box_c;     // MODE_CAR: (tile half-diagonal [rad])^2 / 2 x pixels per radian of the shifted map (car_tile_margin)
+    double pole_sep;  // MODE_CAR: largest angle [rad] between the native poles of the target and of a shifted map
 };
+
+// MODE_CAR: pixels by which the image of a tile may leave the bounding box of its four mapped corners.  The map
+// (phi, theta) -> unit vector -> rotation -> (atan2, asin) -> pixel is not projective; over a tile of half-diagonal s
+// [rad] a component f of it leaves the box of the corner values by at most sup|D^2 f| s^2 / 2, and on the sphere the
+// second derivatives of the longitude grow like 1 / cos^2(latitude) towards the pole of the frame they are taken in
+// (a great circle passing at distance d from a pole turns its longitude by pi within ~d).  th_abs = the largest
+// |native latitude| the tile can reach in EITHER frame (its own extent plus the angle between the two native poles).
+// Beyond 1.5 rad (86 deg) no box is trusted: an infinite margin sends the visit through the per-point global path.
+// Checked against the host map on tiles up to the poles: tests/test_host_abi.py::test_car_tile_margin_bounds_the_map.
+__host__ __device__ inline double car_tile_margin(double box_c, double th_abs) {
+    if (!(th_abs < 1.5)) return __builtin_inf();
+    const double c = cos(th_abs);
+    return 1.0 + box_c * 2.0 / (c * c);
+}
 
 struct CarrDev {
     const double* sin_lon;  // [n_lon] sin(lon')
@@ -1009,6 +1024,59 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
     }
 }
 
+// One compacted point through the scalar data path.  The address is wave-uniform (tile, chunk and point-group are), but
+// the compiler cannot prove the buffer read-only (k_precompute wrote it, another kernel) and would emit per-lane vector
+// loads of one address: two VMEM instructions per point that occupy the texture addresser for 64 lanes' worth of
+// cycles.  Read through the constant address space the same bytes come as s_load_dwordx4/x2 into SGPRs (the scalar
+// cache is invalidated at kernel start, so it sees k_precompute's stores) and the VALU takes them as scalar operands.
+#ifndef COREG_PT_SCALAR
+#define COREG_PT_SCALAR 2
+#endif
+#ifndef COREG_PT_ANCHOR
+#define COREG_PT_ANCHOR 1
+#endif
+// COREG_PT_SCALAR == 2: explicit s_load_dwordx8 of a whole Pt, issued a point ahead (tile_points)
+typedef unsigned SPt __attribute__((ext_vector_type(8)));
+// `anchor`: a per-lane value the point's FIRST vector instruction reads; naming it as an in/out operand keeps the load
+// above that instruction (the scheduler would otherwise sink it below the coordinate arithmetic and shorten the time
+// the load has before the gather's wait)
+__device__ __forceinline__ SPt spt_load(const Pt* __restrict__ p, double& anchor) {
+    SPt r;
+#if defined(__HIP_DEVICE_COMPILE__)
+#if COREG_PT_ANCHOR
+    asm volatile("s_load_dwordx8 %0, %2, 0x0" : "=s"(r), "+v"(anchor) : "s"(p));
+#else
+    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(r) : "s"(p));
+#endif
+#else
+    r = (SPt)(0u);
+    (void)p;
+    (void)anchor;
+#endif
+    return r;
+}
+__device__ __forceinline__ void spt_wait(SPt& r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r));
+#endif
+}
+__device__ __forceinline__ double spt_f64(const SPt& r, int i) {
+    const unsigned long long u = ((unsigned long long)r[2 * i + 1] << 32) | (unsigned long long)r[2 * i];
+    return __builtin_bit_cast(double, u);
+}
+__device__ __forceinline__ void load_pt_uniform(const Pt* __restrict__ p, Pt& out) {
+#if defined(__HIP_DEVICE_COMPILE__) && COREG_PT_SCALAR
+    typedef const __attribute__((address_space(4))) double* ConstF64;
+    ConstF64 q = (ConstF64)(const double*)p;
+    out.b0 = q[0];
+    out.b1 = q[1];
+    out.a = q[2];
+    out.pad = q[3];
+#else
+    out = *p;
+#endif
+}
+
 // Walk this point-group's share of the compacted points of one tile: chunks of kChunk points, chunk c belongs to
 // point-group (c % kPointGroups).  Point data are wave-uniform: the loads below use uniform addresses (scalar loads).
 template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false, int PITCH = 0>
@@ -1020,21 +1088,52 @@ __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __
     // tile's point count
     const double wmax = (double)(W - 1), hmax = (double)(H - 1);
     const int n_full = p_end / kChunk;
+#if defined(__HIP_DEVICE_COMPILE__) && COREG_PT_SCALAR == 2
+    {
+        // rolling scalar prefetch: the s_load of point m + 1 is issued before point m's address arithmetic and is
+        // drained by the s_waitcnt lgkmcnt(0) that ends point m's LDS gather (SMEM and LDS share that counter; a
+        // scalar load further ahead would be drained by the same wait, so one point is the useful distance)
+        int c = p_begin / kChunk + pg;
+        if (c < n_full) {
+            // (lane value read first by the point's arithmetic: the window-relative origin / the projective row)
+            H9 hml = hm;
+            double& anchor = MODE == MODE_TRANSLATE ? (INTERIOR && LDS ? pxw : px0) : hml.h[MODE == MODE_CAR ? 0 : 7];
+            SPt cur = spt_load(pts + c * kChunk, anchor);
+            spt_wait(cur);
+            for (; c < n_full; c += kPointGroups) {
+                const Pt* __restrict__ q = pts + c * kChunk;
+#pragma unroll
+                for (int k = 0; k < kChunk; ++k) {
+                    // (past the group's last chunk this reads up to kPointGroups chunks ahead: inside the allocation
+                    // -- DevBuf::reserve pads by 25 % + 256 B -- and never used)
+                    SPt nxt = spt_load(k + 1 < kChunk ? q + k + 1 : q + kPointGroups * kChunk, anchor);
+                    point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR, PITCH>(
+                        acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0, py0, pxw, pyw, hml, cu, spt_f64(cur, 0),
+                        spt_f64(cur, 1), spt_f64(cur, 2), spt_f64(cur, 3), pivot_b);
+                    spt_wait(nxt);  // (already drained by the gather's wait unless no lane sampled)
+                    cur = nxt;
+                }
+            }
+        }
+    }
+#else
     for (int c = p_begin / kChunk + pg; c < n_full; c += kPointGroups) {
         const Pt* __restrict__ q = pts + c * kChunk;
         Pt pt[kChunk];
 #pragma unroll
-        for (int k = 0; k < kChunk; ++k) pt[k] = q[k];
+        for (int k = 0; k < kChunk; ++k) load_pt_uniform(q + k, pt[k]);
 #pragma unroll
         for (int k = 0; k < kChunk; ++k)
             point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR, PITCH>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax,
                                                                            px0, py0, pxw, pyw, hm, cu, pt[k].b0, pt[k].b1,
                                                                            pt[k].a, pt[k].pad, pivot_b);
     }
+#endif
     // ragged tail (< kChunk points): owned by the point-group next in the rotation
     if (pg == n_full % kPointGroups) {
         for (int p = n_full * kChunk; p < p_end; ++p) {
-            const Pt pt = pts[p];
+            Pt pt;
+            load_pt_uniform(pts + p, pt);
             point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR, PITCH>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax,
                                                                            px0, py0, pxw, pyw, hm, cu, pt.b0, pt.b1, pt.a,
                                                                            pt.pad, pivot_b);
@@ -1123,13 +1222,15 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
             }
             if (MODE == MODE_CAR) {
                 // a rotation of the sphere followed by (atan2, asin) is not projective: the images of the corners do
-                // not bound the tile's image; the host supplies a curvature margin (sweep_car).  A tile that
+                // not bound the tile's image; car_tile_margin widens the box by the curvature over THIS tile (by0, by1 =
+                // its native latitude range; polar tiles get an infinite box = the per-point global path).  A tile that
                 // straddles the +-pi cut of atan2 maps its corners to both ends of the map: such a box is never
                 // "interior" and does not fit the LDS, so the visit takes the per-point global path.
-                mnx -= a.car_inv.box_margin;
-                mxx += a.car_inv.box_margin;
-                mny -= a.car_inv.box_margin;
-                mxy += a.car_inv.box_margin;
+                const double margin = car_tile_margin(a.car_inv.box_c, fmax(fabs(by0), fabs(by1)) + a.car_inv.pole_sep);
+                mnx -= margin;
+                mxx += margin;
+                mny -= margin;
+                mxy += margin;
             }
         }
         for (int o = 32; o > 0; o >>= 1) {

@@ -68,6 +68,7 @@ class Alignment:
         self.cdelt_semantics = cdelt_semantics
         self.device = device
         self.last_stats = None
+        self.last_sharding = None       # how the last sweep was spread over the GPUs (parallel.lag_sharding)
         # set by the jitter-correction session (jitter_correction/jitter_correction.py):
         self.shard_lags = True          # False: every rank runs whole sweeps (images, not lags, are spread over GPUs)
         self._preloaded_small = None    # (data, header) already decoded by the session's prefetch thread
@@ -289,11 +290,25 @@ class Alignment:
                 import torch
                 device = torch.cuda.current_device()
         h = _lib.shared_handle(device, self._handle_slot)  # long-lived: buffers are re-used by the next Alignment
+        # with several ranks over RCCL each image crosses PCIe once in all -- 1/N per rank -- and is assembled on every
+        # GPU by an all-gather over xGMI (parallel.replicate_image); one rank / gloo: the whole image from this host
+        spread = world > 1
+
+        def upload_small(data):
+            t = parallel.replicate_image(data) if spread and np.asarray(data).dtype in (np.float32, np.float64) else None
+            if t is None:
+                h.set_small(data)
+            else:
+                import torch
+                torch.cuda.current_stream().synchronize()  # the all-gather ran on torch's stream, not the handle's
+                h.set_small_from_device(t.data_ptr(), t.shape, np.float32 if t.element_size() == 4 else np.float64)
+                h.synchronize()  # `t` may go once the copy has run
+
         # alignment.py:844-861: thresholds, then the box to remove, then the sub-FOV re-grid
         on_device = (remove_fov_limits is None) and (fov_limits is None)
         if on_device:
             # thresholds applied to the resident copy (self.data_small is left as loaded)
-            h.set_small(self.data_small)
+            upload_small(self.data_small)
             n_finite = h.threshold_small(self.small_fov_value_min, self.small_fov_value_max)
         else:
             self.data_small = np.array(self.data_small, dtype=np.float64)
@@ -303,7 +318,7 @@ class Alignment:
             if fov_limits is not None:
                 self._select_fov_in_small_data(fov_limits, h)
             n_finite = int(np.isfinite(self.data_small).sum())
-            h.set_small(self.data_small)
+            upload_small(self.data_small)
         self._set_initial_header_values(ang2pipi)
         if n_finite == 0:
             raise ValueError("minimum or maximum value have set all small FOV to nan")  # alignment.py:655-656
@@ -313,21 +328,45 @@ class Alignment:
         lags = _lib.LagSet(self.lag_crval1, self.lag_crval2, self.lag_cdelt1, self.lag_cdelt2, self.lag_crota)
         sem = _lib.CDELT_INTENDED if self.cdelt_semantics == "intended" else _lib.CDELT_REFERENCE
         solar_rs = np.atleast_1d(np.asarray(self.lag_solar_r, dtype=np.float64))
-        lo, hi, chunk = parallel.shard_bounds(lags.size, world, rank)
-        # few lag-points per GPU: shard the grid instead of the lags (one all-reduce of the six sums per lag)
-        by_points = parallel.use_point_sharding(lags.size, world)
-        if by_points:
-            lo, hi = 0, lags.size
+        # Spreading the lag set over the GPUs (parallel.lag_sharding): blocks of the (CRVAL1, CRVAL2) plane + one
+        # all-gather -- the partition bench.py measures; contiguous slices of the raveled index (the reference's literal
+        # np.array_split, alignment.py:677-687) when the plane is smaller than the number of GPUs; shares of the GRID +
+        # one all-reduce of the six sums per lag when there are few lag-points per GPU.
+        mode = parallel.lag_sharding(lags.shape, world)
+        self.last_sharding = mode
+        my_lags, lo, hi = lags, 0, lags.size
+        if mode == "blocks":
+            lo1, hi1, lo2, hi2 = parallel.block_bounds(lags.shape[0], lags.shape[1], world, rank)
+            a = lags.arrays
+            my_lags = _lib.LagSet(a[0][lo1:hi1], a[1][lo2:hi2], a[2], a[3], a[4])
+            hi = my_lags.size
+        elif mode == "slices":
+            lo, hi, _ = parallel.shard_bounds(lags.size, world, rank)
+
+        def prepare(kind, *args):
+            """Reference preparation with the source image replicated over xGMI when there are several RCCL ranks."""
+            large = self._large_pixels()
+            t = parallel.replicate_image(large) if spread and large.dtype in (np.float32, np.float64) else None
+            if t is None:
+                getattr(h, "prepare_reference_" + kind)(large, *args)
+                return
+            import torch
+            torch.cuda.current_stream().synchronize()
+            getattr(h, "prepare_reference_" + kind + "_from_device")(
+                t.data_ptr(), t.shape, np.float32 if t.element_size() == 4 else np.float64, *args)
+            h.synchronize()  # the resample has read `t`
+
         out = np.full(lags.shape + (len(solar_rs),), np.nan)
         for kk, solar_r in enumerate(solar_rs):
             if self.coordinate_frame == "final_carrington":
                 grid = _lib.Grid(self.lonlims, self.latlims, self.shape, numpy_lat_trig=True)
                 tag = self._reference_tag("carrington", self.lonlims, self.latlims, self.shape, solar_r)
                 if tag is None or tag != h.reference_tag:
-                    h.prepare_reference_carrington(self._large_pixels(), self.hdr_large, grid, solar_r, self.order)
+                    prepare("carrington", self.hdr_large, grid, solar_r, self.order)
                     h.reference_tag = tag
+
                 def run(g=grid, sr=solar_r):
-                    return h.sweep_carrington(self.hdr_small, g, sr, lags, order=self.order, method=method,
+                    return h.sweep_carrington(self.hdr_small, g, sr, my_lags, order=self.order, method=method,
                                               cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
             elif self.coordinate_frame == "initial_carrington":
                 # the reference map on its own grid, float32 (alignment.py:372); neither the parallel nor the serial
@@ -335,25 +374,27 @@ class Alignment:
                 h.set_reference_on_grid(np.asarray(self._large_pixels(), dtype=np.float32))
 
                 def run():
-                    return h.sweep_helioprojective(self.hdr_large, self.hdr_small, lags, order=self.order,
+                    return h.sweep_helioprojective(self.hdr_large, self.hdr_small, my_lags, order=self.order,
                                                    method=method, cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
             else:
                 if self.parallelism:
-                    h.prepare_reference_helioprojective(self._large_pixels(), self.hdr_large, self.hdr_small,
-                                                        self.order)
+                    prepare("helioprojective", self.hdr_large, self.hdr_small, self.order)
                     target = self.hdr_small
                 else:
                     h.set_reference_on_grid(np.asarray(self._large_pixels(), dtype=np.float64))  # quirk Q1: float64
                     target = self.hdr_large
+
                 def run(t=target):
-                    return h.sweep_helioprojective(t, self.hdr_small, lags, order=self.order, method=method,
+                    return h.sweep_helioprojective(t, self.hdr_small, my_lags, order=self.order, method=method,
                                                    cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
-            if by_points:
+            if mode == "points":
                 part = parallel.point_sharded_sweep(h, run, lags.size)
+            elif mode == "blocks":
+                part = parallel.allgather_lag_blocks(run(), lags.shape)
+            elif mode == "slices":
+                part = parallel.allgather_lag_slices(run(), lags.size).cpu().numpy()
             else:
                 part = run()
-                if world > 1:
-                    part = parallel.allgather_lag_slices(part, lags.size).cpu().numpy()
             out[..., kk] = np.asarray(part).reshape(lags.shape)
         self.last_stats = h.last_stats()
         return out

@@ -81,6 +81,80 @@ def block_gather_index(shape5, world: int):
     return perm.reshape(-1), chunk
 
 
+def lag_sharding(shape5, world: int) -> str:
+    """How a sweep over the lag set `shape5` = (n_crval1, n_crval2, n_cdelt1, n_cdelt2, n_crota) is spread over `world`
+    GPUs.  'none' (one GPU); 'points': every rank sweeps all lag-points over its share of the grid (few lag-points per
+    GPU, one all-reduce); 'blocks': the (CRVAL1, CRVAL2) plane cut in `world` near-square blocks (compact lag patches =
+    small LDS windows, no padded lanes; one all-gather) -- whenever a factorisation of `world` gives every rank a
+    non-empty block; 'slices': contiguous slices of the raveled C-order index, the literal np.array_split fan-out of the
+    reference (alignment.py:677-687), for lag sets whose plane is smaller than `world` (e.g. a pure CROTA sweep)."""
+    n = int(np.prod(shape5))
+    if world <= 1:
+        return "none"
+    if use_point_sharding(n, world):
+        return "points"
+    n1, n2 = int(shape5[0]), int(shape5[1])
+    full = all(b[1] > b[0] and b[3] > b[2] for b in (block_bounds(n1, n2, world, r) for r in range(world)))
+    return "blocks" if full else "slices"
+
+
+def allgather_lag_blocks(local, shape5, group=None):
+    """Every rank holds the coefficients of its block of the lag plane (C order [hi1-lo1, hi2-lo2, n3, n4, n5], numpy):
+    ONE all-gather of ceil-sized chunks + one index permutation give the full raveled C-order map (numpy) on every rank."""
+    import torch
+    import torch.distributed as dist
+    rank, world = world_info(group)
+    perm, chunk = block_gather_index(tuple(int(v) for v in shape5), world)
+    backend = dist.get_backend(group) if world > 1 else None
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    buf = torch.full((chunk,), float("nan"), dtype=torch.float64, device=dev)
+    local = np.ascontiguousarray(local, dtype=np.float64).ravel()
+    if local.size > chunk:
+        raise ValueError(f"a block holds at most chunk={chunk} lag-points, got {local.size}")
+    if local.size:
+        buf[:local.size] = torch.from_numpy(local).to(dev)
+    if world == 1:
+        return buf.cpu().numpy()[perm]
+    out = torch.empty((chunk * world,), dtype=torch.float64, device=dev)
+    try:
+        dist.all_gather_into_tensor(out, buf, group=group)
+    except (RuntimeError, NotImplementedError):
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)
+        out = torch.cat(parts)
+    return out.cpu().numpy()[perm]
+
+
+def replicate_image(img, group=None):
+    """The multi-GPU hand-over of one host image: rank r sends rows [r * ceil(H / N), ...) over ITS OWN PCIe link and one
+    RCCL all-gather over xGMI assembles the full replica on every GPU -- 1/N of the bytes per link instead of N uploads
+    of everything through one host's memory (the reference hands its workers the images through shared memory,
+    alignment.py:692-720).  `img`: the same 2-D float32 / float64 numpy array on every rank.  Returns a device tensor
+    [H, W] (keep it alive while the library reads it), or None when the process group is not RCCL (gloo rehearsals,
+    one rank): the caller then uploads the whole image itself."""
+    import torch
+    import torch.distributed as dist
+    rank, world = world_info(group)
+    if world <= 1 or dist.get_backend(group) != "nccl":
+        return None
+    img = np.ascontiguousarray(img)
+    if img.ndim != 2 or img.dtype not in (np.float32, np.float64):
+        raise ValueError("replicate_image: 2-D float32 / float64 array expected")
+    H, W = img.shape
+    rows = -(-H // world)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    tdt = torch.float32 if img.dtype == np.float32 else torch.float64
+    full = torch.empty((rows * world, W), dtype=tdt, device=dev)
+    lo, hi = min(rank * rows, H), min((rank + 1) * rows, H)
+    mine = full[rank * rows:(rank + 1) * rows]  # all_gather_into_tensor accepts the in-place form
+    if hi > lo:
+        mine[:hi - lo].copy_(torch.from_numpy(img[lo:hi]), non_blocking=False)
+    if hi - lo < rows:
+        mine[hi - lo:].zero_()
+    dist.all_gather_into_tensor(full, mine.clone(), group=group)
+    return full[:H]
+
+
 def allgather_lag_slices(local, n_lags: int, group=None):
     """Concatenate every rank's slice (rank r holds lags [r*chunk, min((r+1)*chunk, n))) into the full raveled map.
 
@@ -132,12 +206,21 @@ def point_sharded_sweep(handle, run_sweep, n_out, group=None, out_dev_ptr=None):
     import torch
     import torch.distributed as dist
     rank, world = world_info(group)
+    if world == 1:
+        return run_sweep()  # nothing to shard: the ordinary sweep, its own result
+    backend = dist.get_backend(group)
+    # the ranks' sums only add up when all of them subtracted the same two pivots: rank 0's are used everywhere
+    piv = torch.tensor(handle.get_pivots(), dtype=torch.float64)
+    mine = piv.clone()
+    if backend == "nccl":
+        piv = piv.to(torch.device("cuda", torch.cuda.current_device()))
+    dist.broadcast(piv, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    piv = piv.cpu()
+    if not torch.equal(piv, mine):
+        handle.set_pivots(float(piv[0]), float(piv[1]))
     handle.set_point_shard(rank, world)
     try:
         run_sweep()
-        if world == 1:
-            return handle.finalize_sums(handle.copy_sums(), n_out, out_dev_ptr)
-        backend = dist.get_backend(group)
         n = handle.sums_size()
         if backend == "nccl":
             buf = torch.empty(n, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))

@@ -151,6 +151,20 @@ int coreg_prepare_reference_carrington_f32(coreg_handle* h, const float* large, 
 int coreg_prepare_reference_helioprojective_f32(coreg_handle* h, const float* large, int32_t ny, int32_t nx,
                                                 const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order);
 
+/* The same three uploads with the pixels ALREADY IN DEVICE MEMORY of the handle's GPU (dtype COREG_F32 or COREG_F64):
+ * the multi-GPU form of the hand-over, where every rank sends 1/N of each image over its own PCIe link and one RCCL
+ * all-gather over xGMI assembles the replicas (euispice_coreg_amd/parallel.py: replicate_image; the reference hands its
+ * workers the images through shared memory, alignment.py:692-720).  The buffer is read by work enqueued on the handle's
+ * stream: whatever produced it must be ordered before that stream (same stream, or synchronised), and it must stay valid
+ * until that work has run (coreg_synchronize).  The image to align is copied; the reference source is only read. */
+int coreg_set_small_from_device(coreg_handle* h, const void* dev_img, int dtype, int32_t ny, int32_t nx);
+int coreg_prepare_reference_carrington_from_device(coreg_handle* h, const void* dev_large, int dtype, int32_t ny,
+                                                   int32_t nx, const coreg_wcs2d* hdr_large,
+                                                   const coreg_carr_grid* grid, double solar_r, int order);
+int coreg_prepare_reference_helioprojective_from_device(coreg_handle* h, const void* dev_large, int dtype, int32_t ny,
+                                                        int32_t nx, const coreg_wcs2d* hdr_large,
+                                                        const coreg_wcs2d* hdr_small, int order);
+
 /* Copy the resident reference-on-grid back (tests / figures). out: [gy][gx] of `dtype` (must match). */
 int coreg_get_reference_on_grid(coreg_handle* h, void* out, int dtype);
 
@@ -199,6 +213,14 @@ int coreg_sums_size(coreg_handle* h, int64_t* n_doubles);
 int coreg_copy_sums(coreg_handle* h, double* dst, int dst_on_device);
 int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device, double* corr_out, int out_on_device);
 
+/* The two pivots the Pearson moments are taken about: [0] mean of the finite reference values on the grid, [1] mean
+ * of the finite pixels of the image to align (set by the upload / preparation calls).  Any pivot gives the same
+ * coefficient up to rounding, but the six sums of DIFFERENT ranks only add up if every rank used the same two values:
+ * a point-sharded multi-GPU sweep reads rank 0's pivots and sets them on every rank before sweeping (the pivots are
+ * device_mean results, identical on identical GPUs, but nothing else enforces it). */
+int coreg_get_pivots(coreg_handle* h, double* pivots2);
+int coreg_set_pivots(coreg_handle* h, const double* pivots2);
+
 /* Waits for an in-flight device-output sweep (those return without synchronising the stream). */
 int coreg_last_stats(coreg_handle* h, coreg_stats* out);
 
@@ -242,6 +264,13 @@ int coreg_carrington_origin(const coreg_wcs2d* hdr, double* x0, double* y0);
  * InvalidTransformError). */
 int coreg_car_map(const coreg_wcs2d* from, const coreg_wcs2d* to, int64_t n, const double* px, const double* py,
                   double* ox, double* oy);
+/* The allowance, in pixels of the shifted map, by which the sweep kernel widens the bounding box of a tile's four mapped
+ * corners on the CAR -> CAR path (the map is not projective): tile = tile_w x (1024 / tile_w) target pixels whose
+ * native latitudes reach tile_abs_lat_rad in absolute value.  +inf = no box is trusted for that tile (polar tiles: the
+ * kernel samples them point by point from global memory).  Exported so that the bound can be checked against
+ * coreg_car_map on the host.  Returns 1 when a header has no valid native pole. */
+int coreg_car_tile_margin(const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_shifted, int32_t tile_w,
+                          double tile_abs_lat_rad, double* margin_px);
 
 
 #ifdef __cplusplus

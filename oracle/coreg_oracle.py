@@ -255,6 +255,7 @@ class TanWCS:
 # atan2(y,x)*R2D is (atan2(y,x)*180)/PI) and glibc's sincos().  PINNED bit for bit, for every border pixel of five
 # headers, by tests/golden/border_golden.npz (astropy 4.3.1 / wcslib 7.6).  libm-dependent, as the reference is.
 import ctypes  # noqa: E402
+import os  # noqa: E402
 
 _libm = ctypes.CDLL("libm.so.6")
 _libm.sincos.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
@@ -482,27 +483,69 @@ class WcslibTan:
                     [float(hdr.get("PC2_1", 0.0)), float(hdr.get("PC2_2", 1.0))]], float(hdr.get("LONPOLE", 180.0)))
 
 
-MAX_INTEGER_REFINE = 300000  # pure-Python loop: pixels re-evaluated for odd spline orders (see below)
+# The same chain in plain C (oracle/csrc/wcslib_tan.c, built by oracle/Makefile): identical arithmetic on the same libm,
+# checked bit for bit against the Python class above and against the astropy / wcslib golden vectors
+# (tests/test_oracle_golden.py).  It exists so that EVERY pixel of a 2048 x 2048 grid can be re-evaluated (odd spline
+# orders at noise-decided lag-points); without the built library the scalar Python loop runs instead, however long.
+_WCSTAN_LIB = None
+
+
+def _wcstan_lib():
+    global _WCSTAN_LIB
+    if _WCSTAN_LIB is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "liboracle_wcstan.so")
+        if os.path.exists(path):
+            lib = ctypes.CDLL(path)
+            lib.oracle_wcstan_pixel_to_pixel.restype = ctypes.c_int
+            lib.oracle_wcstan_pixel_to_pixel.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int64] + [ctypes.c_void_p] * 6
+            _WCSTAN_LIB = lib
+        else:
+            _WCSTAN_LIB = False
+    return _WCSTAN_LIB or None
+
+
+def _wcstan_params(hdr):
+    u1 = unit_to_deg(hdr.get("CUNIT1", "deg"))
+    u2 = unit_to_deg(hdr.get("CUNIT2", "deg"))
+    return np.array([float(hdr["CRPIX1"]), float(hdr["CRPIX2"]), float(hdr["CDELT1"]) * u1, float(hdr["CDELT2"]) * u2,
+                     float(hdr["CRVAL1"]) * u1, float(hdr["CRVAL2"]) * u2, float(hdr.get("PC1_1", 1.0)),
+                     float(hdr.get("PC1_2", 0.0)), float(hdr.get("PC2_1", 0.0)), float(hdr.get("PC2_2", 1.0)),
+                     float(hdr.get("LONPOLE", 180.0))], dtype=np.float64)
+
+
+def wcslib_pixel_to_pixel(hdr_from, hdr_to, px, py, force_python=False):
+    """pixel (0-based) of `hdr_from` -> sky -> ang2pipi -> pixel of `hdr_to` through wcslib's own arithmetic, for arrays
+    of pixels: the C twin when built, else the scalar Python class.  Returns (x, y, lng_deg, lat_deg)."""
+    px = np.ascontiguousarray(px, dtype=np.float64).ravel()
+    py = np.ascontiguousarray(py, dtype=np.float64).ravel()
+    ox, oy, lng, lat = (np.empty_like(px) for _ in range(4))
+    lib = None if force_python else _wcstan_lib()
+    if lib is not None:
+        pf, pt = _wcstan_params(hdr_from), _wcstan_params(hdr_to)
+        lib.oracle_wcstan_pixel_to_pixel(pf.ctypes.data, pt.ctypes.data, px.size, px.ctypes.data, py.ctypes.data,
+                                         ox.ctypes.data, oy.ctypes.data, lng.ctypes.data, lat.ctypes.data)
+        return ox, oy, lng, lat
+    wf, wt = WcslibTan.from_header(hdr_from), WcslibTan.from_header(hdr_to)
+    for k in range(px.size):
+        lng[k], lat[k] = wf.p2s(float(px[k]), float(py[k]))
+        ox[k], oy[k] = wt.s2p(float(ang2pipi(np.float64(lng[k]))), float(ang2pipi(np.float64(lat[k]))))
+    return ox, oy, lng, lat
 
 
 def wcslib_refine_near_integers(hdr_from, hdr_to, x, y, tol=1e-6):
     """Odd spline orders take floor(c) as their first tap (scipy ni_interpolation.c), so where the map returns a
     coordinate within `tol` of an INTEGER -- every pixel of a noise-decided lag-point, see `wcslib_refine_near_bounds` --
     the sign of wcslib's rounding noise decides WHICH taps are used, i.e. which neighbour's NaN poisons the sample.
-    Same remedy: wcslib's own arithmetic for those coordinates.  Limited to MAX_INTEGER_REFINE pixels (the loop is pure
-    Python); larger noise-decided grids keep the numpy coordinates for odd orders and are not pinned (none of the
-    tests or BASELINE configs has one: the default order is 2)."""
+    Same remedy: wcslib's own arithmetic for those coordinates, whatever their number (the C twin of `WcslibTan` takes
+    about a second for a 2048 x 2048 grid)."""
     with np.errstate(invalid="ignore"):
         near = (np.abs(x - np.rint(x)) < tol) | (np.abs(y - np.rint(y)) < tol)
     jj, ii = np.nonzero(near)
-    if jj.size == 0 or jj.size > MAX_INTEGER_REFINE:
+    if jj.size == 0:
         return 0
-    wf, wt = WcslibTan.from_header(hdr_from), WcslibTan.from_header(hdr_to)
-    for j, i in zip(jj.tolist(), ii.tolist()):
-        lng, lat = wf.p2s(float(i), float(j))
-        lng = float(ang2pipi(np.float64(lng)))
-        lat = float(ang2pipi(np.float64(lat)))
-        x[j, i], y[j, i] = wt.s2p(lng, lat)
+    nx, ny, _, _ = wcslib_pixel_to_pixel(hdr_from, hdr_to, ii.astype(np.float64), jj.astype(np.float64))
+    x[jj, ii] = nx
+    y[jj, ii] = ny
     return int(jj.size)
 
 
@@ -518,12 +561,9 @@ def wcslib_refine_near_bounds(hdr_from, hdr_to, x, y, tol=1e-6):
     jj, ii = np.nonzero(near)
     if jj.size == 0:
         return 0
-    wf, wt = WcslibTan.from_header(hdr_from), WcslibTan.from_header(hdr_to)
-    for j, i in zip(jj.tolist(), ii.tolist()):
-        lng, lat = wf.p2s(float(i), float(j))
-        lng = float(ang2pipi(np.float64(lng)))
-        lat = float(ang2pipi(np.float64(lat)))
-        x[j, i], y[j, i] = wt.s2p(lng, lat)
+    bx, by, _, _ = wcslib_pixel_to_pixel(hdr_from, hdr_to, ii.astype(np.float64), jj.astype(np.float64))
+    x[jj, ii] = bx
+    y[jj, ii] = by
     return int(jj.size)
 
 

@@ -117,6 +117,21 @@ def test_block_sharding_covers_plane():
             assert np.array_equal(gathered[perm], full.ravel()), (shape5, world)
 
 
+def test_lag_sharding_modes():
+    """Which partition a sweep gets (parallel.lag_sharding): the drop-in API and bench.py decide with this function."""
+    from euispice_coreg_amd import parallel
+    assert parallel.lag_sharding((60, 60, 1, 1, 1), 1) == "none"
+    for world in (2, 4, 8):
+        assert parallel.lag_sharding((60, 60, 1, 1, 1), world) == "blocks"       # headline
+        assert parallel.lag_sharding((121, 121, 1, 1, 1), world) == "blocks"     # cfg3
+        assert parallel.lag_sharding((61, 61, 1, 1, 21), world) == "blocks"      # cfg4
+        assert parallel.lag_sharding((1, 2000, 1, 1, 1), world) == "blocks"      # one axis: blocks along the other
+        assert parallel.lag_sharding((5, 5, 1, 1, 1), world) == "points"         # few lag-points per GPU
+        assert parallel.lag_sharding((1, 1, 1, 1, 2001), world) == "slices"      # no plane to cut: raveled slices
+    assert parallel.lag_sharding((3, 3, 5, 5, 11), 8) == "slices"                # 9 plane points, 8 GPUs: no full tiling
+    assert parallel.lag_sharding((3, 3, 5, 5, 11), 3) == "blocks"
+
+
 def test_allgather_lag_slices_gloo_world2(tmp_path):
     """N > 1 path on CPU: two ranks (gloo), each 'sweeps' its slice, one all-gather assembles the map."""
     script = tmp_path / "worker.py"
@@ -132,6 +147,13 @@ def test_allgather_lag_slices_gloo_world2(tmp_path):
         "    local = np.arange(lo, hi, dtype=np.float64) * 0.5 + 1.0\n"
         "    full = parallel.allgather_lag_slices(local, n).numpy()\n"
         "    assert np.array_equal(full, np.arange(n) * 0.5 + 1.0), (rank, n, full)\n"
+        "for shape5 in [(60, 60, 1, 1, 1), (7, 3, 2, 1, 3), (1, 9, 1, 1, 2)]:\n"
+        "    assert parallel.lag_sharding(tuple(v * (40 if i < 2 else 1) for i, v in enumerate(shape5)), world) == 'blocks'\n"
+        "    want = np.arange(int(np.prod(shape5)), dtype=np.float64).reshape(shape5) * 0.25 - 3.0\n"
+        "    lo1, hi1, lo2, hi2 = parallel.block_bounds(shape5[0], shape5[1], world, rank)\n"
+        "    full = parallel.allgather_lag_blocks(want[lo1:hi1, lo2:hi2], shape5)\n"
+        "    assert np.array_equal(full, want.ravel()), (rank, shape5)\n"
+        "assert parallel.replicate_image(np.zeros((4, 4), dtype=np.float32)) is None  # gloo: the caller uploads\n"
         "dist.barrier(); dist.destroy_process_group()\n"
         "print('rank', rank, 'ok')\n")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561")

@@ -129,12 +129,22 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     """bench.py --gpus 2 started as a plain command on the one-GPU box (ranks share the device, all-gather over gloo):
     real sweeps on both ranks, the assembled map has the injected shift as its argmax, per-rank kernel times present."""
     from tests.test_api_cpu import _run_bench
-    out = _run_bench({"COREG_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "4", "--warmup", "2",
-                     "--no-cpu-baseline", timeout=900)
+    out = _run_bench({"COREG_BENCH_BACKEND": "gloo", "COREG_CPU_CORES": "8"}, "--gpus", "2", "--steps", "4",
+                     "--warmup", "2", timeout=900)
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["value"] > 0
     assert out["argmax_lag_arcsec"] == out["injected_shift_arcsec"][:2] == [17.0, -9.0]
     assert len(out["per_rank"]) == 2 and all(r["kernel_ms"] > 0 and r["lags"] == 1800 for r in out["per_rank"])
     assert 0.0 < out["roofline"]["frac"] <= 1.0
+    assert out["config"]["lag_sharding"] == "blocks"  # the partition hdrshift.Alignment uses for this lag set
+    # the N > 1 line verifies itself: the assembled map against one GPU sweeping everything, against the oracle on a
+    # CPU sample, and the BASELINE.md section 2 call (host images in, host map out) with every rank taking part
+    m = out["map_vs_single_gpu"]
+    assert m["max_abs_diff"] <= 1e-12 and m["same_argmax"] and m["same_nan_pattern"]
+    p = out["parity_vs_cpu_sample"]
+    assert p["n"] == 128 and p["max_abs_dcorr"] <= 1e-10 and p["argmax_on_sample_equal"]
+    c = out["pcie_inclusive"]
+    assert c["n_gpus"] == 2 and c["value"] > 0 and c["ms_per_step"] > 0 and c["identical_to_resident_map"]
+    assert out["cpu_baseline"] is None  # the CPU leg is timed at N = 1 only
 
 
 def test_bench_two_ranks_point_sharded_gloo():
@@ -147,12 +157,15 @@ def test_bench_two_ranks_point_sharded_gloo():
     assert "all-reduce" in out["config"]["parallelism"]
     assert out["argmax_lag_arcsec"] == out["injected_shift_arcsec"][:2] == [17.0, -9.0]
     assert all(r["kernel_ms"] > 0 and r["lags"] == 3600 for r in out["per_rank"])
+    m = out["map_vs_single_gpu"]
+    assert m["max_abs_diff"] <= 1e-12 and m["same_argmax"] and m["same_nan_pattern"]
+    assert out["pcie_inclusive"]["n_gpus"] == 2 and out["pcie_inclusive"]["value"] > 0
 
 
 def test_alignment_two_ranks_gloo_both_sharding_modes(tmp_path):
     """`Alignment` under torch.distributed (two ranks sharing the one GPU, gloo): a 5 x 5 lag set is below the
-    point-sharding threshold (grid shares + one all-reduce of the six sums per lag), a 24 x 24 one above it (lag slices +
-    one all-gather); both must give the single-process map on every rank."""
+    point-sharding threshold (grid shares + one all-reduce of the six sums per lag), a 24 x 24 one above it (blocks of
+    the lag plane + one all-gather, the partition bench.py times); both must give the single-process map on every rank."""
     import os
     import subprocess
     import sys
@@ -175,7 +188,8 @@ def test_alignment_two_ranks_gloo_both_sharding_modes(tmp_path):
         "single = [run(*small_set), run(*big_set)]\n"
         "dist.init_process_group('gloo')\n"
         "rank, world = parallel.world_info()\n"
-        "assert parallel.use_point_sharding(50, world) and not parallel.use_point_sharding(24 * 24 * 2, world)\n"
+        "assert parallel.lag_sharding((5, 5, 1, 1, 2), world) == 'points'\n"
+        "assert parallel.lag_sharding((24, 24, 1, 1, 2), world) == 'blocks'\n"
         "multi = [run(*small_set), run(*big_set)]\n"
         "for a, b in zip(single, multi):\n"
         "    assert a.shape == b.shape and np.nanmax(np.abs(a - b)) <= 1e-12, np.nanmax(np.abs(a - b))\n"

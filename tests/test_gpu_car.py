@@ -159,3 +159,39 @@ def test_car_maps_with_different_reference_latitudes(gpu_handle, dlat, use_lds, 
                           unit_lag="deg")
     assert np.isfinite(want).any()
     H.assert_corr_close(got, want, 1e-7, f"CAR dlat={dlat} lds={use_lds} tile_w={tile_w}")
+
+
+@pytest.mark.parametrize("use_lds", [1, 0])
+def test_sweep_car_on_a_full_sun_map_up_to_the_pole(gpu_handle, use_lds):
+    """Full-Sun plate-carree reference (latitudes -89.75 .. 89.75) and a map to align whose rows run from latitude 30 to
+    89.6: towards the pole the longitude of the rotated frame turns quickly, the images of a tile's corners no longer
+    bound the tile's image, and the kernel must not trust a staged window there (car_tile_margin: polar tiles take the
+    per-point path).  LDS and global-memory gathers against the oracle, CRVAL2 lags make the shifted maps oblique."""
+    rng = np.random.default_rng(77)
+
+    def hdr(nx, ny, crval, cdelt, crpix=None, rot=0.0):
+        rho, lam = np.deg2rad(rot), cdelt[1] / cdelt[0]
+        crpix = crpix or ((nx + 1) / 2.0, (ny + 1) / 2.0)
+        return {"NAXIS": 2, "NAXIS1": nx, "NAXIS2": ny, "CTYPE1": "CRLN-CAR", "CTYPE2": "CRLT-CAR", "CUNIT1": "deg",
+                "CUNIT2": "deg", "CRPIX1": crpix[0], "CRPIX2": crpix[1], "CRVAL1": crval[0], "CRVAL2": crval[1],
+                "CDELT1": cdelt[0], "CDELT2": cdelt[1], "PC1_1": float(np.cos(rho)),
+                "PC1_2": float(-lam * np.sin(rho)), "PC2_1": float(np.sin(rho) / lam), "PC2_2": float(np.cos(rho)),
+                "CROTA": rot, "DATE-AVG": "2022-03-17T09:50:45.277"}
+
+    hl = hdr(720, 360, (180.0, 0.0), (0.5, 0.5))
+    hs = hdr(240, 150, (200.0, 0.3), (0.4, 0.4), crpix=(120.5, -74.0), rot=1.5)  # rows at latitude ~30 .. 89.6
+    yy, xx = np.mgrid[0:360, 0:720]
+    large = (300.0 + 200.0 * np.sin(xx / 17.0) * np.cos(yy / 11.0) + 20.0 * rng.standard_normal((360, 720))).astype(np.float32)
+    ys, xs = np.mgrid[0:150, 0:240]
+    small = (300.0 + 200.0 * np.sin(xs / 13.0 + 0.4) * np.cos(ys / 9.0) + 20.0 * rng.standard_normal((150, 240))).astype(np.float32)
+    small[rng.random(small.shape) < 0.003] = np.nan
+    lags = (np.array([-1.0, 0.0, 0.7, 1.4]), np.array([-0.6, 0.0, 0.9]), None, None, [0.0, 0.5])
+    gpu_handle.set_option("use_lds", use_lds)
+    try:
+        got = _sweep(gpu_handle, small, hs, large, hl, lags)
+    finally:
+        gpu_handle.set_option("use_lds", 1)
+    want = H.oracle_helio(small.astype(np.float64), hs, large.astype(np.float64), hl, lags, parallelism=False,
+                          unit_lag="deg")
+    assert np.isfinite(want).sum() >= 12
+    H.assert_corr_close(got, want, 1e-7, f"CAR sweep up to the pole, lds={use_lds}")

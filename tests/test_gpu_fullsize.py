@@ -116,6 +116,57 @@ def test_helioprojective_full_size(gpu_handle, big_scene):
     assert np.argmax(self_corr) == 4 and (self_corr[self_corr != self_corr[1, 1]] < 1.0 - 1e-6).all()
 
 
+def test_cfg2_helioprojective_61x61_full_size(gpu_handle, big_scene):
+    """BASELINE config 2 at its stated size: HRIEUV-like 2048^2 against the FSI-like 3072^2 reference, sub-map semantics
+    (alignment.py:649-651, 987-1016, 1018-1069), lag_crval1/2 = [-30, 30] x 1 arcsec = the whole 61 x 61 plane -- the
+    plan this sweep gets (256-lag patches, compile-time window pitch, k_sweep<HOMOGRAPHY_SERIES>) is the one checked:
+    argmax = injected shift, oracle spot checks at the peak, two corners and the zero lag, LDS vs global gather on a
+    strided subset, slice concatenation, and the zero lag's border decision switched off changes that lag-point only."""
+    from euispice_coreg_amd import _lib
+    from oracle import coreg_oracle as O
+    small, hs, large, hl, truth = big_scene
+    lag = np.arange(-30.0, 31.0, 1.0)
+    lags = (lag, lag, None, None, None)
+    ls = _lib.LagSet(*lags)
+    full = H.gpu_helio(gpu_handle, small, hs, large, hl, lags)[..., 0, 0, 0, 0]
+    stats = gpu_handle.last_stats()
+    assert full.shape == (61, 61) and np.isfinite(full).all()
+    assert stats["used_lds"] == 1 and stats["n_sweep_launches"] == 1 and stats["n_lags"] == 3721
+    am = np.unravel_index(np.argmax(full), full.shape)
+    assert (lag[am[0]], lag[am[1]]) == (truth["lag_crval1"], truth["lag_crval2"])
+    # oracle spot checks (seconds each at this size): the peak, two opposite corners, the zero lag
+    st = H.oracle_state(small, hs, large, hl, lags)
+    O.set_initial_header_values(st)
+    sub = O.create_submap_of_large_data(st)
+    for d1, d2 in [(17.0, -9.0), (-30.0, -30.0), (30.0, 30.0), (0.0, 0.0)]:
+        want = O.step(st, "helioprojective", st.data_small, sub, d1, d2, 0.0, 0.0, 0.0, 1.004)
+        got = full[int(d1) + 30, int(d2) + 30]
+        assert abs(got - want) <= 1e-7, (d1, d2, got, want)
+    # slices of the raveled lag range concatenate to the full map
+    n = ls.size
+    parts = [gpu_handle.sweep_helioprojective(hs, hs, ls, lag_begin=a, lag_end=b) for a, b in
+             ((0, 1000), (1000, 1001), (1001, 2500), (2500, n))]
+    assert np.abs(np.concatenate(parts) - full.ravel()).max() <= 1e-12
+    # the same lag-points, every 4th on each axis, through the global-memory gather (same arithmetic, no LDS window)
+    sub_lag = lag[::4]
+    gpu_handle.set_option("use_lds", 0)
+    try:
+        glob = gpu_handle.sweep_helioprojective(hs, hs, _lib.LagSet(sub_lag, sub_lag, None, None, None)).reshape(16, 16)
+    finally:
+        gpu_handle.set_option("use_lds", 1)
+    assert np.abs(glob - full[::4, ::4]).max() <= 1e-12
+    # without the wcslib border decision only the zero lag moves, and by less than 1e-4
+    gpu_handle.set_option("border_fix", 0)
+    try:
+        raw = gpu_handle.sweep_helioprojective(hs, hs, ls).reshape(61, 61)
+    finally:
+        gpu_handle.set_option("border_fix", 1)
+    d = np.abs(raw - full)
+    assert 0.0 < d[30, 30] < 1e-4
+    d[30, 30] = 0.0
+    assert d.max() == 0.0
+
+
 def test_zero_lag_full_size_measured(gpu_handle, big_scene):
     """Config 2 size, README lag axes through exactly 0: the zero lag against the oracle (whose border decision is
     wcslib's, border_golden.npz) at 1e-7, and the MEASURED weight of that decision at this size: the coefficient
@@ -141,6 +192,38 @@ def test_zero_lag_full_size_measured(gpu_handle, big_scene):
     d[1, 1] = 0.0
     assert d.max() == 0.0  # no other lag-point is touched
     assert np.argmax(raw) == np.argmax(got) == np.ravel_multi_index((2, 0, 0, 0, 0, 0), got.shape)
+
+
+def test_zero_lag_order1_full_size_follows_wcslib_taps(gpu_handle, big_scene):
+    """Odd spline orders at a noise-decided lag-point take floor(c) as their first tap, so the sign of wcslib's rounding
+    noise decides, for EVERY pixel, which neighbours (and whose NaN) enter the sample: the host evaluates the wcslib chain
+    for the whole 2048 x 2048 grid and k_parity_fix re-decides the flagged samples.  Checked here at full size against
+    the oracle, whose C twin of the wcslib restatement (oracle/csrc/wcslib_tan.c, bit-exact against astropy on the
+    golden border pixels) re-evaluates all 4 194 304 coordinates; a generic lag-point beside it as control."""
+    from oracle import coreg_oracle as O
+    small, hs, large, hl, truth = big_scene
+    assert O._wcstan_lib() is not None, "oracle/_build/liboracle_wcstan.so missing: run __graft_entry__.build()"
+    lags = (np.array([0.0, 17.0]), np.array([-9.0, 0.0]), None, None, None)
+    got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=1)[..., 0, 0, 0, 0]
+    gpu_handle.set_option("border_fix", 0)  # exact identity map for the zero lag: no wcslib decision at all
+    try:
+        raw = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=1, prepare=False)[..., 0, 0, 0, 0]
+    finally:
+        gpu_handle.set_option("border_fix", 1)
+    st = H.oracle_state(small, hs, large, hl, lags, order=1)
+    O.set_initial_header_values(st)
+    sub = O.create_submap_of_large_data(st)
+    want0 = O.step(st, "helioprojective", st.data_small, sub, 0.0, 0.0, 0.0, 0.0, 0.0, 1.004)
+    want1 = O.step(st, "helioprojective", st.data_small, sub, 17.0, -9.0, 0.0, 0.0, 0.0, 1.004)
+    assert abs(got[0, 1] - want0) <= 1e-7, (got[0, 1], want0)
+    assert abs(got[1, 0] - want1) <= 1e-7
+    # the tap decision is what moved the zero lag: without it the coefficient is measurably elsewhere, and only there
+    d = np.abs(raw - got)
+    print(f"\n[zero lag, order 1, 2048^2] |corr(exact identity) - corr(wcslib taps)| = {d[0, 1]:.3e}; "
+          f"|gpu - oracle| = {abs(got[0, 1] - want0):.2e}")
+    assert d[0, 1] > 10 * abs(got[0, 1] - want0)
+    d[0, 1] = 0.0
+    assert d.max() == 0.0
 
 
 # ---- BASELINE.json configs 3, 4, 5 at their stated sizes ---------------------------------------------------------

@@ -198,3 +198,77 @@ def test_hand_issued_lds_reads_are_not_touched_before_their_wait():
     p = subprocess.run([sys.executable, chk, _lib.LIB_PATH], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert "hand-issued LDS read groups" in p.stdout
+    assert "s_load_dwordx8 in k_sweep" in p.stdout
+
+
+def test_isa_check_catches_a_read_of_a_pending_scalar_load():
+    """The checker itself: an SGPR of a hand-issued s_load_dwordx8 named before the lgkmcnt(0) wait is reported, on the
+    fall-through path and behind a forward branch; the clean sequence passes."""
+    import importlib.util
+    from euispice_coreg_amd import _lib
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc",
+                                                                          "check_isa.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    head = "0000000000001000 <_ZN5coreg7k_sweepILi0ELi2EfLb0ELb0ELi121EEEvNS_9SweepArgsE>:\n"
+    clean = head + "\n".join([
+        "\ts_load_dwordx8 s[36:43], s[4:5], 0x0   // 000000001000: C00E0902 00000000",
+        "\tv_add_f64 v[4:5], v[0:1], s[44:45]      // 000000001008: D2800004 00000000",
+        "\ts_cbranch_execz 2                      // 000000001010: BF880002",
+        "\tv_mul_f64 v[6:7], v[4:5], v[4:5]        // 000000001014: D2810006 00000000",
+        "\ts_waitcnt lgkmcnt(0)                   // 00000000101C: BF8CC07F",
+        "\tv_add_f64 v[4:5], v[0:1], s[36:37]      // 000000001020: D2800004 00000000",
+        "\ts_endpgm                               // 000000001028: BF810000"]) + "\n"
+    n, bad = chk.check_scalar_loads(clean)
+    assert n == 1 and not bad
+    early = clean.replace("v[0:1], s[44:45]", "v[0:1], s[38:39]")
+    assert chk.check_scalar_loads(early)[1]
+    # the branch at 0x1010 skips the wait (target 0x101C + ... = 0x1020 when the offset is 3): the read there is early
+    skipping = clean.replace("s_cbranch_execz 2 ", "s_cbranch_execz 3 ")
+    assert chk.check_scalar_loads(skipping)[1]
+
+
+def _car_hdr(nx, ny, crval, cdelt, crpix=None, rot=0.0):
+    rho, lam = np.deg2rad(rot), cdelt[1] / cdelt[0]
+    crpix = crpix or ((nx + 1) / 2.0, (ny + 1) / 2.0)
+    return {"NAXIS": 2, "NAXIS1": nx, "NAXIS2": ny, "CTYPE1": "CRLN-CAR", "CTYPE2": "CRLT-CAR", "CUNIT1": "deg",
+            "CUNIT2": "deg", "CRPIX1": crpix[0], "CRPIX2": crpix[1], "CRVAL1": crval[0], "CRVAL2": crval[1],
+            "CDELT1": cdelt[0], "CDELT2": cdelt[1], "PC1_1": float(np.cos(rho)), "PC1_2": float(-lam * np.sin(rho)),
+            "PC2_1": float(np.sin(rho) / lam), "PC2_2": float(np.cos(rho)), "CROTA": rot}
+
+
+@pytest.mark.parametrize("tile_w", [8, 32, 128])
+def test_car_tile_margin_bounds_the_map(lib, tile_w):
+    """k_sweep (MODE_CAR) trusts, for the window it stages and for its 'interior' decision, that the image of a tile of
+    the target map lies inside the bounding box of its four mapped corners widened by car_tile_margin.  Checked here
+    against the host map for full-Sun target maps (tiles up to the poles), oblique and rolled shifted maps: every pixel
+    of every tile must land inside the widened box; polar tiles must get an infinite allowance (global path)."""
+    tile_h = 1024 // tile_w
+    target = _car_hdr(720, 360, (180.0, 0.0), (0.5, 0.5))
+    cases = [_car_hdr(400, 300, (181.3, 0.9), (0.4, 0.4)),
+             _car_hdr(300, 340, (170.0, -1.5), (0.3, 0.5), rot=4.0),
+             _car_hdr(200, 180, (200.0, 0.6), (0.45, 0.45), crpix=(100.5, -59.0)),  # rows at latitude 30 .. 89.6
+             _car_hdr(500, 500, (185.0, 25.0), (0.35, 0.35), rot=-7.0)]              # oblique: poles 25 deg apart
+    n_inf = n_checked = 0
+    worst = 0.0
+    for shifted in cases:
+        for j0 in range(0, 360, tile_h):
+            for i0 in range(0, 720, max(tile_w, 720 // 24)):
+                ii, jj = np.meshgrid(np.arange(i0, min(i0 + tile_w, 720)), np.arange(j0, min(j0 + tile_h, 360)))
+                lat = np.abs((jj + 1 - target["CRPIX2"]) * target["CDELT2"])
+                m = lib.car_tile_margin(target, shifted, tile_w, float(np.deg2rad(lat.max())))
+                assert m is not None and m >= 1.0
+                if not np.isfinite(m):
+                    n_inf += 1
+                    continue
+                x, y = lib.car_map(target, shifted, ii.ravel().astype(float), jj.ravel().astype(float))
+                cx, cy = lib.car_map(target, shifted, ii[[0, 0, -1, -1], [0, -1, 0, -1]].astype(float),
+                                     jj[[0, 0, -1, -1], [0, -1, 0, -1]].astype(float))
+                if cx.max() - cx.min() > 0.5 * 360.0 / abs(shifted["CDELT1"]):
+                    continue  # the tile straddles the +-180 deg cut of the shifted map: never 'interior', never in LDS
+                out = max(cx.min() - x.min(), x.max() - cx.max(), cy.min() - y.min(), y.max() - cy.max())
+                worst = max(worst, out / m)
+                assert out <= m, (tile_w, shifted["CRVAL2"], i0, j0, out, m)
+                n_checked += 1
+    print(f"tile_w={tile_w}: {n_checked} tiles checked, {n_inf} with an infinite allowance, worst excess / allowance = {worst:.3f}")
+    assert n_checked > 60 and n_inf > 0 and worst > 0.01  # the bound is exercised, not vacuous

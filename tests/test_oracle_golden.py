@@ -232,6 +232,52 @@ def test_wcslib_restatement_is_bit_exact_on_border_pixels(name):
     assert 0.4 * bx.size < n < 0.6 * bx.size
 
 
+@pytest.fixture(scope="module")
+def wcstan_c():
+    """oracle/_build/liboracle_wcstan.so, built by oracle/Makefile (gcc; __graft_entry__.build() runs it too)."""
+    import os
+    import subprocess
+    from tests.conftest import ROOT
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    O._WCSTAN_LIB = None
+    assert O._wcstan_lib() is not None
+    return O
+
+
+@pytest.mark.parametrize("name", BORDER_CASES)
+def test_wcslib_c_twin_is_bit_exact_on_border_pixels(wcstan_c, name):
+    """oracle/csrc/wcslib_tan.c -- the oracle's wcslib restatement in C, which lets it re-evaluate every pixel of a
+    2048 x 2048 grid -- against astropy 4.3.1 / wcslib 7.6 on EVERY border pixel of the golden headers, bit for bit."""
+    import os
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "border_golden.npz"))
+    h = _border_header(g, name)
+    x, y, lng, lat = wcstan_c.wcslib_pixel_to_pixel(h, h, g[name + "/bx"], g[name + "/by"])
+    assert np.array_equal(lng, g[name + "/lon"]) and np.array_equal(lat, g[name + "/lat"])
+    assert np.array_equal(x, g[name + "/rx"]) and np.array_equal(y, g[name + "/ry"])
+
+
+def test_wcslib_c_twin_equals_python_class_on_interior_pixels_and_lags(wcstan_c):
+    """... and against the Python class on what the golden file does not hold: interior pixels, non-identical header
+    pairs (CRVAL / CDELT / CROTA lags), far off-axis pixels, headers in degrees."""
+    import os
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "border_golden.npz"))
+    rng = np.random.default_rng(3)
+    for name in BORDER_CASES:
+        h = _border_header(g, name)
+        nx, ny = h["NAXIS1"], h["NAXIS2"]
+        px = np.concatenate([rng.integers(0, nx, 150).astype(float), rng.uniform(-0.3 * nx, 1.3 * nx, 50)])
+        py = np.concatenate([rng.integers(0, ny, 150).astype(float), rng.uniform(-0.3 * ny, 1.3 * ny, 50)])
+        for d in [dict(), dict(CRVAL1=h["CRVAL1"] + 3.7 * h["CDELT1"]), dict(CRVAL2=h["CRVAL2"] - 11.0 * h["CDELT2"]),
+                  dict(CDELT1=h["CDELT1"] * 1.0003)]:
+            h2 = dict(h, **d)
+            got = wcstan_c.wcslib_pixel_to_pixel(h, h2, px, py)
+            want = wcstan_c.wcslib_pixel_to_pixel(h, h2, px, py, force_python=True)
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b, equal_nan=True), (name, d)
+
+
 def test_oracle_zero_lag_uses_wcslib_border_decision():
     import os
     from tests.conftest import GOLDEN
