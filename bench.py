@@ -142,6 +142,69 @@ def cpu_baseline(np, small, hs, large, hl, lags, n_sample, cores):
                       f"{dt:.1f} s wall"}, corr, subset
 
 
+def main_threads(args):
+    """`--launch threads`: this ONE process drives args.gpus GPUs through the library's multi-GPU driver (no
+    torch.distributed).  A step = one whole sweep call: per-device sweeps of the lag-plane blocks, the one RCCL all-gather,
+    the map on the host (the call is synchronous, so steps do not overlap)."""
+    import numpy as np
+    from euispice_coreg_amd import _lib, synthetic
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    small, hs, large, hl, truth = synthetic.make_scene(float32_exact=not args.small_f64)
+    lag1 = lag2 = np.arange(-30, 30, 1, dtype=np.float64)
+    lags = _lib.LagSet(lag1, lag2, None, None, None)
+    L = lags.size
+    grid = _lib.Grid(LONLIMS, LATLIMS, GRID_SHAPE, numpy_lat_trig=True)
+    n = args.gpus if args.gpus > 0 else 0
+    with _lib.MultiHandle(n) as m:
+        m.set_option("use_lds", args.use_lds)
+        m.set_small(small)
+        m.prepare_reference_carrington(large, hl, grid, SOLAR_R, ORDER)
+        for _ in range(args.warmup):
+            corr = m.sweep_carrington(hs, grid, SOLAR_R, lags, order=ORDER)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            corr = m.sweep_carrington(hs, grid, SOLAR_R, lags, order=ORDER)
+        elapsed = time.perf_counter() - t0
+        st = m.last_stats()
+        corr = corr.reshape(lag1.size, lag2.size)
+        single = m.handle(0).sweep_carrington(hs, grid, SOLAR_R, lags, order=ORDER).reshape(corr.shape)
+        small_h = small if args.small_f64 else small.astype(np.float32)
+        large_h = large.astype(np.float32)
+        times = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            m.set_small(small_h)
+            m.prepare_reference_carrington(large_h, hl, grid, SOLAR_R, ORDER)
+            out_host = m.sweep_carrington(hs, grid, SOLAR_R, lags, order=ORDER)
+            times.append(time.perf_counter() - t0)
+        best = min(times[1:])
+        am = np.unravel_index(np.nanargmax(corr), corr.shape)
+        out = {"metric": METRIC, "value": L * args.steps / elapsed, "unit": "lag-points/s", "n_gpus": m.size,
+               "n_ranks_seen": m.size, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "headline: Carrington 'fa' 2048x2048 grid, 60x60 CRVAL lags (see bench.py)",
+                          "lag_points": L, "grid": list(GRID_SHAPE), "resident": True, "sweeps_in_flight": 1,
+                          "launch": "threads", "lag_sharding": st["lag_sharding"],
+                          "parallelism": f"one process, {m.size} device threads, lag-plane blocks + 1 all-gather "
+                                         f"({st['collective']})"},
+               "per_rank": [{"rank": k, "kernel_ms": ms} for k, ms in enumerate(st["per_device_sweep_kernel_ms"])],
+               "map_vs_single_gpu": {"max_abs_diff": float(np.nanmax(np.abs(single - corr))),
+                                     "same_argmax": bool(np.nanargmax(single) == np.nanargmax(corr)), "tolerance": 1e-12},
+               "pcie_inclusive": {"value": L / best, "unit": "lag-points/s", "ms_per_step": 1e3 * best, "n_gpus": m.size,
+                                  "identical_to_resident_map": bool(np.array_equal(out_host.reshape(corr.shape), corr,
+                                                                                   equal_nan=True))},
+               "argmax_lag_arcsec": [float(lag1[am[0]]), float(lag2[am[1]])],
+               "injected_shift_arcsec": [truth["lag_crval1"], truth["lag_crval2"]],
+               "roofline": None, "cpu_baseline": None}
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,11 +217,17 @@ def main():
     ap.add_argument("--use-lds", type=int, default=1)
     ap.add_argument("--small-f64", action="store_true",
                     help="image to align with full float64 pixels (not float32-exact): times the TS = double kernel")
+    ap.add_argument("--launch", choices=["ranks", "threads"], default="ranks",
+                    help="N > 1: one process per GPU over torch.distributed / RCCL (the driver's form), or ONE process "
+                         "driving all N GPUs through the library's own multi-GPU driver (coreg_multi: a host thread per "
+                         "device, one RCCL all-gather) -- what a plain `Alignment(parallelism=True)` script uses")
     ap.add_argument("--shard", choices=["auto", "lags", "points"], default="auto",
                     help="N > 1: cut the lag plane in blocks (+ one all-gather) or the target grid in point shares "
                          "(+ one all-reduce of the six sums per lag); auto = points below 128 lag-points per GPU")
     args = ap.parse_args()
 
+    if args.launch == "threads" and "WORLD_SIZE" not in os.environ:
+        return main_threads(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
 

@@ -110,6 +110,28 @@ SYMBOLS = [
     ("coreg_car_map", C.c_int, [_WP, _WP, C.c_int64, _P, _P, _P, _P]),
     ("coreg_wcslib_pixel_to_pixel", C.c_int, [_WP, _WP, C.c_int64, _P, _P, _P, _P, _P, _P]),
     ("coreg_car_tile_margin", C.c_int, [_WP, _WP, C.c_int32, C.c_double, C.POINTER(C.c_double)]),
+    # all GPUs of the node from one process
+    ("coreg_device_count", C.c_int, []),
+    ("coreg_multi_create", C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(C.c_int)]),
+    ("coreg_multi_destroy", None, [_P]),
+    ("coreg_multi_size", C.c_int, [_P]),
+    ("coreg_multi_handle", _P, [_P, C.c_int]),
+    ("coreg_multi_last_error", C.c_char_p, [_P]),
+    ("coreg_multi_collective", C.c_char_p, [_P]),
+    ("coreg_multi_last_mode", C.c_int, [_P]),
+    ("coreg_multi_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
+    ("coreg_multi_set_small", C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32]),
+    ("coreg_multi_threshold_small", C.c_int, [_P, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_longlong)]),
+    ("coreg_multi_set_reference_on_grid", C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32]),
+    ("coreg_multi_prepare_reference_carrington", C.c_int,
+     [_P, _P, C.c_int, C.c_int32, C.c_int32, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
+    ("coreg_multi_prepare_reference_helioprojective", C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32, _WP, _WP, C.c_int]),
+    ("coreg_multi_sweep_carrington", C.c_int,
+     [_P, _WP, C.POINTER(CarrGrid), C.c_double, C.POINTER(Lags), C.c_int, C.c_int, C.c_int, _P]),
+    ("coreg_multi_sweep_helioprojective", C.c_int, [_P, _WP, _WP, C.POINTER(Lags), C.c_int, C.c_int, C.c_int, _P]),
+    ("coreg_multi_last_stats", C.c_int, [_P, C.c_int, C.POINTER(Stats)]),
+    ("coreg_multi_plan", C.c_int,
+     [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 ]
 
 _lib = None
@@ -443,6 +465,191 @@ class CoregHandle:
         return {f: getattr(s, f) for f, _ in Stats._fields_}
 
 
+class _HandleView(CoregHandle):
+    """A CoregHandle that does not own its context (device k of a MultiHandle): single-device utilities and options."""
+
+    def __init__(self, lib, ptr):  # noqa: super().__init__ would create a context
+        self._lib = lib
+        self._h = _P(ptr)
+        self.reference_tag = None
+
+    def close(self):
+        self._h = None
+
+
+MULTI_MODES = {0: "none", 1: "blocks", 2: "slices", 3: "points"}
+
+
+def device_count() -> int:
+    """GPUs the library sees (COREG_VIRTUAL_DEVICES overrides it); 0 when there is none.  Does not touch torch."""
+    return max(0, int(load_library().coreg_device_count()))
+
+
+def multi_plan(n_crval1, n_crval2, n_inner, world):
+    """(mode, g1, g2) the in-library multi-GPU driver gives a lag set (host-only helper; mirrors parallel.py)."""
+    mode, g1, g2 = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = load_library().coreg_multi_plan(int(n_crval1), int(n_crval2), int(n_inner), int(world), C.byref(mode),
+                                         C.byref(g1), C.byref(g2))
+    if rc != COREG_OK:
+        raise CoregError(rc, "coreg_multi_plan: bad arguments")
+    return MULTI_MODES[mode.value], g1.value, g2.value
+
+
+class MultiHandle:
+    """Every GPU of the node from this one process (include/coreg_hip.h, coreg_multi): one host thread + library context
+    per device inside the library, full image replicas, lag-plane blocks, ONE RCCL all-gather of the per-lag
+    coefficients.  Same calling surface as CoregHandle for what `hdrshift.Alignment` needs; sweeps always return the
+    whole map (lag_begin / lag_end must span it)."""
+
+    def __init__(self, n_devices=0, device_ids=None):
+        self._lib = load_library()
+        self._m = _P()
+        ids = None
+        if device_ids is not None:
+            ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+            n_devices = len(device_ids)
+        rc = self._lib.coreg_multi_create(C.byref(self._m), int(n_devices), ids)
+        if rc != COREG_OK:
+            self._m = None
+            raise CoregError(rc, "coreg_multi_create failed (no HIP device visible?)")
+        self.reference_tag = None
+        self.size = int(self._lib.coreg_multi_size(self._m))
+        self.primary = _HandleView(self._lib, self._lib.coreg_multi_handle(self._m, 0))
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self.primary.close()
+            self._lib.coreg_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != COREG_OK:
+            raise CoregError(rc, self._lib.coreg_multi_last_error(self._m).decode("utf-8", "replace"))
+
+    @property
+    def collective(self) -> str:
+        return self._lib.coreg_multi_collective(self._m).decode()
+
+    @property
+    def last_mode(self) -> str:
+        return MULTI_MODES[int(self._lib.coreg_multi_last_mode(self._m))]
+
+    def handle(self, k) -> CoregHandle:
+        ptr = self._lib.coreg_multi_handle(self._m, int(k))
+        if not ptr:
+            raise IndexError(k)
+        return _HandleView(self._lib, ptr)
+
+    def set_option(self, name, value):
+        self._chk(self._lib.coreg_multi_set_option(self._m, name.encode(), int(value)))
+
+    def synchronize(self):
+        for k in range(self.size):
+            self.handle(k).synchronize()
+
+    @staticmethod
+    def _pixels(img):
+        img = np.asarray(img)
+        if img.ndim != 2:
+            raise ValueError("image must be 2-D")
+        if img.dtype == np.float32:
+            return np.ascontiguousarray(img), COREG_F32
+        return np.ascontiguousarray(img, dtype=np.float64), COREG_F64
+
+    def set_small(self, img):
+        img, dt = self._pixels(img)
+        self._chk(self._lib.coreg_multi_set_small(self._m, img.ctypes.data, dt, img.shape[0], img.shape[1]))
+
+    def threshold_small(self, vmin=None, vmax=None) -> int:
+        n = C.c_longlong(0)
+        self._chk(self._lib.coreg_multi_threshold_small(self._m, int(vmin is not None), float(vmin or 0.0),
+                                                        int(vmax is not None), float(vmax or 0.0), C.byref(n)))
+        return int(n.value)
+
+    def set_reference_on_grid(self, ref):
+        ref = np.ascontiguousarray(ref)
+        if ref.ndim != 2 or ref.dtype not in (np.float32, np.float64):
+            raise ValueError("reference on grid must be a 2-D float32/float64 array")
+        self.reference_tag = None
+        self._chk(self._lib.coreg_multi_set_reference_on_grid(
+            self._m, ref.ctypes.data, COREG_F32 if ref.dtype == np.float32 else COREG_F64, ref.shape[0], ref.shape[1]))
+
+    def prepare_reference_carrington(self, large, hdr_large, grid: Grid, solar_r, order=2):
+        large, dt = self._pixels(large)
+        w = wcs_from_header(hdr_large, carrington=True)
+        self.reference_tag = None
+        self._chk(self._lib.coreg_multi_prepare_reference_carrington(
+            self._m, large.ctypes.data, dt, large.shape[0], large.shape[1], C.byref(w), C.byref(grid.c), float(solar_r),
+            int(order)))
+
+    def prepare_reference_helioprojective(self, large, hdr_large, hdr_small, order=2):
+        large, dt = self._pixels(large)
+        wl, ws = wcs_from_header(hdr_large), wcs_from_header(hdr_small)
+        self.reference_tag = None
+        self._chk(self._lib.coreg_multi_prepare_reference_helioprojective(
+            self._m, large.ctypes.data, dt, large.shape[0], large.shape[1], C.byref(wl), C.byref(ws), int(order)))
+
+    def _whole(self, lags, lag_begin, lag_end):
+        if int(lag_begin) != 0 or (lag_end is not None and int(lag_end) != lags.size):
+            raise ValueError("a multi-GPU sweep covers the whole lag set (the library cuts it itself)")
+
+    def sweep_carrington(self, hdr_small, grid: Grid, solar_r, lags: LagSet, order=2, method=METHOD_CORRELATION,
+                         cdelt_semantics=CDELT_INTENDED, lag_begin=0, lag_end=None):
+        self._whole(lags, lag_begin, lag_end)
+        w = wcs_from_header(hdr_small, carrington=True)
+        out = np.empty(lags.size, dtype=np.float64)
+        self._chk(self._lib.coreg_multi_sweep_carrington(self._m, C.byref(w), C.byref(grid.c), float(solar_r),
+                                                         C.byref(lags.c), int(order), int(method), int(cdelt_semantics),
+                                                         out.ctypes.data))
+        return out
+
+    def sweep_helioprojective(self, hdr_target, hdr_small, lags: LagSet, order=2, method=METHOD_CORRELATION,
+                              cdelt_semantics=CDELT_INTENDED, lag_begin=0, lag_end=None):
+        self._whole(lags, lag_begin, lag_end)
+        wt, w = wcs_from_header(hdr_target), wcs_from_header(hdr_small)
+        out = np.empty(lags.size, dtype=np.float64)
+        self._chk(self._lib.coreg_multi_sweep_helioprojective(self._m, C.byref(wt), C.byref(w), C.byref(lags.c),
+                                                              int(order), int(method), int(cdelt_semantics),
+                                                              out.ctypes.data))
+        return out
+
+    def resample_helioprojective(self, hdr_target, hdr, order=2, dtype=np.float32):
+        """Single resample of the resident image to align: device 0's copy (every device holds the same one)."""
+        return self.primary.resample_helioprojective(hdr_target, hdr, order=order, dtype=dtype)
+
+    def get_reference_on_grid(self, shape, dtype):
+        return self.primary.get_reference_on_grid(shape, dtype)
+
+    def last_stats(self, k=None):
+        """Stats of device k's share of the last sweep; k = None: device 0's with the kernel times of all devices."""
+        def one(i):
+            s = Stats()
+            self._chk(self._lib.coreg_multi_last_stats(self._m, int(i), C.byref(s)))
+            return {f: getattr(s, f) for f, _ in Stats._fields_}
+        if k is not None:
+            return one(k)
+        per = [one(i) for i in range(self.size)]
+        out = dict(per[0])
+        out["per_device_sweep_kernel_ms"] = [p["sweep_kernel_ms"] for p in per]
+        out["n_lags"] = sum(p["n_lags"] for p in per) if self.last_mode != "points" else per[0]["n_lags"]
+        out["n_devices"] = self.size
+        out["collective"] = self.collective
+        out["lag_sharding"] = self.last_mode
+        return out
+
+
 _SHARED = {}
 
 
@@ -456,6 +663,15 @@ def shared_handle(device=-1, slot=0) -> CoregHandle:
     if h is None or getattr(h, "_h", None) is None:
         h = CoregHandle(device)
         _SHARED[key] = h
+    return h
+
+
+def shared_multi_handle() -> MultiHandle:
+    """One long-lived MultiHandle over all visible GPUs for this process (created on first use)."""
+    h = _SHARED.get("multi")
+    if h is None or getattr(h, "_m", None) is None:
+        h = MultiHandle(0)
+        _SHARED["multi"] = h
     return h
 
 

@@ -74,6 +74,13 @@ struct PinBuf {  // page-locked host staging (async H2D without a host sync)
     }
 };
 
+// where the pixels of an upload live
+enum SrcKind {
+    SRC_HOST = 0,    // pageable host memory: staged through the handle's pinned buffers
+    SRC_PINNED = 1,  // page-locked host memory every device can DMA from (coreg_multi's shared staging): one async copy
+    SRC_DEVICE = 2,  // memory of the handle's GPU: read where it is
+};
+
 constexpr int kMaxDevices = 64;
 std::mutex g_attr_mutex;
 
@@ -135,6 +142,7 @@ struct coreg_handle {
     long long pending_n_out = 0;
 
     // options
+    int64_t opt_crop_reference = 1;
     int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
 
     coreg_stats stats;
@@ -217,6 +225,7 @@ public:
             src_ = (const char*)src;
             bytes_ = bytes;
             per_ = per;
+            rows_ = 0;
             n_parts_ = nt;
             next_ = 1;  // part 0 is the caller's
             pending_ = nt - 1;
@@ -224,6 +233,35 @@ public:
         }
         cv_.notify_all();
         std::memcpy(dst, src, std::min(per, bytes));
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+    }
+    // `rows` rows of `row_bytes` bytes, `src_pitch` bytes apart in the source, packed contiguously into dst
+    void copy_rows(void* dst, const void* src, size_t rows, size_t row_bytes, size_t src_pitch) {
+        const size_t min_per_thread = (size_t)512 << 10;
+        const unsigned nt = (unsigned)std::min<size_t>(
+            std::min<size_t>(workers_.size() + 1, std::max<size_t>(1, rows)), std::max<size_t>(1, rows * row_bytes / min_per_thread));
+        if (nt <= 1) {
+            for (size_t r = 0; r < rows; ++r)
+                std::memcpy((char*)dst + r * row_bytes, (const char*)src + r * src_pitch, row_bytes);
+            return;
+        }
+        std::lock_guard<std::mutex> use(use_);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            dst_ = (char*)dst;
+            src_ = (const char*)src;
+            rows_ = rows;
+            row_bytes_ = row_bytes;
+            src_pitch_ = src_pitch;
+            per_ = (rows + nt - 1) / nt;  // rows per part
+            n_parts_ = nt;
+            next_ = 1;
+            pending_ = nt - 1;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        part(0);
         std::unique_lock<std::mutex> lk(m_);
         done_.wait(lk, [&] { return pending_ == 0; });
     }
@@ -248,20 +286,28 @@ private:
     void run() {
         unsigned long long seen = 0;
         for (;;) {
-            unsigned part;
+            unsigned idx;
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && next_ < n_parts_); });
                 if (stop_) return;
-                part = next_++;
+                idx = next_++;
                 if (next_ >= n_parts_) seen = epoch_;
             }
-            const size_t lo = std::min(bytes_, (size_t)part * per_), hi = std::min(bytes_, lo + per_);
-            if (hi > lo) std::memcpy(dst_ + lo, src_ + lo, hi - lo);
+            part(idx);
             {
                 std::lock_guard<std::mutex> lk(m_);
                 if (--pending_ == 0) done_.notify_all();
             }
+        }
+    }
+    void part(unsigned p) {
+        if (rows_ > 0) {
+            const size_t lo = std::min(rows_, (size_t)p * per_), hi = std::min(rows_, lo + per_);
+            for (size_t r = lo; r < hi; ++r) std::memcpy(dst_ + r * row_bytes_, src_ + r * src_pitch_, row_bytes_);
+        } else {
+            const size_t lo = std::min(bytes_, (size_t)p * per_), hi = std::min(bytes_, lo + per_);
+            if (hi > lo) std::memcpy(dst_ + lo, src_ + lo, hi - lo);
         }
     }
     std::vector<std::thread> workers_;
@@ -269,12 +315,15 @@ private:
     std::condition_variable cv_, done_;
     char* dst_ = nullptr;
     const char* src_ = nullptr;
-    size_t bytes_ = 0, per_ = 0;
+    size_t bytes_ = 0, per_ = 0, rows_ = 0, row_bytes_ = 0, src_pitch_ = 0;
     unsigned n_parts_ = 0, next_ = 0, pending_ = 0;
     unsigned long long epoch_ = 0;
     bool stop_ = false;
 };
 void parallel_memcpy(void* dst, const void* src, size_t bytes) { CopyPool::get().copy(dst, src, bytes); }
+void parallel_copy_rows(void* dst, const void* src, size_t rows, size_t row_bytes, size_t src_pitch) {
+    CopyPool::get().copy_rows(dst, src, rows, row_bytes, src_pitch);
+}
 
 int staged_upload(coreg_handle* h, void* dev, const void* host, size_t bytes) {
     // two staging buffers used alternately, each guarded by an event recorded behind its last copy: filling the
@@ -304,12 +353,16 @@ int staged_upload(coreg_handle* h, void* dev, const void* host, size_t bytes) {
 // A float64 image (host: staged upload; device: the caller's buffer) is kept as float32 on the device when every finite
 // value is exactly representable (FITS BITPIX=-32 / integer data cast to float64), else as float64.  The test and the
 // conversion run on the GPU.  src_on_device: `img` is device memory, read by work enqueued on the handle's stream.
-int upload_image(coreg_handle* h, const double* img, size_t n, DevBuf& buf, bool* is_f32, bool src_on_device = false) {
+int upload_image(coreg_handle* h, const double* img, size_t n, DevBuf& buf, bool* is_f32, SrcKind kind = SRC_HOST) {
+    const bool src_on_device = kind == SRC_DEVICE;
     HIPCHK(h->up_flag.reserve(sizeof(int)));
     const double* src = img;
     if (!src_on_device) {
         HIPCHK(h->up_f64.reserve(n * sizeof(double)));
-        RETCHK(staged_upload(h, h->up_f64.p, img, n * sizeof(double)));
+        if (kind == SRC_PINNED)
+            HIPCHK(hipMemcpyAsync(h->up_f64.p, img, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        else
+            RETCHK(staged_upload(h, h->up_f64.p, img, n * sizeof(double)));
         src = h->up_f64.as<double>();
     }
     HIPCHK(hipMemsetAsync(h->up_flag.p, 0, sizeof(int), h->stream));
@@ -1074,8 +1127,14 @@ int begin_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_d
         *out_dev = h->out_dev.as<double>();
     }
     HIPCHK(hipEventRecord(h->ev_t0, h->stream));
+    // (the output is NaN-initialised by the prologue kernel of upload_plan, or by fill_nan on the paths that launch
+    // nothing)
+    return COREG_OK;
+}
+
+int fill_nan(coreg_handle* h, double* out_dev, long long n_out) {
     if (n_out > 0) {
-        hipLaunchKernelGGL(k_fill, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, h->stream, *out_dev,
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, h->stream, out_dev,
                            (long long)n_out, std::numeric_limits<double>::quiet_NaN());
         HIPCHK(hipGetLastError());
     }
@@ -1086,7 +1145,11 @@ int collect_stats(coreg_handle* h) {
     if (!h->stats_pending) return COREG_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     h->stats_pending = false;
-    if (h->pin_info.p) h->stats.n_active_points = ((const long long*)h->pin_info.p)[1];
+    if (h->tile_info.p && h->stats.n_sweep_launches > 0) {
+        long long info[3] = {0, 0, 0};
+        HIPCHK(hipMemcpy(info, h->tile_info.p, sizeof(info), hipMemcpyDeviceToHost));
+        h->stats.n_active_points = info[1];
+    }
     float ms = 0.f;
     for (size_t i = 0; i < h->ev_sweep_used; ++i) {
         HIPCHK(hipEventElapsedTime(&ms, h->ev_sweep[i].a, h->ev_sweep[i].b));
@@ -1107,11 +1170,7 @@ int end_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_dev
     HIPCHK(hipEventRecord(h->ev_t1, h->stream));
     if (!out_on_device && n_out > 0)
         HIPCHK(hipMemcpyAsync(corr_out, out_dev, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h->pin_info.reserve(4 * sizeof(long long)));
-    std::memset(h->pin_info.p, 0, 4 * sizeof(long long));
-    if (h->tile_info.p)
-        HIPCHK(hipMemcpyAsync(h->pin_info.p, h->tile_info.p, 3 * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
-    h->stats_pending = true;
+    h->stats_pending = true;  // (the kept-point count is read back when the statistics are asked for: collect_stats)
     if (!out_on_device) return collect_stats(h);
     return COREG_OK;
 }
@@ -1121,19 +1180,24 @@ long long lds_window_elems(const coreg_handle* h) {
     return (long long)(std::max(lds_min, (size_t)h->opt_lds_bytes) / sizeof(double));
 }
 
-// upload the concatenated per-launch lag parameters / output indices through pinned staging (no host sync)
-int upload_plan(coreg_handle* h, const std::vector<double>& params, const std::vector<long long>& outidx) {
-    HIPCHK(h->pin_params.reserve(params.size() * sizeof(double)));
-    HIPCHK(h->pin_outidx.reserve(outidx.size() * sizeof(long long)));
+// The concatenated per-launch lag parameters / output indices go to page-locked memory and are fetched from there by the
+// prologue kernel, which also NaN-initialises the output (no host sync, no DMA-engine copy between the kernels).
+int upload_plan(coreg_handle* h, const std::vector<double>& params, const std::vector<long long>& outidx,
+                double* out_dev, long long n_out) {
+    const size_t bytes = params.size() * sizeof(double) + outidx.size() * sizeof(long long);
     HIPCHK(h->lane_params.reserve(params.size() * sizeof(double)));
     HIPCHK(h->out_index.reserve(outidx.size() * sizeof(long long)));
-    HIPCHK(hipEventSynchronize(h->ev_upload));  // previous upload has left the staging buffers
+    HIPCHK(hipEventSynchronize(h->ev_upload));  // the previous sweep's prologue has read the staging buffer
+    HIPCHK(h->pin_params.reserve(bytes));
     std::memcpy(h->pin_params.p, params.data(), params.size() * sizeof(double));
-    std::memcpy(h->pin_outidx.p, outidx.data(), outidx.size() * sizeof(long long));
-    HIPCHK(hipMemcpyAsync(h->lane_params.p, h->pin_params.p, params.size() * sizeof(double), hipMemcpyHostToDevice,
-                          h->stream));
-    HIPCHK(hipMemcpyAsync(h->out_index.p, h->pin_outidx.p, outidx.size() * sizeof(long long), hipMemcpyHostToDevice,
-                          h->stream));
+    std::memcpy((char*)h->pin_params.p + params.size() * sizeof(double), outidx.data(), outidx.size() * sizeof(long long));
+    void* src_dev = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&src_dev, h->pin_params.p, 0));
+    const long long n_max = std::max<long long>(std::max<long long>((long long)params.size(), (long long)outidx.size()), n_out);
+    const int nb = (int)std::max<long long>(1, std::min<long long>((n_max + 255) / 256, 512));
+    hipLaunchKernelGGL(k_prologue, dim3(nb), dim3(256), 0, h->stream, (const double*)src_dev, h->lane_params.as<double>(),
+                       (long long)params.size(), h->out_index.as<long long>(), (long long)outidx.size(), out_dev, n_out);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev_upload, h->stream));
     return COREG_OK;
 }
@@ -1272,6 +1336,8 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         h->opt_border_fix = value ? 1 : 0;  // 0: the zero lag keeps every border pixel (exact identity map)
     } else if (n == "pitch") {
         h->opt_pitch = value;  // -1: automatic compile-time window pitch, 0: per-visit pitch, else one of pick_pitch's
+    } else if (n == "crop_reference") {
+        h->opt_crop_reference = value ? 1 : 0;  // 0: the reference preparation uploads the whole source image
     } else if (n == "tile_skip") {
         h->opt_tile_skip = value ? 1 : 0;  // 0: k_precompute evaluates every grid point (tests compare both)
     } else if (n == "h_series") {
@@ -1318,23 +1384,29 @@ int coreg_set_small_f32(coreg_handle* h, const float* img, int32_t ny, int32_t n
     return device_mean<float>(h, h->small.as<float>(), (long long)n, h->pivots.as<double>() + 1);
 }
 
-int coreg_set_small_from_device(coreg_handle* h, const void* dev_img, int dtype, int32_t ny, int32_t nx) {
+// image to align from pinned host memory or from this GPU's memory (one asynchronous copy, no staging)
+static int set_small_direct(coreg_handle* h, const void* img, int dtype, int32_t ny, int32_t nx, SrcKind kind) {
     if (!h) return COREG_EINVAL;
-    if (!dev_img || ny < 1 || nx < 1 || (dtype != COREG_F32 && dtype != COREG_F64))
-        return fail(h, COREG_EINVAL, "set_small_from_device: bad argument");
+    if (!img || ny < 1 || nx < 1 || (dtype != COREG_F32 && dtype != COREG_F64))
+        return fail(h, COREG_EINVAL, "set_small: bad argument");
     RETCHK(bind_device(h));
     const size_t n = (size_t)ny * nx;
     if (dtype == COREG_F32) {
         HIPCHK(h->small.reserve(n * sizeof(float)));
-        HIPCHK(hipMemcpyAsync(h->small.p, dev_img, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->small.p, img, n * sizeof(float),
+                              kind == SRC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
         h->small_f32 = true;
     } else {
-        RETCHK(upload_image(h, (const double*)dev_img, n, h->small, &h->small_f32, true));
+        RETCHK(upload_image(h, (const double*)img, n, h->small, &h->small_f32, kind));
     }
     h->sW = nx;
     h->sH = ny;
     if (h->small_f32) return device_mean<float>(h, h->small.as<float>(), (long long)n, h->pivots.as<double>() + 1);
     return device_mean<double>(h, h->small.as<double>(), (long long)n, h->pivots.as<double>() + 1);
+}
+
+int coreg_set_small_from_device(coreg_handle* h, const void* dev_img, int dtype, int32_t ny, int32_t nx) {
+    return set_small_direct(h, dev_img, dtype, ny, nx, SRC_DEVICE);
 }
 
 int coreg_threshold_small(coreg_handle* h, int has_min, double vmin, int has_max, double vmax, long long* n_finite) {
@@ -1389,21 +1461,102 @@ int coreg_set_reference_on_grid(coreg_handle* h, const void* ref, int dtype, int
     return ref_pivot(h);
 }
 
+// Which pixels of the W x H source image can the once-only resample touch?  The bounding box of the in-bounds sample
+// coordinates is computed on the GPU by the same coordinate function the resample uses (k_resample_bbox), widened by the
+// spline apron and clipped to the image.  Uploading only that rectangle -- the Carrington grid of the headline touches
+// 2 % of the 3072 x 3072 reference, the sub-map of a 2048 x 2048 HRIEUV field 0.6 % -- takes the reference image out of
+// the PCIe-inclusive cost of a call; results are bit-identical (same pixels, same arithmetic).  Costs one ~20 us kernel
+// and a 4-double read-back.  crop = {0, 0, W, H} when cropping would not pay (more than half the image) or is disabled
+// (coreg_set_option "crop_reference" 0).
+struct CropRect {
+    int x0, y0, w, h;
+};
+static int reference_crop(coreg_handle* h, int mode, const ResampleArgs& a0, int order, CropRect* out) {
+    *out = {0, 0, a0.W, a0.H};
+    if (!h->opt_crop_reference || a0.W < 64 || a0.H < 64) return COREG_OK;
+    const int nb = 256;
+    HIPCHK(h->red_sum.reserve((size_t)nb * 4 * sizeof(double)));
+    ResampleArgs a = a0;
+    a.bbox = h->red_sum.as<double>();
+    if (mode == MODE_TRANSLATE) hipLaunchKernelGGL((k_resample_bbox<MODE_TRANSLATE>), dim3(nb), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL((k_resample_bbox<MODE_HOMOGRAPHY>), dim3(nb), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    std::vector<double> part((size_t)nb * 4);
+    HIPCHK(hipMemcpyAsync(part.data(), a.bbox, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double mnx = 1e300, mxx = -1e300, mny = 1e300, mxy = -1e300;
+    for (int b = 0; b < nb; ++b) {
+        mnx = std::min(mnx, part[4 * b + 0]);
+        mxx = std::max(mxx, part[4 * b + 1]);
+        mny = std::min(mny, part[4 * b + 2]);
+        mxy = std::max(mxy, part[4 * b + 3]);
+    }
+    const int apron = order / 2 + 3;  // taps of an in-bounds sample: [floor(c) - order/2 - 1, floor(c) + order - order/2 + 1]
+    int x0 = 0, x1 = apron * 2, y0 = 0, y1 = apron * 2;  // nothing in bounds: any small rectangle (never read)
+    if (mnx <= mxx && mny <= mxy) {
+        x0 = std::max(0, (int)std::floor(mnx) - apron);
+        x1 = std::min(a0.W - 1, (int)std::floor(mxx) + apron + 1);
+        y0 = std::max(0, (int)std::floor(mny) - apron);
+        y1 = std::min(a0.H - 1, (int)std::floor(mxy) + apron + 1);
+    }
+    // (taps that mirror at an image edge stay inside: the rectangle starts AT that edge and is at least 2 aprons wide)
+    x1 = std::min(a0.W - 1, std::max(x1, x0 + 2 * apron));
+    y1 = std::min(a0.H - 1, std::max(y1, y0 + 2 * apron));
+    const long long area = (long long)(x1 - x0 + 1) * (y1 - y0 + 1);
+    if (2 * area > (long long)a0.W * a0.H) return COREG_OK;  // not worth a strided copy
+    *out = {x0, y0, x1 - x0 + 1, y1 - y0 + 1};
+    return COREG_OK;
+}
+
+// rows y0 .. of a host image, columns x0 .., packed into pinned staging and sent to `dev` (contiguous, pitch = crop width)
+static int staged_upload_rect(coreg_handle* h, void* dev, const void* host, size_t elem, int W, const CropRect& c) {
+    const char* src = (const char*)host + ((size_t)c.y0 * W + c.x0) * elem;
+    if (c.w == W) return staged_upload(h, dev, src, (size_t)c.w * c.h * elem);  // whole rows: one contiguous range
+    const int k = h->pin_img_next;
+    h->pin_img_next ^= 1;
+    if (!h->ev_img[k]) HIPCHK(hipEventCreateWithFlags(&h->ev_img[k], hipEventDisableTiming));
+    else HIPCHK(hipEventSynchronize(h->ev_img[k]));
+    const size_t bytes = (size_t)c.w * c.h * elem;
+    HIPCHK(h->pin_img[k].reserve(bytes));
+    parallel_copy_rows(h->pin_img[k].p, src, (size_t)c.h, (size_t)c.w * elem, (size_t)W * elem);
+    HIPCHK(hipMemcpyAsync(dev, h->pin_img[k].p, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->ev_img[k], h->stream));
+    return COREG_OK;
+}
+
 // the reference image's pixels: float64 from the caller (tested for float32-exactness on the GPU), or the float32
 // pixels a BITPIX=-32 FITS file holds (half the PCIe bytes; the reference's float64 cast of them is exact)
 // (src_on_device: the pixels are read where they are, by the resample kernel on the handle's stream -- no copy)
 static int upload_reference_source(coreg_handle* h, const void* large, size_t n, bool src_f32, bool* f32,
-                                   bool src_on_device, const void** img_dev) {
-    if (src_on_device) {
+                                   SrcKind kind, const void** img_dev, int W = 0, const CropRect* crop = nullptr) {
+    if (kind == SRC_DEVICE) {
         *f32 = src_f32;
         *img_dev = large;
         return COREG_OK;
     }
+    if (crop && kind == SRC_HOST && (size_t)crop->w * crop->h < n) {
+        // only the rectangle the resample can touch crosses PCIe
+        const size_t nc = (size_t)crop->w * crop->h;
+        if (src_f32) {
+            HIPCHK(h->tmp_img.reserve(nc * sizeof(float)));
+            RETCHK(staged_upload_rect(h, h->tmp_img.p, large, sizeof(float), W, *crop));
+            *f32 = true;
+        } else {
+            HIPCHK(h->up_f64.reserve(nc * sizeof(double)));
+            RETCHK(staged_upload_rect(h, h->up_f64.p, large, sizeof(double), W, *crop));
+            RETCHK(upload_image(h, h->up_f64.as<double>(), nc, h->tmp_img, f32, SRC_DEVICE));
+        }
+        *img_dev = h->tmp_img.p;
+        return COREG_OK;
+    }
     if (!src_f32) {
-        RETCHK(upload_image(h, (const double*)large, n, h->tmp_img, f32));
+        RETCHK(upload_image(h, (const double*)large, n, h->tmp_img, f32, kind));
     } else {
         HIPCHK(h->tmp_img.reserve(n * sizeof(float)));
-        RETCHK(staged_upload(h, h->tmp_img.p, large, n * sizeof(float)));
+        if (kind == SRC_PINNED)
+            HIPCHK(hipMemcpyAsync(h->tmp_img.p, large, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        else
+            RETCHK(staged_upload(h, h->tmp_img.p, large, n * sizeof(float)));
         *f32 = true;
     }
     *img_dev = h->tmp_img.p;
@@ -1412,24 +1565,27 @@ static int upload_reference_source(coreg_handle* h, const void* large, size_t n,
 
 static int prepare_carrington(coreg_handle* h, const void* large, bool src_f32, int32_t ny, int32_t nx,
                               const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r, int order,
-                              bool src_on_device = false) {
+                              SrcKind kind = SRC_HOST) {
     if (!h) return COREG_EINVAL;
     if (!large || !hdr || !grid || ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
     RETCHK(check_order(h, order));
     RETCHK(bind_device(h));
-    bool f32;
-    const void* img_dev = nullptr;
-    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, src_f32, &f32, src_on_device, &img_dev));
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
     RETCHK(upload_carr_tables(h, *grid, *hdr, &a.carr));
     set_carr_common(&a.carr, carr_common(*hdr, solar_r));
     carr_origin(*hdr, &a.x0, &a.y0);
-    a.img = img_dev;
     a.W = nx;
     a.H = ny;
     a.gw = grid->n_lon;
     a.gh = grid->n_lat;
+    CropRect crop = {0, 0, nx, ny};
+    if (kind == SRC_HOST) RETCHK(reference_crop(h, MODE_TRANSLATE, a, order, &crop));
+    bool f32;
+    const void* img_dev = nullptr;
+    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, src_f32, &f32, kind, &img_dev, nx, &crop));
+    a.img = img_dev;
+    if (crop.w != nx || crop.h != ny) a.crop = {crop.x0, crop.y0, crop.w};
     HIPCHK(h->ref.reserve((size_t)a.gw * a.gh * sizeof(double)));
     a.out = h->ref.p;
     RETCHK(dispatch_resample(h, MODE_TRANSLATE, order, f32, false, a, 0));
@@ -1454,7 +1610,7 @@ int coreg_prepare_reference_carrington_f32(coreg_handle* h, const float* large, 
 
 static int prepare_helioprojective(coreg_handle* h, const void* large, bool src_f32, int32_t ny, int32_t nx,
                                    const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order,
-                                   bool src_on_device = false) {
+                                   SrcKind kind = SRC_HOST) {
     if (!h) return COREG_EINVAL;
     if (!large || !hdr_large || !hdr_small || ny < 1 || nx < 1)
         return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
@@ -1463,17 +1619,20 @@ static int prepare_helioprojective(coreg_handle* h, const void* large, bool src_
         return fail(h, COREG_ENOTIMPL, "prepare_reference_helioprojective: TAN headers only");
     RETCHK(check_order(h, order));
     RETCHK(bind_device(h));
-    bool f32;
-    const void* img_dev = nullptr;
-    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, src_f32, &f32, src_on_device, &img_dev));
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
     homography(*hdr_small, *hdr_large, a.hom.h);  // alignment.py:993: pixels of hdr_cut -> pixels of hdr_large
-    a.img = img_dev;
     a.W = nx;
     a.H = ny;
     a.gw = hdr_small->naxis1;
     a.gh = hdr_small->naxis2;
+    CropRect crop = {0, 0, nx, ny};
+    if (kind == SRC_HOST) RETCHK(reference_crop(h, MODE_HOMOGRAPHY, a, order, &crop));
+    bool f32;
+    const void* img_dev = nullptr;
+    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, src_f32, &f32, kind, &img_dev, nx, &crop));
+    a.img = img_dev;
+    if (crop.w != nx || crop.h != ny) a.crop = {crop.x0, crop.y0, crop.w};
     HIPCHK(h->ref.reserve((size_t)a.gw * a.gh * sizeof(float)));
     a.out = h->ref.p;
     RETCHK(dispatch_resample(h, MODE_HOMOGRAPHY, order, f32, true, a, 0));
@@ -1499,14 +1658,14 @@ int coreg_prepare_reference_carrington_from_device(coreg_handle* h, const void* 
                                                    int32_t nx, const coreg_wcs2d* hdr_large,
                                                    const coreg_carr_grid* grid, double solar_r, int order) {
     if (h && dtype != COREG_F32 && dtype != COREG_F64) return fail(h, COREG_EINVAL, "prepare_reference: bad dtype");
-    return prepare_carrington(h, dev_large, dtype == COREG_F32, ny, nx, hdr_large, grid, solar_r, order, true);
+    return prepare_carrington(h, dev_large, dtype == COREG_F32, ny, nx, hdr_large, grid, solar_r, order, SRC_DEVICE);
 }
 
 int coreg_prepare_reference_helioprojective_from_device(coreg_handle* h, const void* dev_large, int dtype, int32_t ny,
                                                         int32_t nx, const coreg_wcs2d* hdr_large,
                                                         const coreg_wcs2d* hdr_small, int order) {
     if (h && dtype != COREG_F32 && dtype != COREG_F64) return fail(h, COREG_EINVAL, "prepare_reference: bad dtype");
-    return prepare_helioprojective(h, dev_large, dtype == COREG_F32, ny, nx, hdr_large, hdr_small, order, true);
+    return prepare_helioprojective(h, dev_large, dtype == COREG_F32, ny, nx, hdr_large, hdr_small, order, SRC_DEVICE);
 }
 
 int coreg_get_reference_on_grid(coreg_handle* h, void* out, int dtype) {
@@ -1599,7 +1758,7 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
     const long long n_out = lag_end - lag_begin;
     double* out_dev = nullptr;
     RETCHK(begin_sweep(h, n_out, corr_out, out_on_device, &out_dev));
-    if (n_out == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+    if (n_out == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);  // (nothing to fill)
 
     CarrDev cd;
     std::memset(&cd, 0, sizeof(cd));
@@ -1704,8 +1863,11 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
         L.f1hi = (double)(h->sH - 1) - y0min;
         launches.push_back(L);
     }
-    if (launches.empty()) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
-    RETCHK(upload_plan(h, params, outidx));
+    if (launches.empty()) {
+        RETCHK(fill_nan(h, out_dev, n_out));
+        return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+    }
+    RETCHK(upload_plan(h, params, outidx, out_dev, n_out));
     RETCHK(prepare_sharded(h, outidx.size(), n_out, lag_begin));
     for (const Launch& L : launches) {
         set_carr_common(&cd, L.cc);
@@ -1852,8 +2014,11 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
         outidx.insert(outidx.end(), slots.outidx.begin(), slots.outidx.end());
         launches.push_back(L);
     }
-    if (launches.empty()) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
-    RETCHK(upload_plan(h, params, outidx));
+    if (launches.empty()) {
+        RETCHK(fill_nan(h, out_dev, n_out));
+        return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+    }
+    RETCHK(upload_plan(h, params, outidx, out_dev, n_out));
     RETCHK(prepare_sharded(h, outidx.size(), n_out, lag_begin));
 
     PrecomputeArgs pa;
@@ -1906,7 +2071,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     const long long n_out = lag_end - lag_begin;
     double* out_dev = nullptr;
     RETCHK(begin_sweep(h, n_out, corr_out, out_on_device, &out_dev));
-    if (n_out == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+    if (n_out == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);  // (nothing to fill)
     if (hdr_small->proj == COREG_PROJ_CAR)
         return sweep_car(h, hdr_target, hdr_small, lags, d, order, method, cdelt_semantics, lag_begin, lag_end, corr_out,
                          out_on_device, out_dev);
@@ -2029,7 +2194,10 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
         outidx.insert(outidx.end(), slots.outidx.begin(), slots.outidx.end());
         n_batches += slots.n_batches;
     }
-    if (n_batches == 0) return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+    if (n_batches == 0) {
+        RETCHK(fill_nan(h, out_dev, n_out));
+        return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
+    }
     const size_t ns = outidx.size();
     std::vector<double> params(9 * ns);
     double eps_max = 0.0;  // largest |h6 x + h7 y| over the target grid and all lags
@@ -2040,7 +2208,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     }
     // 1/(1 + eps) = 1 - eps + eps^2 is exact to float64 below ~4e-6 (eps^3 < 1e-16); wider fields divide exactly
     const int sweep_mode = (h->opt_h_series && eps_max < 4.0e-6) ? MODE_HOMOGRAPHY_SERIES : MODE_HOMOGRAPHY;
-    RETCHK(upload_plan(h, params, outidx));
+    RETCHK(upload_plan(h, params, outidx, out_dev, n_out));
     RETCHK(prepare_sharded(h, outidx.size(), n_out, lag_begin));
 
     PrecomputeArgs pa;
@@ -2237,3 +2405,5 @@ int coreg_carrington_origin(const coreg_wcs2d* hdr, double* x0, double* y0) {
 }
 
 }  // extern "C"
+
+#include "multi.hpp"

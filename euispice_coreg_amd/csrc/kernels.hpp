@@ -283,18 +283,26 @@ __device__ __forceinline__ int mirror_far(int i, int n) {  // scipy NI_EXTEND_MI
     i = i % p;
     return i > n - 1 ? p - i : i;
 }
+// Source images may be CROPS of the image the header describes (the once-only reference preparation uploads only the
+// rectangle the target grid can touch): `img` then holds columns x0 .. and rows y0 .. of the W x H image with row pitch
+// `pitch`; bounds rule and mirroring use the full W x H, the crop is guaranteed to hold every tap of an in-bounds sample.
+struct Crop {
+    int x0, y0, pitch;  // pitch <= 0: the whole image (pitch = W)
+};
 template <typename TS>
 __device__ inline double spline_global_rt(const TS* __restrict__ img, int W, int H, double nx, double ny, int order,
-                                          bool& inb) {
+                                          bool& inb, Crop cr = {0, 0, 0}) {
     inb = (nx >= 0.0) & (nx <= (double)(W - 1)) & (ny >= 0.0) & (ny <= (double)(H - 1));
-    const double cx = inb ? nx : 0.0, cy = inb ? ny : 0.0;
+    const int pitch = cr.pitch > 0 ? cr.pitch : W;
+    const double cx = inb ? nx : (double)cr.x0, cy = inb ? ny : (double)cr.y0;
     int sx, sy;
     double wx[6], wy[6];
     spline_weights_rt(order, cx, sx, wx);
     spline_weights_rt(order, cy, sy, wy);
+    if (!inb) return 0.0;  // (discarded by every caller; no tap is read)
     double acc = 0.0;
     for (int a = 0; a <= order; ++a) {
-        const TS* __restrict__ rowp = img + (size_t)mirror_far(sy + a, H) * W;
+        const TS* __restrict__ rowp = img + (size_t)(mirror_far(sy + a, H) - cr.y0) * pitch - cr.x0;
         double row = 0.0;
         for (int b = 0; b <= order; ++b) row = fma((double)rowp[mirror_far(sx + b, W)], wx[b], row);
         acc = fma(row, wy[a], acc);
@@ -346,10 +354,12 @@ __device__ inline double spline_lds_rt(unsigned win, int pitch, int ox, int oy, 
 // inb = the whole-sample bounds rule (c < 0 or c > n-1 or NaN -> cval).
 template <int ORDER, typename TS>
 __device__ __forceinline__ double spline_global(const TS* __restrict__ img, int W, int H, double nx, double ny,
-                                                bool& inb) {
+                                                bool& inb, Crop cr = {0, 0, 0}) {
     constexpr int N = Spline<ORDER>::N;
     inb = (nx >= 0.0) & (nx <= (double)(W - 1)) & (ny >= 0.0) & (ny <= (double)(H - 1));
-    const double cx = inb ? nx : 0.0, cy = inb ? ny : 0.0;
+    const int pitch = cr.pitch > 0 ? cr.pitch : W;
+    // (an out-of-bounds sample is discarded by every caller; it gathers from the crop's first pixels)
+    const double cx = inb ? nx : (double)(cr.x0 + (cr.pitch > 0)), cy = inb ? ny : (double)(cr.y0 + (cr.pitch > 0));
     int sx, sy;
     double wx[N], wy[N];
     Spline<ORDER>::eval(cx, sx, wx);
@@ -357,8 +367,8 @@ __device__ __forceinline__ double spline_global(const TS* __restrict__ img, int 
     int ix[N], iy[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        ix[k] = mirror_idx(sx + k, W);
-        iy[k] = mirror_idx(sy + k, H) * W;
+        ix[k] = mirror_idx(sx + k, W) - cr.x0;
+        iy[k] = (mirror_idx(sy + k, H) - cr.y0) * pitch;
     }
     double acc = 0.0;
 #pragma unroll
@@ -466,6 +476,21 @@ __global__ void k_fill(double* p, long long n, double v) {
     if (i < n) p[i] = v;
 }
 
+// Prologue of a sweep, one launch: the lag parameters and output indices the host has just written to page-locked
+// memory are read over PCIe by this kernel (a few tens of KB; two DMA-engine copies in their place cost ~50 us of
+// queue switches each between the kernels of a sweep) and the output is NaN-initialised (quirk Q9).
+__global__ void __launch_bounds__(256) k_prologue(const double* __restrict__ src, double* __restrict__ dst_params,
+                                                  long long n_params, long long* __restrict__ dst_outidx,
+                                                  long long n_outidx, double* __restrict__ out, long long n_out) {
+    const long long stride = (long long)gridDim.x * 256;
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (long long i = i0; i < n_params; i += stride) dst_params[i] = src[i];
+    const long long* __restrict__ src_idx = (const long long*)(src + n_params);
+    for (long long i = i0; i < n_outidx; i += stride) dst_outidx[i] = src_idx[i];
+    const double nan = __builtin_nan("");
+    for (long long i = i0; i < n_out; i += stride) out[i] = nan;
+}
+
 // ---- once-only resample (reference preparation, alignment.py:646-651; single-header resample) ----------------------
 struct ResampleArgs {
     const void* img;  // small / large image, TS
@@ -476,13 +501,14 @@ struct ResampleArgs {
     H9 hom;
     void* out;
     int order_rt;  // ORDER == ORDER_RT: the spline order
+    Crop crop;     // `img` holds this crop of the W x H image
+    double* bbox;  // k_resample_bbox: [gridDim.x][4] partial (min x, max x, min y, max y) of the in-bounds coordinates
 };
-template <int MODE, int ORDER, typename TS, typename TO>
-__global__ void __launch_bounds__(256) k_resample(const ResampleArgs a) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)a.gw * a.gh) return;
+// the 0-based source-pixel coordinate of output grid point idx -- ONE function for the resample and for the bounding box
+// that decides which pixels it can touch (bit-identical coordinates in both)
+template <int MODE>
+__device__ __forceinline__ bool resample_coord(const ResampleArgs& a, long long idx, double& nx, double& ny) {
     const int i = (int)(idx % a.gw), j = (int)(idx / a.gw);
-    double nx, ny;
     bool ok = true;
     if (MODE == MODE_TRANSLATE) {
         double t0, t1;
@@ -492,12 +518,57 @@ __global__ void __launch_bounds__(256) k_resample(const ResampleArgs a) {
     } else {
         apply_h(a.hom, (double)i, (double)j, nx, ny);
     }
-    bool inb;
     if (!ok) nx = __builtin_nan("");
-    double v;
-    if constexpr (ORDER == ORDER_RT) v = spline_global_rt<TS>((const TS*)a.img, a.W, a.H, nx, ny, a.order_rt, inb);
-    else v = spline_global<ORDER, TS>((const TS*)a.img, a.W, a.H, nx, ny, inb);
-    if (!inb) v = __builtin_nan("");
+    return (nx >= 0.0) & (nx <= (double)(a.W - 1)) & (ny >= 0.0) & (ny <= (double)(a.H - 1));
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) k_resample_bbox(const ResampleArgs a) {
+    __shared__ double red[4][4];
+    const double inf = __builtin_inf();
+    double mnx = inf, mxx = -inf, mny = inf, mxy = -inf;
+    const long long n = (long long)a.gw * a.gh;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
+        double nx, ny;
+        if (resample_coord<MODE>(a, idx, nx, ny)) {
+            mnx = fmin(mnx, nx);
+            mxx = fmax(mxx, nx);
+            mny = fmin(mny, ny);
+            mxy = fmax(mxy, ny);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = fmin(mnx, __shfl_xor(mnx, o));
+        mxx = fmax(mxx, __shfl_xor(mxx, o));
+        mny = fmin(mny, __shfl_xor(mny, o));
+        mxy = fmax(mxy, __shfl_xor(mxy, o));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wave][0] = mnx;
+        red[wave][1] = mxx;
+        red[wave][2] = mny;
+        red[wave][3] = mxy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* o = a.bbox + (size_t)blockIdx.x * 4;
+        o[0] = fmin(fmin(red[0][0], red[1][0]), fmin(red[2][0], red[3][0]));
+        o[1] = fmax(fmax(red[0][1], red[1][1]), fmax(red[2][1], red[3][1]));
+        o[2] = fmin(fmin(red[0][2], red[1][2]), fmin(red[2][2], red[3][2]));
+        o[3] = fmax(fmax(red[0][3], red[1][3]), fmax(red[2][3], red[3][3]));
+    }
+}
+template <int MODE, int ORDER, typename TS, typename TO>
+__global__ void __launch_bounds__(256) k_resample(const ResampleArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.gw * a.gh) return;
+    double nx, ny;
+    bool inb = resample_coord<MODE>(a, idx, nx, ny);
+    double v = __builtin_nan("");
+    if (inb) {  // (an out-of-bounds point reads nothing: the source may be a crop that only holds what can be touched)
+        if constexpr (ORDER == ORDER_RT) v = spline_global_rt<TS>((const TS*)a.img, a.W, a.H, nx, ny, a.order_rt, inb, a.crop);
+        else v = spline_global<ORDER, TS>((const TS*)a.img, a.W, a.H, nx, ny, inb, a.crop);
+    }
     ((TO*)a.out)[idx] = (TO)v;
 }
 

@@ -14,12 +14,14 @@ surface.  Differences, all deliberate and listed in DESIGN.md:
     `cdelt_semantics="reference"`.
   * inputs may be FITS paths or (data, header) pairs; astropy is optional.
   * with torch.distributed initialised (one process per GPU) the lag grid is sharded and all-gathered
-    (euispice_coreg_amd/parallel.py).
+    (euispice_coreg_amd/parallel.py); without it, `parallelism=True` drives every visible GPU from this one process
+    (include/coreg_hip.h: coreg_multi) -- the unchanged user script uses the whole node, as it does with the reference.
 There is no CPU fallback: without the HIP library / a GPU the sweep raises.
 """
 from __future__ import annotations
 
 import copy
+import os
 import warnings
 
 import numpy as np
@@ -289,7 +291,18 @@ class Alignment:
             if parallel.world_info()[1] > 1:
                 import torch
                 device = torch.cuda.current_device()
-        h = _lib.shared_handle(device, self._handle_slot)  # long-lived: buffers are re-used by the next Alignment
+        # A plain script (no torch.distributed) that asks for `parallelism=True` gets what the reference gives it: the whole
+        # machine (alignment.py:692-744 fans out over counts_cpu_max processes).  Here: every visible GPU, driven from
+        # this one process by the library itself (coreg_multi: a host thread + context per device, lag-plane blocks, one
+        # RCCL all-gather).  An explicit `device=`, a jitter session spreading images over GPUs, one visible GPU or
+        # COREG_SINGLE_DEVICE=1 keep the single-device context.
+        use_all = (self.parallelism and world == 1 and self.device is None and self.shard_lags
+                   and parallel.world_info()[1] == 1 and os.environ.get("COREG_SINGLE_DEVICE", "0") != "1"
+                   and _lib.device_count() > 1)
+        if use_all:
+            h = _lib.shared_multi_handle()
+        else:
+            h = _lib.shared_handle(device, self._handle_slot)  # long-lived: buffers are re-used by the next Alignment
         # with several ranks over RCCL each image crosses PCIe once in all -- 1/N per rank -- and is assembled on every
         # GPU by an all-gather over xGMI (parallel.replicate_image); one rank / gloo: the whole image from this host
         spread = world > 1
@@ -397,4 +410,6 @@ class Alignment:
                 part = run()
             out[..., kk] = np.asarray(part).reshape(lags.shape)
         self.last_stats = h.last_stats()
+        if use_all:
+            self.last_sharding = h.last_mode
         return out

@@ -232,6 +232,9 @@ int coreg_last_stats(coreg_handle* h, coreg_stats* out);
  *   "h_series"     1 (default) helioprojective maps with |projective term| < 4e-6 invert 1 + eps as 1 - eps + eps^2
  *                  (exact to float64 there) instead of dividing; 0 always divide
  *   "patch_w"      0 (default, auto) or the maximum width, in CRVAL1 lags, of a workgroup's lag patch
+ *   "crop_reference" 1 (default) coreg_prepare_reference_* upload only the rectangle of the reference image the target
+ *                  grid can touch (bounding box of the sample coordinates, computed on the GPU; identical results),
+ *                  0 the whole image
  * Returns COREG_EINVAL for unknown names. */
 int coreg_set_option(coreg_handle* h, const char* name, int64_t value);
 
@@ -272,6 +275,50 @@ int coreg_car_map(const coreg_wcs2d* from, const coreg_wcs2d* to, int64_t n, con
 int coreg_car_tile_margin(const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_shifted, int32_t tile_w,
                           double tile_abs_lat_rad, double* margin_px);
 
+
+/* ---- All GPUs of the node from ONE process ------------------------------------------------------------------------
+ * The reference's `Alignment(..., parallelism=True, counts_cpu_max=N)` uses the whole machine from a plain
+ * `python script.py`: its lag loop is fanned out over a process pool (hdrshift/alignment.py:692-744, README.md:47-87).
+ * A coreg_multi is the same from one process on this library: one host thread + one coreg_handle (own stream and
+ * buffers) per GPU, full image replicas (one shared page-locked staging buffer, every device copies from it over its
+ * own PCIe link), the lag set cut exactly as euispice_coreg_amd/parallel.py cuts it for the one-process-per-GPU form --
+ * blocks of the (CRVAL1, CRVAL2) plane; contiguous slices of the raveled index when the plane is smaller than the
+ * number of GPUs (alignment.py:677-687); shares of the GRID below 128 lag-points per GPU -- per-device sweeps with
+ * device outputs and ONE collective over xGMI: an RCCL all-gather of the per-lag coefficients (all-reduce of the six
+ * sums per lag in the grid-share mode), one communicator per device from ncclCommInitAll, all devices' calls between
+ * ncclGroupStart / ncclGroupEnd on the handles' own streams; device 0 hands the map to the host.  RCCL is looked up at
+ * run time (dlopen; a copy already loaded in the process, e.g. PyTorch's, first).  Without it -- or when
+ * COREG_VIRTUAL_DEVICES=k maps k logical devices onto the GPUs present (tests of this path on a one-GPU box; RCCL
+ * refuses two ranks on one device) -- every device copies its block to the host instead.
+ * n_devices 0 = all visible (or COREG_VIRTUAL_DEVICES); device_ids NULL = 0 .. n-1.  The calls mirror the single-device
+ * ones (dtype = COREG_F32 / COREG_F64 of the host pixels); sweeps return the WHOLE map, C order, in host memory. */
+typedef struct coreg_multi coreg_multi;
+int coreg_device_count(void); /* visible GPUs, or COREG_VIRTUAL_DEVICES when set */
+int coreg_multi_create(coreg_multi** m, int n_devices, const int* device_ids);
+void coreg_multi_destroy(coreg_multi* m);
+int coreg_multi_size(const coreg_multi* m);
+coreg_handle* coreg_multi_handle(coreg_multi* m, int k); /* device k's context (options, single-device utilities) */
+const char* coreg_multi_last_error(const coreg_multi* m);
+const char* coreg_multi_collective(const coreg_multi* m); /* "rccl", "host-copy" or "none" (what sweeps use / used) */
+int coreg_multi_last_mode(const coreg_multi* m);          /* partition of the last sweep: 0 none, 1 blocks, 2 slices, 3 points */
+int coreg_multi_set_option(coreg_multi* m, const char* name, int64_t value);
+int coreg_multi_set_small(coreg_multi* m, const void* img, int dtype, int32_t ny, int32_t nx);
+int coreg_multi_threshold_small(coreg_multi* m, int has_min, double vmin, int has_max, double vmax, long long* n_finite);
+int coreg_multi_set_reference_on_grid(coreg_multi* m, const void* ref, int dtype, int32_t gy, int32_t gx);
+int coreg_multi_prepare_reference_carrington(coreg_multi* m, const void* large, int dtype, int32_t ny, int32_t nx,
+                                             const coreg_wcs2d* hdr_large, const coreg_carr_grid* grid, double solar_r,
+                                             int order);
+int coreg_multi_prepare_reference_helioprojective(coreg_multi* m, const void* large, int dtype, int32_t ny, int32_t nx,
+                                                  const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order);
+int coreg_multi_sweep_carrington(coreg_multi* m, const coreg_wcs2d* hdr_small, const coreg_carr_grid* grid, double solar_r,
+                                 const coreg_lags* lags, int order, int method, int cdelt_semantics, double* corr_out);
+int coreg_multi_sweep_helioprojective(coreg_multi* m, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_small,
+                                      const coreg_lags* lags, int order, int method, int cdelt_semantics, double* corr_out);
+int coreg_multi_last_stats(coreg_multi* m, int k, coreg_stats* out);
+/* The partition a sweep over (n_crval1, n_crval2, n_inner = n_cdelt1 n_cdelt2 n_crota) lag-points gets on `world` GPUs
+ * (host-only; checked against euispice_coreg_amd/parallel.py): mode as coreg_multi_last_mode, (g1, g2) the block grid. */
+int coreg_multi_plan(int32_t n_crval1, int32_t n_crval2, int64_t n_inner, int32_t world, int32_t* mode, int32_t* g1,
+                     int32_t* g2);
 
 #ifdef __cplusplus
 }

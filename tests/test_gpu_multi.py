@@ -1,0 +1,144 @@
+"""GPU tests of the in-library multi-GPU driver (include/coreg_hip.h: coreg_multi; euispice_coreg_amd/csrc/multi.hpp): every
+GPU of the node from ONE process, the way the reference's `parallelism=True` uses the whole machine from a plain script
+(hdrshift/alignment.py:692-744).  The GPU box has one GPU: COREG_VIRTUAL_DEVICES maps several logical devices onto it
+(own host thread, library context and stream each), the blocks then reach the host by one copy per device instead of
+the RCCL all-gather (RCCL refuses two ranks on one device); the RCCL calls themselves run with a one-rank group."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+SHAPE = (72, 64)
+
+
+def _single_carr(h, small, hs, large, hl, lags, **kw):
+    return H.gpu_carrington(h, small, hs, large, hl, lags, SHAPE, **kw).ravel()
+
+
+def _multi_carr(m, small, hs, large, hl, lags, order=2, method=0):
+    from euispice_coreg_amd import _lib
+    grid = _lib.Grid(H.CARR_LON, H.CARR_LAT, SHAPE)
+    m.set_small(small)
+    m.prepare_reference_carrington(large, hl, grid, 1.004, order)
+    return m.sweep_carrington(hs, grid, 1.004, _lib.LagSet(*lags), order=order, method=method)
+
+
+@pytest.mark.parametrize("n_virtual", [2, 3, 4])
+def test_multi_blocks_slices_points_equal_single_device(gpu_handle, monkeypatch, n_virtual):
+    from euispice_coreg_amd import _lib
+    monkeypatch.setenv("COREG_VIRTUAL_DEVICES", str(n_virtual))
+    small, hs, large, hl, _ = H.scene()
+    assert _lib.device_count() == n_virtual
+    cases = {
+        "blocks": (17.0 + 1.0 * (np.arange(24) - 12), -9.0 + 1.0 * (np.arange(23) - 11), None, None, [0.0, 0.3]),
+        "slices": ([17.0], [-9.0], [0.0, 0.002], [-0.001, 0.0, 0.001], np.linspace(-1.0, 1.0, 90)),
+        "points": (17.0 + 2.0 * (np.arange(5) - 2), -9.0 + 2.0 * (np.arange(4) - 2), None, None, None),
+    }
+    with _lib.MultiHandle() as m:
+        assert m.size == n_virtual and m.collective == "host-copy"
+        for mode, lags in cases.items():
+            got = _multi_carr(m, small, hs, large, hl, lags)
+            assert m.last_mode == mode, (mode, m.last_mode)
+            want = _single_carr(gpu_handle, small, hs, large, hl, lags)
+            assert np.array_equal(np.isnan(got), np.isnan(want)), mode
+            # (different lag sets cull the grid differently: agreement to rounding, as for slices of one handle)
+            assert np.nanmax(np.abs(got - want)) <= 1e-12, (mode, n_virtual)
+            assert np.nanargmax(got) == np.nanargmax(want)
+            st = m.last_stats()
+            assert st["n_devices"] == n_virtual and st["lag_sharding"] == mode
+            assert len(st["per_device_sweep_kernel_ms"]) == n_virtual
+        # method 'residus' through the grid-share mode (sums from different devices add up about the same pivots)
+        got = _multi_carr(m, small, hs, large, hl, cases["points"], method=1)
+        gpu_handle.set_small(small)
+        want = H.gpu_carrington(gpu_handle, small, hs, large, hl, cases["points"], SHAPE).ravel() * 0  # shape only
+        grid = _lib.Grid(H.CARR_LON, H.CARR_LAT, SHAPE)
+        want = gpu_handle.sweep_carrington(hs, grid, 1.004, _lib.LagSet(*cases["points"]), method=1)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        if np.isfinite(want).any():
+            assert np.nanmax(np.abs(got - want)) <= 1e-10
+
+
+def test_multi_helioprojective_with_the_zero_lag(gpu_handle, monkeypatch):
+    """Sub-map semantics over three logical devices, lag axes through 0: the noise-decided zero lag lands in ONE
+    device's block and carries its border correction there."""
+    from euispice_coreg_amd import _lib
+    monkeypatch.setenv("COREG_VIRTUAL_DEVICES", "3")
+    small, hs, large, hl, _ = H.scene()
+    lags = (np.arange(-8.0, 20.0, 1.0), np.arange(-14.0, 3.0, 1.0), None, None, None)  # 28 x 17 = 476 lag-points
+    want = H.gpu_helio(gpu_handle, small, hs, large, hl, lags).ravel()
+    with _lib.MultiHandle() as m:
+        m.set_small(small)
+        m.prepare_reference_helioprojective(large, hl, hs, 2)
+        got = m.sweep_helioprojective(hs, hs, _lib.LagSet(*lags))
+        assert m.last_mode == "blocks"
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) <= 1e-12
+    oracle = H.oracle_helio(small, hs, large, hl, ([0.0, 17.0], [-9.0, 0.0], None, None, None)).ravel()
+    full = got.reshape(28, 17)
+    assert abs(full[8, 14] - oracle[1]) <= 1e-7 and abs(full[25, 5] - oracle[2]) <= 1e-7  # (0, 0) and (17, -9)
+
+
+def test_multi_rccl_calls_run_with_a_one_rank_group(gpu_handle, monkeypatch):
+    """The RCCL side of the driver on the one GPU there is: dlopen, ncclCommInitAll, ncclGroupStart / ncclAllGather /
+    ncclGroupEnd on the handle's stream, device-0 hand-over -- a one-rank group (the all-gather is then a copy)."""
+    from euispice_coreg_amd import _lib
+    monkeypatch.delenv("COREG_VIRTUAL_DEVICES", raising=False)
+    monkeypatch.setenv("COREG_MULTI_FORCE_RCCL", "1")
+    small, hs, large, hl, _ = H.scene()
+    lags = (17.0 + 1.0 * (np.arange(12) - 6), -9.0 + 1.0 * (np.arange(12) - 6), None, None, None)
+    with _lib.MultiHandle(device_ids=[0]) as m:
+        if m.collective != "rccl":
+            pytest.skip("no RCCL runtime could be loaded in this process")
+        got = _multi_carr(m, small, hs, large, hl, lags)
+        assert m.last_mode == "slices" and m.collective == "rccl"
+    want = _single_carr(gpu_handle, small, hs, large, hl, lags)
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_alignment_uses_every_visible_gpu_from_a_plain_script(tmp_path, monkeypatch):
+    """`Alignment(..., parallelism=True).align_using_carrington()` with no torch.distributed: the library drives every
+    (here: virtual) GPU itself; same map as the single-device context, and an explicit device= keeps the latter."""
+    from euispice_coreg_amd import _lib
+    from euispice_coreg_amd.hdrshift import Alignment
+    small, hs, large, hl, truth = H.scene()
+    lag1, lag2 = 17.0 + 1.0 * (np.arange(20) - 10), -9.0 + 1.0 * (np.arange(20) - 10)
+
+    def run(**kw):
+        A = Alignment((large, hl), (small, hs), lag_crval1=lag1, lag_crval2=lag2, lag_cdelt1=None, lag_cdelt2=None,
+                      lag_crota=[0.0], parallelism=True, **kw)
+        corr = A.align_using_carrington(lonlims=H.CARR_LON, latlims=H.CARR_LAT, shape=SHAPE, return_type="corr")
+        return corr, A
+
+    single, A1 = run(device=0)
+    assert "n_devices" not in A1.last_stats
+    monkeypatch.setenv("COREG_VIRTUAL_DEVICES", "2")
+    _lib._close_shared()
+    try:
+        multi, A2 = run()
+        assert A2.last_stats["n_devices"] == 2 and A2.last_sharding == "blocks"
+        assert np.nanmax(np.abs(multi - single)) <= 1e-12 and np.nanargmax(multi) == np.nanargmax(single)
+        # helioprojective frame, FITS in, through the same driver
+        B = Alignment((large, hl), (small, hs), lag_crval1=lag1, lag_crval2=lag2, lag_cdelt1=None, lag_cdelt2=None,
+                      lag_crota=None, parallelism=True)
+        helio = B.align_using_helioprojective(return_type="corr")
+        assert B.last_stats["n_devices"] == 2
+        want = H.oracle_helio(small, hs, large, hl, (lag1[8:12], lag2[8:12], None, None, None))
+        assert np.nanmax(np.abs(helio[8:12, 8:12] - want)) <= 1e-7
+    finally:
+        _lib._close_shared()
+
+
+def test_bench_launch_threads_two_virtual_devices():
+    """`python bench.py --gpus 2 --launch threads`: one process, the library's own multi-GPU driver (two logical devices
+    on the one GPU of the box): the headline map with the injected shift as argmax, equal to device 0 sweeping alone."""
+    from tests.test_api_cpu import _run_bench
+    out = _run_bench({"COREG_VIRTUAL_DEVICES": "2"}, "--gpus", "2", "--launch", "threads", "--steps", "3", "--warmup",
+                     "1", timeout=900)
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["value"] > 0
+    assert out["config"]["launch"] == "threads" and out["config"]["lag_sharding"] == "blocks"
+    assert out["argmax_lag_arcsec"] == out["injected_shift_arcsec"][:2] == [17.0, -9.0]
+    assert out["map_vs_single_gpu"]["max_abs_diff"] <= 1e-12 and out["map_vs_single_gpu"]["same_argmax"]
+    assert len(out["per_rank"]) == 2 and all(r["kernel_ms"] > 0 for r in out["per_rank"])
+    assert out["pcie_inclusive"]["identical_to_resident_map"]

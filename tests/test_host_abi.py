@@ -272,3 +272,16 @@ def test_car_tile_margin_bounds_the_map(lib, tile_w):
                 n_checked += 1
     print(f"tile_w={tile_w}: {n_checked} tiles checked, {n_inf} with an infinite allowance, worst excess / allowance = {worst:.3f}")
     assert n_checked > 60 and n_inf > 0 and worst > 0.01  # the bound is exercised, not vacuous
+
+
+def test_multi_plan_matches_the_python_partition(lib):
+    """The in-library multi-GPU driver (csrc/multi.hpp) and the one-process-per-GPU path (parallel.py) must cut a lag
+    set the same way: mode and block grid for a spread of lag shapes and GPU counts."""
+    from euispice_coreg_amd import parallel
+    shapes = [(60, 60, 1), (61, 61, 1), (121, 121, 1), (61, 61, 21), (41, 41, 275), (1, 2000, 1), (2000, 1, 1),
+              (5, 5, 1), (1, 1, 2001), (3, 3, 275), (7, 2, 40), (2, 7, 40), (16, 16, 1), (1, 1, 1), (9, 9, 2)]
+    for n1, n2, inner in shapes:
+        for world in (1, 2, 3, 4, 6, 8):
+            mode, g1, g2 = lib.multi_plan(n1, n2, inner, world)
+            assert mode == parallel.lag_sharding((n1, n2, inner, 1, 1), world), (n1, n2, inner, world)
+            assert (g1, g2) == parallel.block_grid(n1, n2, world), (n1, n2, inner, world)
