@@ -389,7 +389,7 @@ def main():
                     dist.all_gather(parts, mine[k].cpu())
                     result[0] = torch.cat(parts)[perm.cpu()]
             else:
-                result[0] = mine[k][perm]
+                result[0] = mine[k]  # one rank: the block IS the map (the permutation is the identity)
 
     def timed(n_steps, n_in_flight):
         """EXACTLY n_steps steps between barrier + synchronize on both sides; max over ranks.  Seconds."""

@@ -137,11 +137,36 @@ SYMBOLS = [
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch's ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, same SONAME as the system one).  A
+    process that loads the SYSTEM runtime first (through this library) and imports torch afterwards ends up with a torch
+    that reports "No HIP GPUs are available"; the other order works, both then share torch's copy.  So when torch is
+    installed but not imported yet, its runtime is loaded first -- without importing torch (that costs seconds).
+    COREG_NO_TORCH_PRELOAD=1 switches this off."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("COREG_NO_TORCH_PRELOAD", "0") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # the system runtime will serve; torch, if imported later, may not see the GPU
+
+
 def load_library():
     """dlopen libcoreg_hip.so and declare every prototype.  Raises if the library is missing."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension has not been built. "

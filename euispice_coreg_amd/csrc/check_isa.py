@@ -52,10 +52,36 @@ def regs(tok):
     return out
 
 
+def _addr_index(lines):
+    addr_of = {}
+    for idx, ln in enumerate(lines):
+        m = re.search(r"//\s*([0-9A-Fa-f]{8,16}):", ln)
+        if m:
+            addr_of.setdefault(int(m.group(1), 16), idx)
+    return addr_of
+
+
+def _branch_target(lines, k, addr_of):
+    """(kind, line index of the target or None) of the branch instruction on line k; kind 'branch' / 'cbranch...'."""
+    t = lines[k].strip().split("//")[0].strip()
+    mb = re.match(r"s_(c?branch\w*)\s+(\d+)", t)
+    if not mb:
+        return None, None
+    am = re.search(r"//\s*([0-9A-Fa-f]{8,16}):", lines[k])
+    off = int(mb.group(2))
+    off = off - 65536 if off >= 32768 else off
+    tgt = addr_of.get(int(am.group(1), 16) + 4 + 4 * off) if am else None
+    return mb.group(1), tgt
+
+
 def check(text):
+    """Every group of hand-issued ds_read_b64 (4 or 9 in a row, kernels.hpp Taps<N>): on EVERY control-flow path from
+    the group to the next `s_waitcnt lgkmcnt(0)` (the software-pipelined loop waits for a sample's reads after its
+    back edge) no instruction may name one of the group's destination registers."""
     n_groups, bad = 0, []
     kernel = "?"
     lines = text.splitlines()
+    addr_of = _addr_index(lines)
     i = 0
     while i < len(lines):
         ln = lines[i]
@@ -64,7 +90,6 @@ def check(text):
             kernel = m.group(1)
         ins = ln.strip().split("//")[0].strip()
         if ins.startswith("ds_read_b64") and "k_sweep" in kernel:
-            # a hand-issued group: consecutive ds_read_b64
             dst = set()
             j = i
             while j < len(lines) and lines[j].strip().startswith("ds_read_b64"):
@@ -73,27 +98,33 @@ def check(text):
                 j += 1
             if j - i in (4, 9):  # Taps<2> / Taps<3>
                 n_groups += 1
-                k = j
-                younger = 0  # LDS reads issued after this group (software-pipelined loop: the next sample's)
-                while k < len(lines):
-                    t = lines[k].strip().split("//")[0].strip()
-                    m2 = re.match(r"s_waitcnt .*lgkmcnt\((\d+)\)", t)
-                    if m2 and int(m2.group(1)) <= younger:
-                        break  # in-order return: this group's reads have landed
-                    if t.startswith("ds_read"):
-                        younger += 1
-                    if t and not t.startswith(("s_nop", ";")):
-                        ops = t.split(None, 1)[1] if " " in t else ""
-                        if regs(ops) & dst:
-                            bad.append((kernel, t))
-                    if t.startswith(("s_endpgm", "s_branch", "s_cbranch")):
-                        # a short FORWARD conditional branch (the EXEC-masked accumulation of the previous sample in
-                        # the software-pipelined loop) only skips instructions that are checked here anyway
-                        m3 = re.match(r"s_cbranch_\w+\s+(\d+)", t)
-                        if not (m3 and int(m3.group(1)) < 64):
-                            bad.append((kernel, "control flow before the wait: " + t))
+                work, seen = [j], set()
+                while work:
+                    k = work.pop()
+                    steps = 0
+                    while k < len(lines) and k not in seen and steps < 6000:
+                        seen.add(k)
+                        steps += 1
+                        t = lines[k].strip().split("//")[0].strip()
+                        if re.match(r"^[0-9a-f]+ <", lines[k]) or t.startswith("s_endpgm"):
+                            bad.append((kernel, "end of kernel before the wait"))
                             break
-                    k += 1
+                        if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
+                            break  # in-order return: this group's reads have landed
+                        if t and not t.startswith(("s_nop", ";")):
+                            ops = t.split(None, 1)[1] if " " in t else ""
+                            if regs(ops) & dst:
+                                bad.append((kernel, t))
+                                break
+                        kind, tgt = _branch_target(lines, k, addr_of)
+                        if kind is not None:
+                            if tgt is None:
+                                bad.append((kernel, "branch to an unknown address before the wait: " + t))
+                                break
+                            work.append(tgt)
+                            if kind == "branch":
+                                break  # unconditional: no fall-through
+                        k += 1
             i = j
             continue
         i += 1

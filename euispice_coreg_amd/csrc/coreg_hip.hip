@@ -86,6 +86,8 @@ std::mutex g_attr_mutex;
 
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
+    bool b_is_next_sweep = false;  // precompute intervals end at the opening event of sweep launch `next_sweep_index`
+    size_t next_sweep_index = 0;
 };
 
 }  // namespace
@@ -679,7 +681,10 @@ int launch_precompute(coreg_handle* h, const PrecomputeArgs& a, int n_tiles, int
     hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, h->stream, (const int*)a.tile_count, n_tiles, n_groups,
                        h->tile_list.as<int>(), h->tile_cum.as<int>(), h->group_first.as<int>(),
                        h->tile_info.as<long long>());
-    HIPCHK(hipEventRecord(ev->b, h->stream));
+    // (no closing event: the sweep launch that follows opens with one, and that is where this interval ends --
+    // collect_stats; one marker packet less between the kernels of a sweep)
+    ev->b_is_next_sweep = true;
+    ev->next_sweep_index = h->ev_sweep_used;
     HIPCHK(hipGetLastError());
     return COREG_OK;
 }
@@ -1156,7 +1161,9 @@ int collect_stats(coreg_handle* h) {
         h->stats.sweep_kernel_ms += ms;
     }
     for (size_t i = 0; i < h->ev_pre_used; ++i) {
-        HIPCHK(hipEventElapsedTime(&ms, h->ev_pre[i].a, h->ev_pre[i].b));
+        const EventPair& e = h->ev_pre[i];
+        if (e.b_is_next_sweep && e.next_sweep_index >= h->ev_sweep_used) continue;  // (no sweep launch followed)
+        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b_is_next_sweep ? h->ev_sweep[e.next_sweep_index].a : e.b));
         h->stats.precompute_ms += ms;
     }
     HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));

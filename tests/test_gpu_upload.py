@@ -36,7 +36,7 @@ def test_reference_crop_is_bit_identical(gpu_handle, order, f32):
     assert np.isfinite(out[0]).any()
     # helioprojective sub-map (small header's grid inside the large image), and a target that sticks out of the image
     hs_out = dict(hs)
-    hs_out["CRVAL1"] = hs["CRVAL1"] + 0.45 * hl["NAXIS1"] * hl["CDELT1"]
+    hs_out["CRVAL1"] = hl["CRVAL1"] + 0.5 * hl["NAXIS1"] * hl["CDELT1"]  # centred on the edge of the large image
     for hdr in (hs, hs_out):
         out = []
         for crop in (1, 0):
