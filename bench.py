@@ -448,8 +448,9 @@ def main():
     corr = result[0].cpu().numpy().reshape(lag1.size, lag2.size)
 
     # ---- BASELINE.md section 2 at every N: ONE call that is handed host images.  Every rank uploads its share of both
-    # images (the float32 pixels a BITPIX=-32 FITS file holds: 16 + 36 MiB in all; with RCCL 1/N per rank + one all-gather
-    # over xGMI, parallel.replicate_image; one rank or gloo: the whole images), prepares the reference, sweeps its block,
+    # images (the float32 pixels a BITPIX=-32 FITS file holds: 16 + 36 MiB in all; image to align: with RCCL 1/N per rank +
+    # one all-gather over xGMI, parallel.replicate_image, else whole; reference: the library sends only the rectangle the
+    # grid can touch), prepares the reference, sweeps its block,
     # the all-gather assembles the map and every rank copies it to the host.  Barrier on both sides, max over ranks,
     # best of 4 after one warm-up.
     pcie = None
@@ -465,14 +466,12 @@ def main():
             t0 = time.perf_counter()
             with torch.cuda.stream(streams[0]):
                 ts = parallel.replicate_image(small_h) if use_dist else None
-                tl = parallel.replicate_image(large_h) if use_dist else None
                 if ts is None:
                     h.set_small(small_h)
-                    h.prepare_reference_carrington(large_h, hl, grid, SOLAR_R, ORDER)
                 else:  # (the handle runs on streams[0] = torch's current stream here: stream-ordered, no sync needed)
                     h.set_small_from_device(ts.data_ptr(), ts.shape, small_h.dtype)
-                    h.prepare_reference_carrington_from_device(tl.data_ptr(), tl.shape, np.float32, hl, grid, SOLAR_R,
-                                                               ORDER)
+                # the reference: every rank sends the rectangle its grid can touch (the library crops: ~2 % of 36 MiB)
+                h.prepare_reference_carrington(large_h, hl, grid, SOLAR_R, ORDER)
                 same_pivots(h)
             step_no[0] = 0
             step(1)  # sweep of this rank's block (+ the one collective) on stream / handle 0
@@ -485,9 +484,11 @@ def main():
             times.append(el)
         best = min(times[1:])
         pcie = {"value": L / best, "unit": "lag-points/s", "ms_per_step": 1e3 * best, "n_gpus": world,
-                "image_hand_over": ("1/N of each image per rank over its own PCIe link + one all-gather over xGMI"
+                "image_hand_over": ("image to align: 1/N per rank over its own PCIe link + one all-gather over xGMI; "
+                                    "reference: every rank uploads the rectangle its grid can touch"
                                     if (use_dist and backend == "nccl" and world > 1) else
-                                    "every rank uploads both images whole"),
+                                    "every rank uploads the image to align whole and the rectangle of the reference its "
+                                    "grid can touch"),
                 "identical_to_resident_map": bool(np.array_equal(out_host.reshape(corr.shape), corr, equal_nan=True)),
                 "what": "BASELINE.md section 2 / SURVEY 8d: wall time of one call with host images in (2048^2 image to "
                         "align + 3072^2 reference, float32 = 52 MiB; reference re-prepared), sweep, all-gather, host "

@@ -544,12 +544,10 @@ int coreg_multi_prepare_reference_carrington(coreg_multi* m, const void* large, 
     if (!m) return COREG_EINVAL;
     if (!large || ny < 1 || nx < 1 || (dtype != COREG_F32 && dtype != COREG_F64))
         return mfail(m, COREG_EINVAL, "multi_prepare_reference: bad argument");
-    const bool one = m->n == 1;
-    if (!one) RETCHK(multi_stage(m, large, (size_t)ny * nx * (dtype == COREG_F32 ? 4 : 8)));
+    // every device sends its own copy of the rectangle the grid can touch (reference_crop: usually a few hundred KB;
+    // when the grid covers most of the image, N whole uploads through the devices' own staging buffers)
     return multi_run(m, [&](int k) {
-        RETCHK(prepare_carrington(m->h[k], one ? large : m->stage.p, dtype == COREG_F32, ny, nx, hdr_large, grid, solar_r,
-                                  order, one ? SRC_HOST : SRC_PINNED));
-        return one ? COREG_OK : coreg_synchronize(m->h[k]);
+        return prepare_carrington(m->h[k], large, dtype == COREG_F32, ny, nx, hdr_large, grid, solar_r, order, SRC_HOST);
     });
 }
 
@@ -558,12 +556,8 @@ int coreg_multi_prepare_reference_helioprojective(coreg_multi* m, const void* la
     if (!m) return COREG_EINVAL;
     if (!large || ny < 1 || nx < 1 || (dtype != COREG_F32 && dtype != COREG_F64))
         return mfail(m, COREG_EINVAL, "multi_prepare_reference: bad argument");
-    const bool one = m->n == 1;
-    if (!one) RETCHK(multi_stage(m, large, (size_t)ny * nx * (dtype == COREG_F32 ? 4 : 8)));
     return multi_run(m, [&](int k) {
-        RETCHK(prepare_helioprojective(m->h[k], one ? large : m->stage.p, dtype == COREG_F32, ny, nx, hdr_large, hdr_small,
-                                       order, one ? SRC_HOST : SRC_PINNED));
-        return one ? COREG_OK : coreg_synchronize(m->h[k]);
+        return prepare_helioprojective(m->h[k], large, dtype == COREG_F32, ny, nx, hdr_large, hdr_small, order, SRC_HOST);
     });
 }
 

@@ -357,17 +357,9 @@ class Alignment:
             lo, hi, _ = parallel.shard_bounds(lags.size, world, rank)
 
         def prepare(kind, *args):
-            """Reference preparation with the source image replicated over xGMI when there are several RCCL ranks."""
-            large = self._large_pixels()
-            t = parallel.replicate_image(large) if spread and large.dtype in (np.float32, np.float64) else None
-            if t is None:
-                getattr(h, "prepare_reference_" + kind)(large, *args)
-                return
-            import torch
-            torch.cuda.current_stream().synchronize()
-            getattr(h, "prepare_reference_" + kind + "_from_device")(
-                t.data_ptr(), t.shape, np.float32 if t.element_size() == 4 else np.float64, *args)
-            h.synchronize()  # the resample has read `t`
+            """Once-only reference preparation.  The library uploads only the rectangle of the reference image the target
+            grid can touch (usually a few hundred KB), so every rank simply sends its own crop: nothing to replicate."""
+            getattr(h, "prepare_reference_" + kind)(self._large_pixels(), *args)
 
         out = np.full(lags.shape + (len(solar_rs),), np.nan)
         for kk, solar_r in enumerate(solar_rs):
