@@ -151,7 +151,10 @@ def replicate_image(img, group=None):
         mine[:hi - lo].copy_(torch.from_numpy(img[lo:hi]), non_blocking=False)
     if hi - lo < rows:
         mine[hi - lo:].zero_()
-    dist.all_gather_into_tensor(full, mine.clone(), group=group)
+    try:
+        dist.all_gather_into_tensor(full, mine.clone(), group=group)
+    except (RuntimeError, NotImplementedError):
+        return None  # (raised on every rank alike: the callers then upload the whole image themselves)
     return full[:H]
 
 
