@@ -120,6 +120,8 @@ struct coreg_handle {
     // sweep
     DevBuf lane_params, out_index, partials, out_dev, tmp_img;
     DevBuf up_f64, up_flag;  // upload staging on the device (float64 copy, exactness flag)
+    DevBuf bbox_buf;         // reference_crop: partial bounding boxes
+    hipStream_t aux_stream = nullptr;  // side stream of reference_crop (created on first use)
     // zero-lag border decision of the helioprojective sub-map path (geometry.hpp WcslibTan): grid pixels the
     // reference's wcslib round trip drops, cached per header
     std::map<std::vector<double>, std::vector<int>> border_cache;
@@ -1177,8 +1179,9 @@ int end_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_dev
     HIPCHK(hipEventRecord(h->ev_t1, h->stream));
     if (!out_on_device && n_out > 0)
         HIPCHK(hipMemcpyAsync(corr_out, out_dev, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    h->stats_pending = true;  // (the kept-point count is read back when the statistics are asked for: collect_stats)
-    if (!out_on_device) return collect_stats(h);
+    h->stats_pending = true;  // (timings and the kept-point count are gathered when coreg_last_stats asks: collect_stats)
+    // host output: the values must be there on return; device output: the sweep stays stream-ordered work
+    if (!out_on_device) HIPCHK(hipStreamSynchronize(h->stream));
     return COREG_OK;
 }
 
@@ -1294,6 +1297,8 @@ void coreg_destroy(coreg_handle* h) {
     if (h->ev_upload) (void)hipEventDestroy(h->ev_upload);
     h->pin_info.release();
     h->pin_border.release();
+    h->bbox_buf.release();
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1482,15 +1487,20 @@ static int reference_crop(coreg_handle* h, int mode, const ResampleArgs& a0, int
     *out = {0, 0, a0.W, a0.H};
     if (!h->opt_crop_reference || a0.W < 64 || a0.H < 64) return COREG_OK;
     const int nb = 256;
-    HIPCHK(h->red_sum.reserve((size_t)nb * 4 * sizeof(double)));
+    // On a side stream: the box depends on headers and grid tables only, so it need not queue behind the upload of the
+    // image to align that usually precedes it on the handle's stream (its last DMA segment is still in flight).
+    if (!h->aux_stream) HIPCHK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    HIPCHK(h->bbox_buf.reserve((size_t)nb * 4 * sizeof(double)));
     ResampleArgs a = a0;
-    a.bbox = h->red_sum.as<double>();
-    if (mode == MODE_TRANSLATE) hipLaunchKernelGGL((k_resample_bbox<MODE_TRANSLATE>), dim3(nb), dim3(256), 0, h->stream, a);
-    else hipLaunchKernelGGL((k_resample_bbox<MODE_HOMOGRAPHY>), dim3(nb), dim3(256), 0, h->stream, a);
+    a.bbox = h->bbox_buf.as<double>();
+    if (mode == MODE_TRANSLATE)
+        hipLaunchKernelGGL((k_resample_bbox<MODE_TRANSLATE>), dim3(nb), dim3(256), 0, h->aux_stream, a);
+    else
+        hipLaunchKernelGGL((k_resample_bbox<MODE_HOMOGRAPHY>), dim3(nb), dim3(256), 0, h->aux_stream, a);
     HIPCHK(hipGetLastError());
     std::vector<double> part((size_t)nb * 4);
-    HIPCHK(hipMemcpyAsync(part.data(), a.bbox, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(part.data(), a.bbox, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->aux_stream));
+    HIPCHK(hipStreamSynchronize(h->aux_stream));
     double mnx = 1e300, mxx = -1e300, mny = 1e300, mxy = -1e300;
     for (int b = 0; b < nb; ++b) {
         mnx = std::min(mnx, part[4 * b + 0]);
