@@ -950,7 +950,8 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     f.out = out_dev;
     f.residus = method == COREG_METHOD_RESIDUS ? 1 : 0;
     f.n_required = (long long)h->gW * h->gH;
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_slots + 63) / 64)), dim3(64 * kFinLanes), 0, h->stream, f);
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_slots + kFinSlots - 1) / kFinSlots)), dim3(kFinSlots * kFinLanes), 0,
+                       h->stream, f);
     HIPCHK(hipGetLastError());
     return COREG_OK;
 }
@@ -2311,7 +2312,8 @@ int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device,
         f.n_required = (long long)h->gW * h->gH;
         f.sums_out = nullptr;
         f.sums_stride = f.sums_off = 0;
-        hipLaunchKernelGGL(k_finalize, dim3((unsigned)((pf.n_slots + 63) / 64)), dim3(64 * kFinLanes), 0, h->stream, f);
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned)((pf.n_slots + kFinSlots - 1) / kFinSlots)), dim3(kFinSlots * kFinLanes),
+                           0, h->stream, f);
     }
     HIPCHK(hipGetLastError());
     if (!out_on_device && n_out > 0) {

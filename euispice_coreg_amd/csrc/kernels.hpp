@@ -1638,11 +1638,13 @@ struct FinalizeArgs {
     long long part_stride;  // distance between the six sums of a slab (n_slots, or sums_stride when reading reduced sums)
 };
 constexpr int kFinLanes = 16;  // threads per lag slot in k_finalize
-__global__ void __launch_bounds__(64 * kFinLanes) k_finalize(const FinalizeArgs a) {
-    // 64 lag slots per block; kFinLanes threads per slot each add every kFinLanes-th slab, then one adds them in order
-    __shared__ double red[kFinLanes - 1][kNumSums][64];
-    const int ls = threadIdx.x & 63, j = threadIdx.x >> 6;
-    const long long slot = (long long)blockIdx.x * 64 + ls;
+constexpr int kFinSlots = 16;  // lag slots per block: 256-thread blocks, 16 of them per 256-lag batch -- a sweep of two
+                               // batches (one GPU's share of the headline at N = 8) still spreads over 32 CUs
+__global__ void __launch_bounds__(kFinSlots * kFinLanes) k_finalize(const FinalizeArgs a) {
+    // kFinLanes threads per slot each add every kFinLanes-th slab, then one adds them in order
+    __shared__ double red[kFinLanes - 1][kNumSums][kFinSlots];
+    const int ls = threadIdx.x % kFinSlots, j = threadIdx.x / kFinSlots;
+    const long long slot = (long long)blockIdx.x * kFinSlots + ls;
     double s[kNumSums];
 #pragma unroll
     for (int k = 0; k < kNumSums; ++k) s[k] = 0.0;
