@@ -147,6 +147,7 @@ struct coreg_handle {
 
     // options
     int64_t opt_crop_reference = 1;
+    int64_t opt_taper_min = 128, opt_taper_frac = -1, opt_taper_rounds = 6;  // tapered group shares (pick_taper)
     int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
 
     coreg_stats stats;
@@ -671,10 +672,27 @@ int pick_groups(coreg_handle* h, int n_batches, int n_tiles) {
     return (int)g;
 }
 
+// Tapered shares (kernels.hpp group_start) pay when the launch has many rounds of workgroups; with few rounds the large
+// early shares would simply finish last (measured on the translation sweep, profiles/taper_sweep.sh: -3.5 % at 15
+// rounds, -4 % at 8, about even at 4, +14 % at 2) ...
+void pick_taper(const coreg_handle* h, int n_groups, int n_batches, int* tmin, int* tfrac) {
+    *tmin = (int)h->opt_taper_min;
+    if (h->opt_taper_frac >= 0) {
+        *tfrac = (int)h->opt_taper_frac;
+        return;
+    }
+    // ... and when the groups are many (a fine taper) -- cfg4's 16 groups of a 156-tile grid lost 27 % to it, the
+    // 4-round plate-carree launch 20 %
+    const double rounds = (double)n_groups * n_batches / 256.0;
+    *tfrac = (rounds >= (double)h->opt_taper_rounds && n_groups >= 128 && h->opt_shard_world <= 1) ? 512 : 0;
+}
+
 template <int MODE>
-int launch_precompute(coreg_handle* h, const PrecomputeArgs& a, int n_tiles, int n_groups) {
+int launch_precompute(coreg_handle* h, const PrecomputeArgs& a, int n_tiles, int n_groups, int n_batches) {
     EventPair* ev = next_event(h, h->ev_pre, h->ev_pre_used);
     if (!ev) return fail(h, COREG_EHIP, "hipEventCreate failed");
+    int tmin, tfrac;
+    pick_taper(h, n_groups, n_batches, &tmin, &tfrac);
     HIPCHK(hipEventRecord(ev->a, h->stream));
     if (h->ref_dtype == COREG_F32)
         hipLaunchKernelGGL((k_precompute<MODE, float>), dim3(n_tiles), dim3(256), 0, h->stream, a);
@@ -682,7 +700,7 @@ int launch_precompute(coreg_handle* h, const PrecomputeArgs& a, int n_tiles, int
         hipLaunchKernelGGL((k_precompute<MODE, double>), dim3(n_tiles), dim3(256), 0, h->stream, a);
     hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, h->stream, (const int*)a.tile_count, n_tiles, n_groups,
                        h->tile_list.as<int>(), h->tile_cum.as<int>(), h->group_first.as<int>(),
-                       h->tile_info.as<long long>());
+                       h->tile_info.as<long long>(), tmin, tfrac);
     // (no closing event: the sweep launch that follows opens with one, and that is where this interval ends --
     // collect_stats; one marker packet less between the kernels of a sweep)
     ev->b_is_next_sweep = true;
@@ -697,7 +715,7 @@ int reserve_tiles(coreg_handle* h, int n_tiles) {
     HIPCHK(h->tile_count.reserve(n_tiles * sizeof(int)));
     HIPCHK(h->tile_list.reserve(n_tiles * sizeof(int)));
     HIPCHK(h->tile_cum.reserve((n_tiles + 1) * sizeof(int)));
-    HIPCHK(h->group_first.reserve(1024 * sizeof(int)));
+    HIPCHK(h->group_first.reserve(2 * 1024 * sizeof(int) + 64));  // [0, 1024): first list entry; [1024, ...): first unit
     HIPCHK(h->tile_info.reserve(4 * sizeof(long long)));
     HIPCHK(h->tile_bbox.reserve((size_t)n_tiles * 4 * sizeof(double)));
     return COREG_OK;
@@ -1349,6 +1367,15 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         h->opt_border_fix = value ? 1 : 0;  // 0: the zero lag keeps every border pixel (exact identity map)
     } else if (n == "pitch") {
         h->opt_pitch = value;  // -1: automatic compile-time window pitch, 0: per-visit pitch, else one of pick_pitch's
+    } else if (n == "taper_frac") {
+        if (value < -1 || value > 1000) return fail(h, COREG_EINVAL, "taper_frac must be in [-1, 1000]");
+        h->opt_taper_frac = value;  // -1: automatic (512 for launches of many rounds, else 0 = equal shares)
+    } else if (n == "taper_min") {
+        if (value < 16 || value > 1024) return fail(h, COREG_EINVAL, "taper_min must be in [16, 1024]");
+        h->opt_taper_min = value;
+    } else if (n == "taper_rounds") {
+        if (value < 1) return fail(h, COREG_EINVAL, "taper_rounds must be >= 1");
+        h->opt_taper_rounds = value;
     } else if (n == "crop_reference") {
         h->opt_crop_reference = value ? 1 : 0;  // 0: the reference preparation uploads the whole source image
     } else if (n == "tile_skip") {
@@ -1905,7 +1932,7 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
             pa.dlon = grid->n_lon > 1 ? (std::fabs(grid->lon1 - grid->lon0) / (grid->n_lon - 1) * 1.001 + 1e-4) * kDeg2Rad : 0.0;
             pa.dlat = grid->n_lat > 1 ? (std::fabs(grid->lat1 - grid->lat0) / (grid->n_lat - 1) * 1.001 + 1e-4) * kDeg2Rad : 0.0;
         }
-        RETCHK(launch_precompute<MODE_TRANSLATE>(h, pa, n_tiles, pick_groups(h, L.n_batches, n_tiles)));
+        RETCHK(launch_precompute<MODE_TRANSLATE>(h, pa, n_tiles, pick_groups(h, L.n_batches, n_tiles), L.n_batches));
         // SoA block of this launch starts at 2 * slot_off doubles (every earlier launch contributed 2 per slot)
         RETCHK(launch_sweep(h, MODE_TRANSLATE, order, method, h->lane_params.as<double>() + 2 * L.slot_off,
                             h->out_index.as<long long>() + L.slot_off, L.n_batches, n_tiles, lag_begin, out_dev, nullptr,
@@ -2058,12 +2085,13 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
     const double inf = std::numeric_limits<double>::infinity();
     pa.f0lo = pa.f1lo = -inf;  // no culling by position: only non-finite reference values drop out
     pa.f0hi = pa.f1hi = inf;
-    int last_groups = -1;
+    int last_groups = -1, last_batches = -1;
     for (const Launch& L : launches) {
         // the work partition (k_tile_list) depends on the group count of the launch: redo it only when that changes
         const int ng = pick_groups(h, L.n_batches, n_tiles);
-        if (ng != last_groups) RETCHK(launch_precompute<MODE_CAR>(h, pa, n_tiles, ng));
+        if (ng != last_groups || L.n_batches != last_batches) RETCHK(launch_precompute<MODE_CAR>(h, pa, n_tiles, ng, L.n_batches));
         last_groups = ng;
+        last_batches = L.n_batches;
         RETCHK(launch_sweep(h, MODE_CAR, order, method, h->lane_params.as<double>() + 9 * L.slot_off,
                             h->out_index.as<long long>() + L.slot_off, L.n_batches, n_tiles, lag_begin, out_dev,
                             &L.inv, nullptr, (long long)L.slot_off));
@@ -2252,7 +2280,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
             HIPCHK(hipMemcpy(h->border_flags.as<unsigned char>() + k * each, flags_host[k].data(), each,
                              hipMemcpyHostToDevice));
     }
-    RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles, pick_groups(h, n_batches, n_tiles)));
+    RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles, pick_groups(h, n_batches, n_tiles), n_batches));
     RETCHK(launch_sweep(h, sweep_mode, order, method, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
                         n_tiles, lag_begin, out_dev, nullptr, &fix, 0,
                         pick_pitch(h, plan, h->opt_use_lds ? lds_window_elems(h) : 0)));

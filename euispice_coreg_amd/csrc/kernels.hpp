@@ -706,8 +706,30 @@ __global__ void __launch_bounds__(256) k_precompute(const PrecomputeArgs a) {
 //   tile group g start when the total is cut in n_groups equal shares;
 //   info[0] = non-empty tiles, info[1] = kept points, info[2] = work units.
 constexpr int kUnitPts = kChunk * kPointGroups;
+// Where tile group g's share of the `total` work units starts.  taper_frac = 0: equal shares.  Otherwise the last
+// taper_frac / 1024 of the groups get linearly smaller shares, down to taper_min / 1024 of a full one, and the others
+// proportionally more: the groups are dispatched in increasing order, so small late workgroups even out the end of a
+// launch of many rounds, and the larger early ones stage fewer partial tiles per point (measured).
+// Evaluated once per group by k_tile_list, which leaves the starts in a table for k_sweep.
+__host__ __device__ inline long long group_start(int g, long long total, int n_groups, int taper_min, int taper_frac) {
+    if (taper_frac <= 0) return (long long)g * total / n_groups;
+    const int g0 = n_groups - (int)((long long)n_groups * taper_frac / 1024);  // first tapered group
+    const int nt = n_groups - 1 - g0;                                          // its weight falls over nt steps
+    if (nt <= 0) return (long long)g * total / n_groups;
+    // weight(k) = 1 for k < g0, 1 - (1 - m) (k - g0) / nt after: cumulative weight in closed form (exact in float64)
+    const double m = (double)taper_min / 1024.0;
+    auto cum = [&](int k) -> double {
+        if (k <= g0) return (double)k;
+        const double j = (double)(k - g0);
+        return (double)g0 + j - (1.0 - m) * j * (j - 1.0) / (2.0 * (double)nt);
+    };
+    if (g >= n_groups) return total;
+    const long long s0 = (long long)(cum(g) / cum(n_groups) * (double)total);
+    return s0 < 0 ? 0 : (s0 > total ? total : s0);
+}
 __global__ void __launch_bounds__(1024) k_tile_list(const int* __restrict__ tile_count, int n_tiles, int n_groups,
-                                                    int* tile_list, int* tile_cum, int* group_first, long long* info) {
+                                                    int* tile_list, int* tile_cum, int* group_first, long long* info,
+                                                    int taper_min, int taper_frac) {
     __shared__ int wcnt[16];
     __shared__ int wunits[16];
     __shared__ long long wpts[16];
@@ -774,7 +796,8 @@ __global__ void __launch_bounds__(1024) k_tile_list(const int* __restrict__ tile
     __syncthreads();
     // first list entry of each group's unit range [g * total / n_groups, ...): largest k with tile_cum[k] <= start
     for (int g = threadIdx.x; g <= n_groups; g += 1024) {
-        const long long start = (long long)g * total / n_groups;
+        const long long start = group_start(g, total, n_groups, taper_min, taper_frac);
+        group_first[1024 + g] = (int)start;  // second half of the table: the unit each group's share starts at
         int lo = 0, hi = n_list;  // answer in [0, n_list]
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -1255,9 +1278,8 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
     const int W = a.W, H = a.H;
     const double inf = __builtin_inf();
     // this tile group's share of the work: units [u_lo, u_hi) of the concatenated compacted points
-    const long long total_units = a.tile_info[2];
-    const int u_lo = (int)((long long)group * total_units / a.n_groups);
-    const int u_hi = (int)((long long)(group + 1) * total_units / a.n_groups);
+    const int u_lo = a.group_first[1024 + group];  // (k_tile_list: group_start)
+    const int u_hi = a.group_first[1024 + group + 1];
     const int n_list = (int)a.tile_info[0];
     const double pivot_b = a.pivots[1];
     const unsigned win = (unsigned)(uintptr_t)lds;  // LDS byte address of the window

@@ -232,6 +232,9 @@ int coreg_last_stats(coreg_handle* h, coreg_stats* out);
  *   "h_series"     1 (default) helioprojective maps with |projective term| < 4e-6 invert 1 + eps as 1 - eps + eps^2
  *                  (exact to float64 there) instead of dividing; 0 always divide
  *   "patch_w"      0 (default, auto) or the maximum width, in CRVAL1 lags, of a workgroup's lag patch
+ *   "taper_frac"   -1 (default, automatic) / 0 equal shares of the grid points per tile group / n: the last n/1024 of the
+ *                  groups get linearly smaller shares (down to "taper_min"/1024, default 128) and the others more;
+ *                  automatic = 512 for launches of at least "taper_rounds" (default 6) rounds of workgroups and at least 128 tile groups
  *   "crop_reference" 1 (default) coreg_prepare_reference_* upload only the rectangle of the reference image the target
  *                  grid can touch (bounding box of the sample coordinates, computed on the GPU; identical results),
  *                  0 the whole image

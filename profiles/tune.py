@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Tuning harness: headline sweep (bench.py workload) under different library options; prints sweep-kernel ms.
-usage: python profiles/tune.py "opt=val,opt=val" "opt=val" ...   (each argument = one configuration)"""
+usage: python profiles/tune.py "opt=val,opt=val" "opt=val" ...   (each argument = one configuration)
+NOTE: the FIRST configuration timed in a process runs 5-8 % slower than the following ones (clock ramp): repeat the
+baseline after the candidates before believing a difference."""
 import os
 import sys
 import time
@@ -26,7 +28,8 @@ def main():
     h.prepare_reference_carrington(large, hl, grid, 1.004, 2)
     base = None
     for cfg in (sys.argv[1:] or [""]):
-        defaults = {"use_lds": 1, "tile_w": 0, "n_groups": 0, "lds_bytes": int(os.environ.get("TUNE_LDS", 159 * 1024)), "patch_w": 0, "skew": 0}
+        defaults = {"use_lds": 1, "tile_w": 0, "n_groups": 0, "lds_bytes": int(os.environ.get("TUNE_LDS", 159 * 1024)), "patch_w": 0,
+                    "pitch": -1, "taper_frac": -1, "taper_min": 128, "taper_rounds": 6}
         for kv in filter(None, cfg.split(",")):
             k, v = kv.split("=")
             defaults[k] = int(v)
