@@ -70,6 +70,45 @@ def test_headline_size_properties(gpu_handle, big_scene, carr_ready):
     assert np.array_equal(again, full)
 
 
+def test_tapered_group_shares_do_not_change_the_map(gpu_handle, big_scene, carr_ready):
+    """Launches of many rounds of workgroups cut the grid points in TAPERED shares (kernels.hpp group_start: the late tile
+    groups small, the early ones larger); equal shares, other taper shapes and the automatic choice must give the same
+    map (the partition only changes which workgroup adds which points: agreement to rounding), and a few-round launch
+    keeps equal shares."""
+    small, hs, large, hl, truth = big_scene
+    grid = carr_ready
+    lag = np.arange(-30.0, 30.0, 1.0)
+    lags = (lag, lag, None, None, None)
+    auto = _sweep(gpu_handle, hs, grid, lags)
+    maps = {}
+    try:
+        for name, opts in {"equal": {"taper_frac": 0}, "half": {"taper_frac": 512, "taper_min": 128},
+                           "steep": {"taper_frac": 768, "taper_min": 16}, "late": {"taper_frac": 128, "taper_min": 512}}.items():
+            for k, v in opts.items():
+                gpu_handle.set_option(k, v)
+            maps[name] = _sweep(gpu_handle, hs, grid, lags)
+            gpu_handle.set_option("taper_frac", -1)
+            gpu_handle.set_option("taper_min", 128)
+    finally:
+        gpu_handle.set_option("taper_frac", -1)
+        gpu_handle.set_option("taper_min", 128)
+    assert np.array_equal(auto, maps["half"])  # 15 rounds, 256 groups: the automatic choice is the half taper
+    for name, m in maps.items():
+        assert np.isfinite(m).all() and np.abs(m - maps["equal"]).max() <= 1e-13, name
+        assert np.argmax(m) == np.argmax(maps["equal"])
+    with pytest.raises(Exception):
+        gpu_handle.set_option("taper_frac", 2000)
+    # a 2-batch launch (two rounds of workgroups) is not tapered automatically
+    few = (lag[:15], lag[:30], None, None, None)
+    a = _sweep(gpu_handle, hs, grid, few)
+    gpu_handle.set_option("taper_frac", 0)
+    try:
+        b = _sweep(gpu_handle, hs, grid, few)
+    finally:
+        gpu_handle.set_option("taper_frac", -1)
+    assert np.array_equal(a, b)
+
+
 def test_headline_size_oracle_spot_check(gpu_handle, big_scene, carr_ready):
     """Three lag-points of the headline workload against the oracle (float64 both sides, NumPy lat trig): 1e-10."""
     from oracle import coreg_oracle as O
