@@ -112,7 +112,7 @@ struct coreg_handle {
     DevBuf t_sin_lon, t_cos_lon, t_cos_lat, t_sin_lat;
     CarrTables tabs;
     std::vector<double> tabs_key;
-    PinBuf pin_params, pin_outidx, pin_img[2];
+    PinBuf pin_img[2];
     hipEvent_t ev_img[2] = {nullptr, nullptr};
     int pin_img_next = 0;
     // precompute outputs
@@ -120,6 +120,7 @@ struct coreg_handle {
     // sweep
     DevBuf lane_params, out_index, partials, out_dev, tmp_img;
     DevBuf up_f64, up_flag;  // upload staging on the device (float64 copy, exactness flag)
+    PrologueArgs pending_prologue = {};  // set by upload_plan, consumed by the sweep's first k_precompute launch
     DevBuf bbox_buf;         // reference_crop: partial bounding boxes
     hipStream_t aux_stream = nullptr;  // side stream of reference_crop (created on first use)
     // zero-lag border decision of the helioprojective sub-map path (geometry.hpp WcslibTan): grid pixels the
@@ -153,10 +154,15 @@ struct coreg_handle {
     coreg_stats stats;
     bool stats_pending = false;   // a device-output sweep is in flight: timings are collected on demand
     PinBuf pin_info;              // tile_info read-back of the in-flight sweep
-    hipEvent_t ev_upload = nullptr;  // completes when the last lag-parameter upload has left the pinned staging
     std::vector<EventPair> ev_sweep, ev_pre;
     size_t ev_sweep_used = 0, ev_pre_used = 0;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    // The plan staging (lag parameters in pinned memory) is double-buffered: slot k is rewritten only when the sweep
+    // that last used it has ended (its end event), so the host can plan sweep n + 1 while the GPU runs sweep n, with no
+    // extra event between the kernels.  ev_t1 is an alias of the current slot's end event.
+    hipEvent_t ev_end[2] = {nullptr, nullptr};
+    PinBuf pin_plan[2];
+    int plan_slot = 0;
 };
 
 namespace {
@@ -693,11 +699,16 @@ int launch_precompute(coreg_handle* h, const PrecomputeArgs& a, int n_tiles, int
     if (!ev) return fail(h, COREG_EHIP, "hipEventCreate failed");
     int tmin, tfrac;
     pick_taper(h, n_groups, n_batches, &tmin, &tfrac);
+    PrecomputeArgs b = a;
+    b.prologue = h->pending_prologue;  // (the first launch after upload_plan carries the sweep's prologue)
+    const bool with_prologue = b.prologue.src != nullptr;
+    std::memset(&h->pending_prologue, 0, sizeof(h->pending_prologue));
     HIPCHK(hipEventRecord(ev->a, h->stream));
     if (h->ref_dtype == COREG_F32)
-        hipLaunchKernelGGL((k_precompute<MODE, float>), dim3(n_tiles), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL((k_precompute<MODE, float>), dim3(n_tiles), dim3(256), 0, h->stream, b);
     else
-        hipLaunchKernelGGL((k_precompute<MODE, double>), dim3(n_tiles), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL((k_precompute<MODE, double>), dim3(n_tiles), dim3(256), 0, h->stream, b);
+    (void)with_prologue;
     hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, h->stream, (const int*)a.tile_count, n_tiles, n_groups,
                        h->tile_list.as<int>(), h->tile_cum.as<int>(), h->group_first.as<int>(),
                        h->tile_info.as<long long>(), tmin, tfrac);
@@ -1153,8 +1164,8 @@ int begin_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_d
         *out_dev = h->out_dev.as<double>();
     }
     HIPCHK(hipEventRecord(h->ev_t0, h->stream));
-    // (the output is NaN-initialised by the prologue kernel of upload_plan, or by fill_nan on the paths that launch
-    // nothing)
+    // (the output is NaN-initialised by the prologue part of the first k_precompute launch, or by fill_nan on the
+    // paths that launch nothing)
     return COREG_OK;
 }
 
@@ -1195,7 +1206,9 @@ int collect_stats(coreg_handle* h) {
 // Host output: copy back and wait.  Device output: return at once -- the sweep is stream-ordered work like any other
 // (a following collective on the same stream sees the results); timings are gathered when coreg_last_stats asks.
 int end_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_device, double* out_dev) {
+    h->ev_t1 = h->ev_end[h->plan_slot];  // this sweep's end: statistics, and the guard of its plan staging slot
     HIPCHK(hipEventRecord(h->ev_t1, h->stream));
+    h->plan_slot ^= 1;
     if (!out_on_device && n_out > 0)
         HIPCHK(hipMemcpyAsync(corr_out, out_dev, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     h->stats_pending = true;  // (timings and the kept-point count are gathered when coreg_last_stats asks: collect_stats)
@@ -1209,25 +1222,29 @@ long long lds_window_elems(const coreg_handle* h) {
     return (long long)(std::max(lds_min, (size_t)h->opt_lds_bytes) / sizeof(double));
 }
 
-// The concatenated per-launch lag parameters / output indices go to page-locked memory and are fetched from there by the
-// prologue kernel, which also NaN-initialises the output (no host sync, no DMA-engine copy between the kernels).
+// The concatenated per-launch lag parameters / output indices go to page-locked memory; the FIRST k_precompute launch of
+// the sweep fetches them from there and NaN-initialises the output (PrologueArgs: no host sync, no DMA-engine copy, no
+// launch of its own between the kernels).
 int upload_plan(coreg_handle* h, const std::vector<double>& params, const std::vector<long long>& outidx,
                 double* out_dev, long long n_out) {
     const size_t bytes = params.size() * sizeof(double) + outidx.size() * sizeof(long long);
     HIPCHK(h->lane_params.reserve(params.size() * sizeof(double)));
     HIPCHK(h->out_index.reserve(outidx.size() * sizeof(long long)));
-    HIPCHK(hipEventSynchronize(h->ev_upload));  // the previous sweep's prologue has read the staging buffer
-    HIPCHK(h->pin_params.reserve(bytes));
-    std::memcpy(h->pin_params.p, params.data(), params.size() * sizeof(double));
-    std::memcpy((char*)h->pin_params.p + params.size() * sizeof(double), outidx.data(), outidx.size() * sizeof(long long));
+    PinBuf& pin = h->pin_plan[h->plan_slot];
+    HIPCHK(hipEventSynchronize(h->ev_end[h->plan_slot]));  // the sweep before last (same slot) has ended
+    HIPCHK(pin.reserve(bytes));
+    std::memcpy(pin.p, params.data(), params.size() * sizeof(double));
+    std::memcpy((char*)pin.p + params.size() * sizeof(double), outidx.data(), outidx.size() * sizeof(long long));
     void* src_dev = nullptr;
-    HIPCHK(hipHostGetDevicePointer(&src_dev, h->pin_params.p, 0));
-    const long long n_max = std::max<long long>(std::max<long long>((long long)params.size(), (long long)outidx.size()), n_out);
-    const int nb = (int)std::max<long long>(1, std::min<long long>((n_max + 255) / 256, 512));
-    hipLaunchKernelGGL(k_prologue, dim3(nb), dim3(256), 0, h->stream, (const double*)src_dev, h->lane_params.as<double>(),
-                       (long long)params.size(), h->out_index.as<long long>(), (long long)outidx.size(), out_dev, n_out);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(h->ev_upload, h->stream));
+    HIPCHK(hipHostGetDevicePointer(&src_dev, pin.p, 0));
+    PrologueArgs& p = h->pending_prologue;
+    p.src = (const double*)src_dev;
+    p.dst_params = h->lane_params.as<double>();
+    p.n_params = (long long)params.size();
+    p.dst_outidx = h->out_index.as<long long>();
+    p.n_outidx = (long long)outidx.size();
+    p.out = out_dev;
+    p.n_out = n_out;
     return COREG_OK;
 }
 
@@ -1242,8 +1259,12 @@ int prepare_sharded(coreg_handle* h, size_t total_slots, long long n_out, long l
     h->sums_slots = (long long)total_slots;
     HIPCHK(h->sums.reserve(std::max<size_t>(1, total_slots) * kNumSums * sizeof(double)));
     HIPCHK(h->fin_outidx.reserve(std::max<size_t>(1, total_slots) * sizeof(long long)));
-    HIPCHK(hipMemcpyAsync(h->fin_outidx.p, h->out_index.p, total_slots * sizeof(long long), hipMemcpyDeviceToDevice,
-                          h->stream));
+    // (from the pinned plan staging: the device copy of the output indices is only written by the prologue part of the
+    // sweep's first k_precompute launch, which has not been enqueued yet)
+    const PrologueArgs& pr = h->pending_prologue;
+    if (!pr.src || (size_t)pr.n_outidx < total_slots) return fail(h, COREG_ESTATE, "prepare_sharded: no plan staged");
+    HIPCHK(hipMemcpyAsync(h->fin_outidx.p, (const char*)h->pin_plan[h->plan_slot].p + (size_t)pr.n_params * sizeof(double),
+                          total_slots * sizeof(long long), hipMemcpyHostToDevice, h->stream));
     return COREG_OK;
 }
 
@@ -1274,8 +1295,9 @@ int coreg_create(coreg_handle** out, int device) {
     }
     h->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_t1) != hipSuccess ||
-        hipEventCreate(&h->ev_upload) != hipSuccess || hipEventRecord(h->ev_upload, h->stream) != hipSuccess ||
+        hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_end[0]) != hipSuccess ||
+        hipEventCreate(&h->ev_end[1]) != hipSuccess || hipEventRecord(h->ev_end[0], h->stream) != hipSuccess ||
+        hipEventRecord(h->ev_end[1], h->stream) != hipSuccess ||
         h->pivots.reserve(2 * sizeof(double)) != hipSuccess ||
         hipMemsetAsync(h->pivots.p, 0, 2 * sizeof(double), h->stream) != hipSuccess) {
         h->own_stream = h->stream != nullptr;
@@ -1297,8 +1319,6 @@ void coreg_destroy(coreg_handle* h) {
                       &h->tile_info, &h->tile_bbox, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
                       &h->tmp_img, &h->up_f64, &h->up_flag, &h->border_dev, &h->sums, &h->fin_outidx, &h->border_flags, &h->fix_partial};
     for (DevBuf* b : bufs) b->release();
-    h->pin_params.release();
-    h->pin_outidx.release();
     for (int k = 0; k < 2; ++k) {
         h->pin_img[k].release();
         if (h->ev_img[k]) (void)hipEventDestroy(h->ev_img[k]);
@@ -1312,8 +1332,10 @@ void coreg_destroy(coreg_handle* h) {
         (void)hipEventDestroy(e.b);
     }
     if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
-    if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
-    if (h->ev_upload) (void)hipEventDestroy(h->ev_upload);
+    for (int k = 0; k < 2; ++k) {
+        if (h->ev_end[k]) (void)hipEventDestroy(h->ev_end[k]);
+        h->pin_plan[k].release();
+    }
     h->pin_info.release();
     h->pin_border.release();
     h->bbox_buf.release();

@@ -476,21 +476,6 @@ __global__ void k_fill(double* p, long long n, double v) {
     if (i < n) p[i] = v;
 }
 
-// Prologue of a sweep, one launch: the lag parameters and output indices the host has just written to page-locked
-// memory are read over PCIe by this kernel (a few tens of KB; two DMA-engine copies in their place cost ~50 us of
-// queue switches each between the kernels of a sweep) and the output is NaN-initialised (quirk Q9).
-__global__ void __launch_bounds__(256) k_prologue(const double* __restrict__ src, double* __restrict__ dst_params,
-                                                  long long n_params, long long* __restrict__ dst_outidx,
-                                                  long long n_outidx, double* __restrict__ out, long long n_out) {
-    const long long stride = (long long)gridDim.x * 256;
-    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
-    for (long long i = i0; i < n_params; i += stride) dst_params[i] = src[i];
-    const long long* __restrict__ src_idx = (const long long*)(src + n_params);
-    for (long long i = i0; i < n_outidx; i += stride) dst_outidx[i] = src_idx[i];
-    const double nan = __builtin_nan("");
-    for (long long i = i0; i < n_out; i += stride) out[i] = nan;
-}
-
 // ---- once-only resample (reference preparation, alignment.py:646-651; single-header resample) ----------------------
 struct ResampleArgs {
     const void* img;  // small / large image, TS
@@ -573,7 +558,31 @@ __global__ void __launch_bounds__(256) k_resample(const ResampleArgs a) {
 }
 
 // ---- precompute: base coordinates, culling, tile-major compaction -----------------------------------------------
+// Prologue of a sweep, folded into its FIRST k_precompute launch: the lag parameters and output indices the host has
+// just written to page-locked memory are read over PCIe by the kernel (a few tens of KB; two DMA-engine copies in their
+// place cost ~50 us of queue switches each between the kernels of a sweep) and the output is NaN-initialised (quirk Q9).
+struct PrologueArgs {
+    const double* src;      // pinned host memory (device-visible): [n_params doubles][n_outidx int64]; null: nothing to do
+    double* dst_params;
+    long long n_params;
+    long long* dst_outidx;
+    long long n_outidx;
+    double* out;
+    long long n_out;
+};
+__device__ __forceinline__ void run_prologue(const PrologueArgs& p) {
+    if (!p.src) return;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long i = i0; i < p.n_params; i += stride) p.dst_params[i] = p.src[i];
+    const long long* __restrict__ src_idx = (const long long*)(p.src + p.n_params);
+    for (long long i = i0; i < p.n_outidx; i += stride) p.dst_outidx[i] = src_idx[i];
+    const double nan = __builtin_nan("");
+    for (long long i = i0; i < p.n_out; i += stride) p.out[i] = nan;
+}
+
 struct PrecomputeArgs {
+    PrologueArgs prologue;  // first launch of a sweep only
     const void* ref;  // reference on grid, TA, [gh][gw]
     int gw, gh;
     int tile_w, tile_h;  // tile_w * tile_h == kTilePts
@@ -594,6 +603,7 @@ template <int MODE, typename TA>
 __global__ void __launch_bounds__(256) k_precompute(const PrecomputeArgs a) {
     __shared__ int wave_cnt[4];
     __shared__ double red[4][4];
+    run_prologue(a.prologue);
     const int tile = blockIdx.x;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
