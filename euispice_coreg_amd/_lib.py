@@ -153,12 +153,17 @@ def _preload_torch_hip_runtime():
         return
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    cand = os.path.join(libdir, "libamdhip64.so")
     if os.path.exists(cand):
         try:
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
         except OSError:
-            pass  # the system runtime will serve; torch, if imported later, may not see the GPU
+            return  # the system runtime will serve; torch, if imported later, may not see the GPU
+        # ... and the RCCL that goes with that runtime is the one the in-library multi-GPU driver should dlopen
+        rccl = os.path.join(libdir, "librccl.so")
+        if os.path.exists(rccl):
+            os.environ.setdefault("COREG_RCCL_LIB", rccl)
 
 
 def load_library():

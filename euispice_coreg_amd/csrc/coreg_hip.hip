@@ -156,7 +156,7 @@ struct coreg_handle {
     PinBuf pin_info;              // tile_info read-back of the in-flight sweep
     std::vector<EventPair> ev_sweep, ev_pre;
     size_t ev_sweep_used = 0, ev_pre_used = 0;
-    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_t1 = nullptr;
     // The plan staging (lag parameters in pinned memory) is double-buffered: slot k is rewritten only when the sweep
     // that last used it has ended (its end event), so the host can plan sweep n + 1 while the GPU runs sweep n, with no
     // extra event between the kernels.  ev_t1 is an alias of the current slot's end event.
@@ -1163,7 +1163,7 @@ int begin_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_d
         HIPCHK(h->out_dev.reserve((size_t)std::max<long long>(n_out, 1) * sizeof(double)));
         *out_dev = h->out_dev.as<double>();
     }
-    HIPCHK(hipEventRecord(h->ev_t0, h->stream));
+    // (no start event of its own: the opening event of the first k_precompute launch is the sweep's start, collect_stats)
     // (the output is NaN-initialised by the prologue part of the first k_precompute launch, or by fill_nan on the
     // paths that launch nothing)
     return COREG_OK;
@@ -1198,8 +1198,10 @@ int collect_stats(coreg_handle* h) {
         HIPCHK(hipEventElapsedTime(&ms, e.a, e.b_is_next_sweep ? h->ev_sweep[e.next_sweep_index].a : e.b));
         h->stats.precompute_ms += ms;
     }
-    HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
-    h->stats.total_gpu_ms = ms;
+    if (h->ev_pre_used > 0) {
+        HIPCHK(hipEventElapsedTime(&ms, h->ev_pre[0].a, h->ev_t1));
+        h->stats.total_gpu_ms = ms;
+    }
     return COREG_OK;
 }
 
@@ -1295,7 +1297,7 @@ int coreg_create(coreg_handle** out, int device) {
     }
     h->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_end[0]) != hipSuccess ||
+        hipEventCreate(&h->ev_end[0]) != hipSuccess ||
         hipEventCreate(&h->ev_end[1]) != hipSuccess || hipEventRecord(h->ev_end[0], h->stream) != hipSuccess ||
         hipEventRecord(h->ev_end[1], h->stream) != hipSuccess ||
         h->pivots.reserve(2 * sizeof(double)) != hipSuccess ||
@@ -1331,7 +1333,6 @@ void coreg_destroy(coreg_handle* h) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
-    if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
     for (int k = 0; k < 2; ++k) {
         if (h->ev_end[k]) (void)hipEventDestroy(h->ev_end[k]);
         h->pin_plan[k].release();

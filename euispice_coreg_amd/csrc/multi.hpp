@@ -39,7 +39,11 @@ struct RcclApi {
     static RcclApi& get() {
         static RcclApi api = [] {
             RcclApi a;
-            const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+            // COREG_RCCL_LIB: the copy that matches the HIP runtime in use (euispice_coreg_amd/_lib.py names PyTorch's
+            // when it has pre-loaded PyTorch's HIP runtime); then whatever the loader finds; then the ROCm install
+            const char* env = std::getenv("COREG_RCCL_LIB");
+            const char* names[] = {env && *env ? env : "librccl.so", "librccl.so", "librccl.so.1",
+                                   "/opt/rocm/lib/librccl.so.1"};
             // a copy some other library of this process has already loaded (PyTorch's) is preferred: two RCCL runtimes
             // in one process would each set up their own transports
             for (const char* n : names) {

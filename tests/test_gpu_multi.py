@@ -142,3 +142,39 @@ def test_bench_launch_threads_two_virtual_devices():
     assert out["map_vs_single_gpu"]["max_abs_diff"] <= 1e-12 and out["map_vs_single_gpu"]["same_argmax"]
     assert len(out["per_rank"]) == 2 and all(r["kernel_ms"] > 0 for r in out["per_rank"])
     assert out["pcie_inclusive"]["identical_to_resident_map"]
+
+
+def test_multi_rccl_in_a_script_that_never_imports_torch(tmp_path):
+    """The plain user script of the reference's README imports no torch: the library then loads PyTorch's HIP runtime
+    itself (two HIP runtimes in one process do not both see the GPU) and the multi-GPU driver dlopens the RCCL that goes
+    with it.  One-rank group on the one GPU; the map equals the single-device one."""
+    import os
+    import subprocess
+    import sys
+    from tests.test_api_cpu import ROOT
+    script = tmp_path / "plain.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from euispice_coreg_amd import _lib\n"
+        "from tests import helpers as H\n"
+        "assert 'torch' not in sys.modules\n"
+        "small, hs, large, hl, _ = H.scene()\n"
+        "grid = _lib.Grid(H.CARR_LON, H.CARR_LAT, (72, 64))\n"
+        "lags = _lib.LagSet(17.0 + np.arange(-6, 6.0), -9.0 + np.arange(-6, 6.0), None, None, None)\n"
+        "with _lib.MultiHandle(device_ids=[0]) as m:\n"
+        "    m.set_small(small); m.prepare_reference_carrington(large, hl, grid, 1.004, 2)\n"
+        "    got = m.sweep_carrington(hs, grid, 1.004, lags)\n"
+        "    print('collective', m.collective, 'mode', m.last_mode)\n"
+        "with _lib.CoregHandle(0) as h:\n"
+        "    h.set_small(small); h.prepare_reference_carrington(large, hl, grid, 1.004, 2)\n"
+        "    want = h.sweep_carrington(hs, grid, 1.004, lags)\n"
+        "assert np.array_equal(got, want, equal_nan=True)\n"
+        "assert 'torch' not in sys.modules\n"
+        "print('ok')\n")
+    env = dict(os.environ, COREG_MULTI_FORCE_RCCL="1")
+    env.pop("COREG_VIRTUAL_DEVICES", None)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "ok" in r.stdout
+    assert "collective rccl mode slices" in r.stdout, r.stdout
