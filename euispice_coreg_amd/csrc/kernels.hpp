@@ -1252,7 +1252,11 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double* lds = (double*)lds_raw;
     constexpr int kWaves = kSweepThreads / 64;
-    __shared__ double wred[kWaves][4];
+    // bounding boxes of the waves, double-buffered by visit parity: a visit then needs two workgroup barriers, not three
+    // (a wave can only write slot k again after the barrier of the visit in between, which every wave reaches after
+    // it has read slot k)
+    __shared__ double wred2[2][kWaves][4];
+    int visit = 0;
 
     // XCD-aware block -> (group, batch): blocks with equal blockIdx % 8 share an XCD (round-robin dispatch), so all
     // lag batches of one tile group land on one XCD and re-use its tiles / image window from that XCD's L2.
@@ -1342,14 +1346,15 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
             mny = fmin(mny, __shfl_xor(mny, o));
             mxy = fmax(mxy, __shfl_xor(mxy, o));
         }
-        __syncthreads();  // previous tile's LDS window and wred are no longer in use
+        double(*wred)[4] = wred2[visit & 1];
+        ++visit;
         if (lane == 0) {
             wred[wave][0] = mnx;
             wred[wave][1] = mxx;
             wred[wave][2] = mny;
             wred[wave][3] = mxy;
         }
-        __syncthreads();
+        __syncthreads();  // every wave has left the previous tile's LDS window; the boxes of this visit are in place
         // the kPointGroups copies of each lag are identical: the first kBlock/64 waves cover every lag
         mnx = fmin(fmin(wred[0][0], wred[1][0]), fmin(wred[2][0], wred[3][0]));
         mxx = fmax(fmax(wred[0][1], wred[1][1]), fmax(wred[2][1], wred[3][1]));
@@ -1389,33 +1394,50 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
         {
           if (in_lds) {
             swept = true;
-            // Stage the window.  The loads are L2 round trips: kStage rows per wave are in flight at a time (one wave
-            // would otherwise wait out ~20 dependent load -> store round trips per visit).
-            constexpr int kStage = 8;
+            // Stage the window.  The loads are L2 round trips: kStage rows x kCols column chunks per wave are in flight
+            // at a time (one wave would otherwise wait out ~20 dependent load -> store round trips per visit).  Deeper
+            // than 8 x 1 measured neutral on the headline (6 x 2, 8 x 2, 12 x 2 = a wave's whole share in one round
+            // trip: 3.07 - 3.10 ms all, the last one at the price of SGPR spills).
+#ifndef COREG_STAGE_ROWS
+#define COREG_STAGE_ROWS 8
+#endif
+#ifndef COREG_STAGE_COLS
+#define COREG_STAGE_COLS 1
+#endif
+            constexpr int kStage = COREG_STAGE_ROWS, kCols = COREG_STAGE_COLS;
             // the quadratic spline uses doubled weights on both axes (see gather_o2)
             const double scale = ORDER == 2 ? 0.25 : 1.0;
             // (the row index is wave-uniform: with it in an SGPR the row addresses are scalar arithmetic)
             const int wave_u = __builtin_amdgcn_readfirstlane(wave);
             for (int r0 = wave_u; r0 < wh; r0 += kWaves * kStage) {
-                for (int c0 = 0; c0 < ww; c0 += 64) {
-                    const int c = c0 + lane;
-                    // (the apron of the run-time orders can reach several samples past the edge: general reflection)
-                    const int gx = ORDER == ORDER_RT ? mirror_far(ox + min(c, ww - 1), W) : mirror_idx(ox + min(c, ww - 1), W);
-                    TS v[kStage];
+                for (int c0 = 0; c0 < ww; c0 += 64 * kCols) {
+                    int gx[kCols];
+#pragma unroll
+                    for (int j = 0; j < kCols; ++j) {
+                        const int c = c0 + 64 * j + lane;
+                        // (the apron of the run-time orders can reach several samples past the edge: general reflection)
+                        gx[j] = ORDER == ORDER_RT ? mirror_far(ox + min(c, ww - 1), W) : mirror_idx(ox + min(c, ww - 1), W);
+                    }
+                    TS v[kStage][kCols];
 #pragma unroll
                     for (int k = 0; k < kStage; ++k) {
                         const int r = min(r0 + k * kWaves, wh - 1);
                         const int gy = ORDER == ORDER_RT ? mirror_far(oy + r, H) : mirror_idx(oy + r, H);
                         const TS* __restrict__ row = img + (size_t)gy * W;
-                        v[k] = row[gx];
-                    }
-                    if (c < ww) {
 #pragma unroll
-                        for (int k = 0; k < kStage; ++k) {
-                            const int r = r0 + k * kWaves;
-                            if (r < wh) {
-                                const double e = (ROUND ? (double)v[k] : (double)v[k] - pivot_b) * scale;
-                                lds[r * pitch + c] = e;
+                        for (int j = 0; j < kCols; ++j) v[k][j] = row[gx[j]];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kCols; ++j) {
+                        const int c = c0 + 64 * j + lane;
+                        if (c < ww) {
+#pragma unroll
+                            for (int k = 0; k < kStage; ++k) {
+                                const int r = r0 + k * kWaves;
+                                if (r < wh) {
+                                    const double e = (ROUND ? (double)v[k][j] : (double)v[k][j] - pivot_b) * scale;
+                                    lds[r * pitch + c] = e;
+                                }
                             }
                         }
                     }
