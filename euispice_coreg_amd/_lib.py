@@ -100,6 +100,7 @@ SYMBOLS = [
     ("coreg_get_pivots", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("coreg_set_pivots", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("coreg_last_stats", C.c_int, [_P, C.POINTER(Stats)]),
+    ("coreg_last_visit_counts", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("coreg_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("coreg_shift_header", C.c_int,
      [_WP, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _WP]),
@@ -493,6 +494,12 @@ class CoregHandle:
         s = Stats()
         self._chk(self._lib.coreg_last_stats(self._h, C.byref(s)))
         return {f: getattr(s, f) for f, _ in Stats._fields_}
+
+    def last_visit_counts(self) -> dict:
+        """(tile, lag batch) visits of the sweep kernel's last launch by kind (diagnostics; waits for the stream)."""
+        c = (C.c_int64 * 4)()
+        self._chk(self._lib.coreg_last_visit_counts(self._h, c))
+        return {"visits": c[0], "lds": c[1], "interior": c[2], "all_finite": c[3]}
 
 
 class _HandleView(CoregHandle):

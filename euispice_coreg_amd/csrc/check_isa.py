@@ -42,6 +42,54 @@ def disassemble(lib):
         return "\n".join(text)
 
 
+def kernel_metadata(lib):
+    """[(kernel name, static LDS bytes, VGPRs, spilled VGPRs + scratch bytes)] from the code objects' metadata notes."""
+    out = []
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fat],
+                       check=True, capture_output=True)
+        listing = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--list", f"--input={fat}"],
+                                 check=True, capture_output=True, text=True).stdout.split()
+        for t in [t for t in listing if t.startswith("hip") and "amdgcn" in t]:
+            subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--unbundle", f"--targets={t}",
+                            f"--input={fat}", f"--output={co}"], check=True, capture_output=True)
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True,
+                                   text=True).stdout
+            cur = {}
+            for ln in notes.splitlines():
+                m = re.match(r"\s*-?\s*\.(\w+):\s*(.+?)\s*$", ln)
+                if not m:
+                    continue
+                key, val = m.group(1), m.group(2).strip("'\"")
+                if key == "agpr_count" and cur.get("name"):  # (first key of a kernel entry: flush the previous one)
+                    out.append(cur)
+                    cur = {}
+                cur[key] = val
+            if cur.get("name"):
+                out.append(cur)
+    return [(k.get("name", "?"), int(k.get("group_segment_fixed_size", 0)), int(k.get("vgpr_count", 0)),
+             int(k.get("vgpr_spill_count", 0)) + int(k.get("private_segment_fixed_size", 0))) for k in out if "name" in k]
+
+
+# dynamic LDS the host asks for at most (coreg_hip.hip: opt_lds_bytes) and what a gfx950 workgroup can have
+MAX_DYNAMIC_LDS = 159 * 1024
+LDS_PER_WORKGROUP = 160 * 1024
+
+
+def check_static_lds(lib):
+    """k_sweep's static LDS + the largest dynamic window must fit a workgroup's LDS (hipFuncSetAttribute fails at run
+    time otherwise, on the GPU box only)."""
+    meta = [m for m in kernel_metadata(lib) if "k_sweep" in m[0]]
+    if not meta:
+        raise SystemExit("check_isa: no k_sweep kernel in the metadata notes (format changed?)")
+    worst = max(meta, key=lambda m: m[1])
+    if worst[1] + MAX_DYNAMIC_LDS > LDS_PER_WORKGROUP:
+        raise SystemExit(f"check_isa: {worst[0]} has {worst[1]} B of static LDS: with the {MAX_DYNAMIC_LDS} B dynamic "
+                         f"window that exceeds the {LDS_PER_WORKGROUP} B of a workgroup")
+    return len(meta), worst[1], max(m[2] for m in meta), sum(1 for m in meta if m[3])
+
+
 def regs(tok):
     """Register numbers named by an operand token such as v12, v[50:51] (VGPRs only)."""
     out = set()
@@ -196,6 +244,9 @@ def check_scalar_loads(text):
 
 
 def main(lib):
+    n_k, lds, vgprs, spilled = check_static_lds(lib)
+    print(f"[check_isa] ok: {n_k} k_sweep kernels, static LDS <= {lds} B (+ {MAX_DYNAMIC_LDS} dynamic <= "
+          f"{LDS_PER_WORKGROUP}), <= {vgprs} VGPRs, {spilled} with VGPR spills or scratch")
     text = disassemble(lib)
     n_s, bad_s = check_scalar_loads(text)
     if bad_s:

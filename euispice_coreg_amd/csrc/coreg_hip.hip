@@ -149,7 +149,7 @@ struct coreg_handle {
     // options
     int64_t opt_crop_reference = 1;
     int64_t opt_taper_min = 128, opt_taper_frac = -1, opt_taper_rounds = 6;  // tapered group shares (pick_taper)
-    int64_t opt_use_lds = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
+    int64_t opt_use_lds = 1, opt_clean_path = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
 
     coreg_stats stats;
     bool stats_pending = false;   // a device-output sweep is in flight: timings are collected on demand
@@ -727,7 +727,7 @@ int reserve_tiles(coreg_handle* h, int n_tiles) {
     HIPCHK(h->tile_list.reserve(n_tiles * sizeof(int)));
     HIPCHK(h->tile_cum.reserve((n_tiles + 1) * sizeof(int)));
     HIPCHK(h->group_first.reserve(2 * 1024 * sizeof(int) + 64));  // [0, 1024): first list entry; [1024, ...): first unit
-    HIPCHK(h->tile_info.reserve(4 * sizeof(long long)));
+    HIPCHK(h->tile_info.reserve(8 * sizeof(long long)));
     HIPCHK(h->tile_bbox.reserve((size_t)n_tiles * 4 * sizeof(double)));
     return COREG_OK;
 }
@@ -808,6 +808,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     a.partials = h->partials.as<double>();
     a.pivots = h->pivots.as<double>();
     a.use_lds = h->opt_use_lds ? 1 : 0;
+    a.clean_path = h->opt_clean_path ? 1 : 0;
     // the dynamic LDS also carries the end-of-kernel point-group reduction: (kPointGroups-1) x 6 x 256 doubles
     const size_t lds_min = (size_t)(kPointGroups - 1) * kNumSums * kBlock * sizeof(double);
     const size_t lds_bytes = std::max(lds_min, a.use_lds ? (size_t)h->opt_lds_bytes : 0);
@@ -1370,6 +1371,8 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
     const std::string n(name);
     if (n == "use_lds") {
         h->opt_use_lds = value ? 1 : 0;
+    } else if (n == "clean_path") {
+        h->opt_clean_path = value ? 1 : 0;
     } else if (n == "tile_w") {
         if (value != 0 && (value < 1 || value > kTilePts || (value & (value - 1)) != 0))
             return fail(h, COREG_EINVAL, "tile_w must be 0 or a power of two <= 1024");
@@ -2414,6 +2417,16 @@ int coreg_car_map(const coreg_wcs2d* from, const coreg_wcs2d* to, int64_t n, con
     CarMapHost m;
     if (m.init(*from, *to)) return 1;
     for (int64_t i = 0; i < n; ++i) m.apply(px[i], py[i], &ox[i], &oy[i]);
+    return COREG_OK;
+}
+
+int coreg_last_visit_counts(coreg_handle* h, int64_t* counts4) {
+    if (!h || !counts4) return COREG_EINVAL;
+    RETCHK(bind_device(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    long long info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (h->tile_info.p) HIPCHK(hipMemcpy(info, h->tile_info.p, 7 * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) counts4[k] = info[3 + k];
     return COREG_OK;
 }
 

@@ -37,6 +37,9 @@ constexpr int kChunk = 4;       // points per scalar-load chunk
 constexpr int kNumSums = 6;     // n, sum a, sum b, sum aa, sum bb, sum ab
 
 // one compacted grid point: lag-independent base coordinates + (reference value - pivot)
+// pad: method 'residus': 1/sqrt(reference); MODE_CAR: third component of the unit vector; otherwise the sums of the
+// point's chunk for the all-finite interior visits of k_sweep (point 4c: sum of the chunk's four a, point 4c + 1: sum of
+// their squares, k_precompute)
 struct __attribute__((aligned(32))) Pt {
     double b0, b1, a, pad;
 };
@@ -687,6 +690,25 @@ __global__ void __launch_bounds__(256) k_precompute(const PrecomputeArgs a) {
         base_pos += tot;
         __syncthreads();
     }
+    if (MODE != MODE_CAR && !a.residus) {
+        // Sums of (reference - pivot) and of its square over every full chunk of kChunk compacted points, in a fixed
+        // order: where k_sweep knows that every sample of a visit is finite (interior window without a NaN) the count
+        // and these two moments do not depend on the lag, and the lanes add them per chunk instead of per sample.
+        // (The stores above are visible: the loop ends with a workgroup barrier.)
+        static_assert(kChunk >= 2, "the two chunk sums live in the pads of the chunk's first two points");
+        Pt* tp = a.pts + tbase;
+        for (int c = threadIdx.x; c < base_pos / kChunk; c += 256) {
+            double sa = tp[c * kChunk].a, saa = sa * sa;
+#pragma unroll
+            for (int k = 1; k < kChunk; ++k) {
+                const double v = tp[c * kChunk + k].a;
+                sa += v;
+                saa = fma(v, v, saa);
+            }
+            tp[c * kChunk].pad = sa;
+            tp[c * kChunk + 1].pad = saa;
+        }
+    }
     for (int o = 32; o > 0; o >>= 1) {
         mn0 = fmin(mn0, __shfl_xor(mn0, o));
         mx0 = fmax(mx0, __shfl_xor(mx0, o));
@@ -714,7 +736,8 @@ __global__ void __launch_bounds__(256) k_precompute(const PrecomputeArgs a) {
 //   tile_list  = non-empty tiles in tile order; tile_cum[k] = work units before list entry k, one unit =
 //   kChunk * kPointGroups points (tile_cum[n_nonempty] = total);  group_first[g] = list entry in which the units of
 //   tile group g start when the total is cut in n_groups equal shares;
-//   info[0] = non-empty tiles, info[1] = kept points, info[2] = work units.
+//   info[0] = non-empty tiles, info[1] = kept points, info[2] = work units;  info[3..6] = 0: k_sweep adds its tile
+//   visits there (all, LDS-staged, interior, all-finite interior -- coreg_last_visit_counts).
 constexpr int kUnitPts = kChunk * kPointGroups;
 // Where tile group g's share of the `total` work units starts.  taper_frac = 0: equal shares.  Otherwise the last
 // taper_frac / 1024 of the groups get linearly smaller shares, down to taper_min / 1024 of a full one, and the others
@@ -802,6 +825,7 @@ __global__ void __launch_bounds__(1024) k_tile_list(const int* __restrict__ tile
         info[0] = n_list;
         info[1] = s_pts;
         info[2] = total;
+        info[3] = info[4] = info[5] = info[6] = 0;
     }
     __syncthreads();
     // first list entry of each group's unit range [g * total / n_groups, ...): largest k with tile_cum[k] <= start
@@ -827,7 +851,7 @@ struct SweepArgs {
     const int* tile_list;
     const int* tile_cum;         // work units before each list entry (see k_tile_list)
     const int* group_first;      // first list entry of each tile group
-    const long long* tile_info;  // [0] = non-empty tiles, [1] = kept points, [2] = work units
+    long long* tile_info;  // [0] = non-empty tiles, [1] = kept points, [2] = work units, [3..6] visit counters
     const double* tile_bbox;
     const double* lane_params;  // SoA [NP][n_slots]; TRANSLATE: X0, Y0; HOMOGRAPHY: h0..h8
     long long n_slots;          // n_batches * 256
@@ -837,6 +861,7 @@ struct SweepArgs {
     double* partials;  // [groups of this launch][kNumSums][n_slots]
     const double* pivots;  // device: [0] mean(reference) (already subtracted in aval), [1] mean(small image)
     int use_lds;
+    int clean_path;    // 1: interior visits whose window holds only finite values skip the sample mask (point_lag, CLEAN)
     int lds_elems;     // capacity of the dynamic LDS window in float64 elements
     LaunchU car_inv;      // MODE_CAR: native (phi, theta) [rad] -> 0-based pixel of the shifted map of this launch
 };
@@ -972,7 +997,11 @@ __device__ __forceinline__ double gather_o2(unsigned win, int pitch, double ux, 
 // pxw, pyw (interior LDS visits): TRANSLATE: lane origin + (0.5 for order 2) - (first tap's offset + window origin), so
 // that trunc(pxw + b0) is the window column of the first tap and fract() gives the spline argument; other modes: the
 // same constant to add to the mapped coordinate.
-template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false, int PITCH = 0>
+// CLEAN (interior LDS visits whose window holds no NaN or infinity, Pearson method): every sample is finite, so the mask
+// is not evaluated and only the three lag-dependent sums are accumulated here; the count and the two moments of the
+// reference are added per chunk by tile_points.
+template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false, int PITCH = 0,
+          bool CLEAN = false>
 __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                           int ox, int oy, int W, int H, double wmax, double hmax, double px0, double py0,
                                           double pxw, double pyw, const H9& hm, const LaunchU& cu, double b0, double b1, double av,
@@ -1023,7 +1052,12 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
         } else {
             bm = v;  // the window holds (pixel - pivot)
         }
-        if (RESID) {
+        if constexpr (CLEAN) {
+            static_assert(!RESID && MODE != MODE_CAR, "no room for the chunk sums in Pt");
+            acc.b += bm;
+            acc.bb = fma(bm, bm, acc.bb);
+            acc.ab = fma(av, bm, acc.ab);
+        } else if (RESID) {
             const double d = (av - (ROUND ? v : v + pivot_b)) * (MODE == MODE_CAR ? 1.0 / sqrt(av) : isa);
             if (isfinite(d)) {
                 acc.n += 1;
@@ -1183,7 +1217,8 @@ __device__ __forceinline__ void load_pt_uniform(const Pt* __restrict__ p, Pt& ou
 
 // Walk this point-group's share of the compacted points of one tile: chunks of kChunk points, chunk c belongs to
 // point-group (c % kPointGroups).  Point data are wave-uniform: the loads below use uniform addresses (scalar loads).
-template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false, int PITCH = 0>
+template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false, int PITCH = 0,
+          bool CLEAN = false>
 __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                             int ox, int oy, int W, int H, double px0, double py0, double pxw,
                                             double pyw, const H9& hm, const LaunchU& cu, const Pt* __restrict__ pts, int p_begin, int p_end,
@@ -1211,9 +1246,15 @@ __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __
                     // (past the group's last chunk this reads up to kPointGroups chunks ahead: inside the allocation
                     // -- DevBuf::reserve pads by 25 % + 256 B -- and never used)
                     SPt nxt = spt_load(k + 1 < kChunk ? q + k + 1 : q + kPointGroups * kChunk, anchor);
-                    point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR, PITCH>(
+                    point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR, PITCH, CLEAN>(
                         acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0, py0, pxw, pyw, hml, cu, spt_f64(cur, 0),
                         spt_f64(cur, 1), spt_f64(cur, 2), spt_f64(cur, 3), pivot_b);
+                    if constexpr (CLEAN) {
+                        // the chunk's lag-independent sums (k_precompute left them in the pads of its first two points)
+                        if (k == 0) acc.a += spt_f64(cur, 3);
+                        if (k == 1) acc.aa += spt_f64(cur, 3);
+                        if (k == kChunk - 1) acc.n += kChunk;
+                    }
                     spt_wait(nxt);  // (already drained by the gather's wait unless no lane sampled)
                     cur = nxt;
                 }
@@ -1228,9 +1269,14 @@ __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __
         for (int k = 0; k < kChunk; ++k) load_pt_uniform(q + k, pt[k]);
 #pragma unroll
         for (int k = 0; k < kChunk; ++k)
-            point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR, PITCH>(acc, win, img, pitch, ox, oy, W, H, wmax, hmax,
-                                                                           px0, py0, pxw, pyw, hm, cu, pt[k].b0, pt[k].b1,
-                                                                           pt[k].a, pt[k].pad, pivot_b);
+            point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR, PITCH, CLEAN>(acc, win, img, pitch, ox, oy, W, H, wmax,
+                                                                                  hmax, px0, py0, pxw, pyw, hm, cu, pt[k].b0,
+                                                                                  pt[k].b1, pt[k].a, pt[k].pad, pivot_b);
+        if constexpr (CLEAN) {
+            acc.n += kChunk;
+            acc.a += pt[0].pad;
+            acc.aa += pt[1].pad;
+        }
     }
 #endif
     // ragged tail (< kChunk points): owned by the point-group next in the rotation
@@ -1255,8 +1301,17 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
     // bounding boxes of the waves, double-buffered by visit parity: a visit then needs two workgroup barriers, not three
     // (a wave can only write slot k again after the barrier of the visit in between, which every wave reaches after
     // it has read slot k)
-    __shared__ double wred2[2][kWaves][4];
+    // (only the first kBlock / 64 waves write: the kPointGroups copies of each lag are identical)
+    constexpr int kLagWaves = kBlock / 64;
+    __shared__ double wred2[2][kLagWaves][4];
+    // "this wave staged a NaN or an infinity", per visit parity like the boxes (written before the barrier that ends the
+    // staging, read after it; the next write of the same slot lies two barriers later)
+    __shared__ int wdirty[2][kWaves];
+    // all-finite interior visits take the variant without the sample mask (point_lag, CLEAN); a float64 image rounded
+    // to float32 (ROUND) could overflow to infinity in the rounding, so it keeps the mask
+    constexpr bool kCleanPath = MODE != MODE_CAR && !RESID && ORDER != ORDER_RT && !(ROUND && sizeof(TS) == 8);
     int visit = 0;
+    int n_vis = 0, n_vis_lds = 0, n_vis_int = 0, n_vis_clean = 0;  // (uniform: tile visits of this workgroup by kind)
 
     // XCD-aware block -> (group, batch): blocks with equal blockIdx % 8 share an XCD (round-robin dispatch), so all
     // lag batches of one tile group land on one XCD and re-use its tiles / image window from that XCD's L2.
@@ -1296,7 +1351,13 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
     const int u_hi = a.group_first[1024 + group + 1];
     const int n_list = (int)a.tile_info[0];
     const double pivot_b = a.pivots[1];
-    const unsigned win = (unsigned)(uintptr_t)lds;  // LDS byte address of the window
+    // LDS byte address of the window (through the LDS address space: the generic pointer's null check would otherwise
+    // be re-evaluated with every sample's address)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned win = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw;
+#else
+    const unsigned win = 0;
+#endif
 
     for (int tl = a.group_first[group]; tl < n_list && u_lo < u_hi; ++tl) {
         const int ubase = a.tile_cum[tl];
@@ -1347,8 +1408,9 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
             mxy = fmax(mxy, __shfl_xor(mxy, o));
         }
         double(*wred)[4] = wred2[visit & 1];
+        int* wdirt = wdirty[visit & 1];
         ++visit;
-        if (lane == 0) {
+        if (lane == 0 && wave < kLagWaves) {
             wred[wave][0] = mnx;
             wred[wave][1] = mxx;
             wred[wave][2] = mny;
@@ -1391,9 +1453,11 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
         const Pt* __restrict__ pts = a.pts + (size_t)tile * kTilePts;
 
         bool swept = false;
+        ++n_vis;
         {
           if (in_lds) {
             swept = true;
+            ++n_vis_lds;
             // Stage the window.  The loads are L2 round trips: kStage rows x kCols column chunks per wave are in flight
             // at a time (one wave would otherwise wait out ~20 dependent load -> store round trips per visit).  Deeper
             // than 8 x 1 measured neutral on the headline (6 x 2, 8 x 2, 12 x 2 = a wave's whole share in one round
@@ -1409,6 +1473,7 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
             const double scale = ORDER == 2 ? 0.25 : 1.0;
             // (the row index is wave-uniform: with it in an SGPR the row addresses are scalar arithmetic)
             const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+            double poison = 0.0;  // becomes NaN when this lane stages a NaN or an infinity (0 * e)
             for (int r0 = wave_u; r0 < wh; r0 += kWaves * kStage) {
                 for (int c0 = 0; c0 < ww; c0 += 64 * kCols) {
                     int gx[kCols];
@@ -1437,26 +1502,41 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
                                 if (r < wh) {
                                     const double e = (ROUND ? (double)v[k][j] : (double)v[k][j] - pivot_b) * scale;
                                     lds[r * pitch + c] = e;
+                                    if (kCleanPath) poison = fma(e, 0.0, poison);
                                 }
                             }
                         }
                     }
                 }
             }
+            if (kCleanPath && interior) {
+                const int dirty = __ballot(poison != poison) != 0ull;  // (all lanes vote: outside the lane-0 branch)
+                if (lane == 0) wdirt[wave] = dirty;
+            }
             __syncthreads();
             bool done = false;
             if constexpr (ORDER != ORDER_RT) {
                 if (interior) {
                     done = true;
+                    bool clean = false;
+                    if constexpr (kCleanPath) clean = a.clean_path && __ballot(wdirt[lane % kWaves] != 0) == 0ull;  // (uniform)
+                    ++n_vis_int;
+                    n_vis_clean += clean ? 1 : 0;
                     if (!pad_lane) {
                         // window-relative lane constants (exact: a small integer is subtracted)
                         const double offx = (ORDER == 2 ? 0.5 : 0.0) - (double)((ORDER == 2 ? 1 : 0) + ox);
                         const double offy = (ORDER == 2 ? 0.5 : 0.0) - (double)((ORDER == 2 ? 1 : 0) + oy);
                         const double pxw = MODE == MODE_TRANSLATE ? px0 + offx : offx;
                         const double pyw = MODE == MODE_TRANSLATE ? py0 + offy : offy;
-                        tile_points<MODE, ORDER, TS, true, ROUND, RESID, true, PITCH>(acc, win, img, pitch, ox, oy, W, H,
-                                                                                      px0, py0, pxw, pyw, hm, a.car_inv,
-                                                                                      pts, p_begin, p_end, pivot_b, pg);
+                        if (kCleanPath && clean) {
+                            tile_points<MODE, ORDER, TS, true, ROUND, RESID, true, PITCH, kCleanPath>(
+                                acc, win, img, pitch, ox, oy, W, H, px0, py0, pxw, pyw, hm, a.car_inv, pts, p_begin, p_end,
+                                pivot_b, pg);
+                        } else {
+                            tile_points<MODE, ORDER, TS, true, ROUND, RESID, true, PITCH>(acc, win, img, pitch, ox, oy, W, H,
+                                                                                          px0, py0, pxw, pyw, hm, a.car_inv,
+                                                                                          pts, p_begin, p_end, pivot_b, pg);
+                        }
                     }
                 }
             }
@@ -1476,6 +1556,12 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
         }
     }
 
+    if (threadIdx.x == 0) {
+        atomicAdd((unsigned long long*)a.tile_info + 3, (unsigned long long)n_vis);
+        atomicAdd((unsigned long long*)a.tile_info + 4, (unsigned long long)n_vis_lds);
+        atomicAdd((unsigned long long*)a.tile_info + 5, (unsigned long long)n_vis_int);
+        atomicAdd((unsigned long long*)a.tile_info + 6, (unsigned long long)n_vis_clean);
+    }
     // add the kPointGroups partial sums of every lag in a fixed order (deterministic), one slab per workgroup
     __syncthreads();  // the window is dead: reuse the LDS
     const int ls = threadIdx.x % kBlock;

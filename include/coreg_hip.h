@@ -224,8 +224,15 @@ int coreg_set_pivots(coreg_handle* h, const double* pivots2);
 /* Waits for an in-flight device-output sweep (those return without synchronising the stream). */
 int coreg_last_stats(coreg_handle* h, coreg_stats* out);
 
+/* Diagnostics of the sweep kernel's LAST launch: (tile, lag batch) visits of its workgroups -- counts4[0] all,
+ * [1] gathered from an LDS window, [2] of those, "interior" (every sample inside the image: no bounds rule),
+ * [3] of those, all-finite windows (no sample mask either).  Waits for the stream. */
+int coreg_last_visit_counts(coreg_handle* h, int64_t* counts4);
+
 /* Tuning / test knobs (name -> integer value). Known names:
  *   "use_lds"      1 (default) stage the gather window in LDS, 0 gather from global memory
+ *   "clean_path"   1 (default) interior visits whose LDS window holds only finite values skip the per-sample mask and
+ *                  take the count and the reference moments from per-chunk sums; 0: always the masked arithmetic
  *   "tile_w"       0 (default, auto) or a power of two in [4, 256]: grid-tile width in points (tile = 1024 pts)
  *   "n_groups"     0 (default, auto): tile groups (partial-sum slabs) per lag batch
  *   "lds_bytes"    dynamic LDS per workgroup for the float64 gather window (default and max 159 KiB)

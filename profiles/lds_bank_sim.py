@@ -16,7 +16,10 @@ What is compared:
     extent, lanes 16-31 the odd ones,
   * a SECOND copy of the window one element further (odd bank pairs), read by the lanes of odd lag rows / columns /
     (row + column) parity,
-  * a de-interleaved window (even columns first, then odd columns).
+  * a de-interleaved window (even columns first, then odd columns),
+  * (SIM_ONLY=pair) a row-pair layout, element (r, c) at (r >> 1) * Q + (r & 1) * R + c with Q odd, which puts rows r and
+    r + 2 an odd number of elements apart (a linear pitch cannot): best 3.61 cycles (16 x 16 patch, Q = 257) -- the roll
+    still mixes row parities inside a lag row -- for 4 more address instructions per sample; not built.
 usage: python profiles/lds_bank_sim.py [n_points]   ->  table on stdout (committed as profiles/r03_lds_bank_sim.txt)
 """
 import os
@@ -102,7 +105,7 @@ def main():
         valid = (li < sw) & (lj < sh)
         return np.where(valid, li, 0), np.where(valid, lj, 0)
 
-    def run(name, sw, sh, pitch, order="row", copy_rule=None, deinterleave=False):
+    def run(name, sw, sh, pitch, order="row", copy_rule=None, deinterleave=False, pair=None):
         li, lj = lanes_of_patch(sw, sh, order)
         cyc, n = 0.0, 0
         for p1 in range(0, 60, sw):
@@ -118,7 +121,9 @@ def main():
                 for dr in range(3):
                     for dc in range(3):
                         c, r = c0 + dc, r0 + dr
-                        if deinterleave:  # even columns first, odd columns after them (half pitch each)
+                        if pair is not None:  # row pairs: element (r, c) at (r >> 1) * Q + (r & 1) * R + c
+                            a = (r >> 1) * pair[0] + (r & 1) * pair[1] + c
+                        elif deinterleave:  # even columns first, odd columns after them (half pitch each)
                             a = r * pitch + (c & 1) * (pitch // 2 + 1) + (c >> 1)
                         else:
                             a = r * pitch + c
@@ -132,6 +137,14 @@ def main():
         return cyc / n
 
     only = os.environ.get("SIM_ONLY")
+    if only == "pair":
+        # rows r and r + 2 an ODD number of elements apart (a linear pitch makes that distance 2 * pitch, always even,
+        # which is what keeps neighbouring lag rows on the same half of the bank pairs)
+        for sw, sh in ((12, 20), (16, 16), (32, 8)):
+            for q, r_ in ((243, 121), (245, 122), (247, 123), (249, 124), (251, 125), (253, 126), (255, 127), (257, 128),
+                          (259, 129), (261, 130), (241, 120)):
+                run(f"{sw} x {sh} row-major, row pairs Q = {q}, R = {r_}", sw, sh, 0, pair=(q, r_))
+        return
     if only == "copy":
         for sw, sh in ((16, 16), (12, 20), (32, 8)):
             for pitch in (128, 160):

@@ -15,7 +15,8 @@ from euispice_coreg_amd import _lib, synthetic  # noqa: E402
 
 
 def main():
-    small, hs, large, hl, truth = synthetic.make_scene()
+    # TUNE_NAN: fraction of NaN pixels in the image to align (bench.py's scene: 0.005; 0 = every LDS window all-finite)
+    small, hs, large, hl, truth = synthetic.make_scene(nan_frac=float(os.environ.get("TUNE_NAN", "0.005")))
     n = int(os.environ.get("TUNE_NLAG", "60"))
     lag = (np.arange(n) - n // 2).astype(np.float64)
     lags = _lib.LagSet(lag, lag, None, None, None)
@@ -28,7 +29,7 @@ def main():
     h.prepare_reference_carrington(large, hl, grid, 1.004, 2)
     base = None
     for cfg in (sys.argv[1:] or [""]):
-        defaults = {"use_lds": 1, "tile_w": 0, "n_groups": 0, "lds_bytes": int(os.environ.get("TUNE_LDS", 159 * 1024)), "patch_w": 0,
+        defaults = {"use_lds": 1, "clean_path": 1, "tile_w": 0, "n_groups": 0, "lds_bytes": int(os.environ.get("TUNE_LDS", 159 * 1024)), "patch_w": 0,
                     "pitch": -1, "taper_frac": -1, "taper_min": 128, "taper_rounds": 6}
         for kv in filter(None, cfg.split(",")):
             k, v = kv.split("=")
@@ -49,7 +50,7 @@ def main():
         am = np.unravel_index(np.nanargmax(out), (n, n)) if np.isfinite(out).any() else (0, 0)
         print(f"{cfg or 'default':40s} kernel {ms[:,0].min():7.3f} ms  pre {ms[:,1].min():6.3f}  gpu {ms[:,2].min():7.3f}  "
               f"wall {ms[:,3].min():7.3f}  argmax {lag[am[0]]:.0f},{lag[am[1]]:.0f}  maxdiff {np.nanmax(np.abs(out-base)) if np.isfinite(out).any() else -1:.1e}  "
-              f"active {st['n_active_points']}", flush=True)
+              f"active {st['n_active_points']}  visits {h.last_visit_counts()}", flush=True)
     h.close()
 
 

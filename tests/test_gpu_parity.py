@@ -531,3 +531,53 @@ def test_point_sharded_sweeps_add_up_to_the_unsharded_map(gpu_handle):
     with pytest.raises(_lib.CoregError):
         gpu_handle.sweep_helioprojective(hs, hs, ls)
         gpu_handle.finalize_sums(np.zeros(6), 1)
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_all_finite_windows_take_the_unmasked_path_and_agree(gpu_handle, order):
+    """Interior visits whose LDS window holds no NaN skip the per-sample mask and take the count and the reference
+    moments from per-chunk sums (kernels.hpp: point_lag CLEAN): same map as the masked arithmetic up to summation
+    rounding, on both geometries, and the oracle's map on an image with a NaN block (windows of both kinds)."""
+    small, hs, large, hl, _ = H.scene(small_n=192, large_n=200, nan_frac=0.0)
+    lags = _lags(9, 8, step=1.5)
+    shape = (160, 144)
+    inner = dict(lonlims=(240.0, 250.0), latlims=(0.0, 10.0))  # a grid well inside the field of view: interior tiles
+    maps, counts = {}, {}
+    for clean in (1, 0):
+        gpu_handle.set_option("clean_path", clean)
+        gpu_handle.set_option("tile_w", 16)
+        try:
+            c = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, shape, order=order, **inner)
+            counts[clean] = [gpu_handle.last_visit_counts()]
+            hp = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order)
+            counts[clean].append(gpu_handle.last_visit_counts())
+            maps[clean] = (c, hp)
+        finally:
+            gpu_handle.set_option("clean_path", 1)
+            gpu_handle.set_option("tile_w", 0)
+    for k in (0, 1):
+        assert counts[1][k]["interior"] > 0 and counts[1][k]["all_finite"] == counts[1][k]["interior"], counts
+        assert counts[0][k]["interior"] == counts[1][k]["interior"] and counts[0][k]["all_finite"] == 0, counts
+        assert np.array_equal(np.isnan(maps[1][k]), np.isnan(maps[0][k]))
+        assert np.nanmax(np.abs(maps[1][k] - maps[0][k])) <= 1e-13
+    H.assert_corr_close(maps[1][0], H.oracle_carrington(small, hs, large, hl, lags, shape, order=order, **inner), 1e-10,
+                        "carrington, all-finite image")
+    H.assert_corr_close(maps[1][1], H.oracle_helio(small, hs, large, hl, lags, order=order), 1e-7,
+                        "helioprojective, all-finite image")
+    # a NaN block: windows that touch it keep the mask, the others do not
+    holed = small.copy()
+    holed[60:100, 80:140] = np.nan
+    gpu_handle.set_option("tile_w", 16)
+    try:
+        got = H.gpu_carrington(gpu_handle, holed, hs, large, hl, lags, shape, order=order, **inner)
+        cc = gpu_handle.last_visit_counts()
+        got_h = H.gpu_helio(gpu_handle, holed, hs, large, hl, lags, order=order)
+        ch = gpu_handle.last_visit_counts()
+    finally:
+        gpu_handle.set_option("tile_w", 0)
+    assert 0 < cc["all_finite"] < cc["interior"], cc
+    assert ch["all_finite"] < ch["interior"], ch
+    H.assert_corr_close(got, H.oracle_carrington(holed, hs, large, hl, lags, shape, order=order, **inner), 1e-10,
+                        "carrington, NaN block")
+    H.assert_corr_close(got_h, H.oracle_helio(holed, hs, large, hl, lags, order=order), 1e-7,
+                        "helioprojective, NaN block")
