@@ -17,6 +17,7 @@ def main():
     scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # image / grid size multiplier
     h = _lib.CoregHandle(-1)
     bad = 0
+    kinds = {"visits": 0, "lds": 0, "interior": 0, "all_finite": 0}  # tile visits of each case's LAST sweep launch
     t0 = time.time()
     for seed in range(seed0, seed0 + n):
         small, hs, large, hl, lags, rng = _random_case(seed, scale)
@@ -45,13 +46,15 @@ def main():
                 got = H.gpu_helio(h, small, hs, large, hl, lags, order=order, serial_semantics=serial,
                                   cdelt_semantics=0 if sem == "intended" else 1)
                 tol = 1e-7
+            for k, v in h.last_visit_counts().items():
+                kinds[k] += v
             H.assert_corr_close(got, want, tol, f"seed={seed} {frame}")
         except AssertionError as e:
             bad += 1
             print(f"FAIL seed={seed} frame={frame} order={order} sem={sem}: {e}", flush=True)
         if (seed - seed0) % 20 == 19:
             print(f"[deep_fuzz] {seed - seed0 + 1}/{n} cases, {bad} failures, {time.time() - t0:.0f} s", flush=True)
-    print(f"[deep_fuzz] done: {n} cases, {bad} failures")
+    print(f"[deep_fuzz] done: {n} cases, {bad} failures; tile visits of the last launches: {kinds}")
     return 1 if bad else 0
 
 
