@@ -151,7 +151,7 @@ def main_threads(args):
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
-    small, hs, large, hl, truth = synthetic.make_scene(float32_exact=not args.small_f64)
+    small, hs, large, hl, truth = synthetic.make_scene(float32_exact=not args.small_f64, nan_frac=args.nan_frac)
     lag1 = lag2 = np.arange(-30, 30, 1, dtype=np.float64)
     lags = _lib.LagSet(lag1, lag2, None, None, None)
     L = lags.size
@@ -215,6 +215,12 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement after the timed region")
     ap.add_argument("--cpu-sample", type=int, default=0, help="lag-points in the CPU sample (0 = 48 per core)")
     ap.add_argument("--use-lds", type=int, default=1)
+    ap.add_argument("--no-all-finite", action="store_true",
+                    help="skip the side measurement on the NaN-free image after the timed region (profiling runs: its "
+                         "sweeps would be averaged into the per-kernel figures)")
+    ap.add_argument("--nan-frac", type=float, default=0.005,
+                    help="fraction of NaN pixels in the image to align (scene default 0.005; 0: every LDS window is "
+                         "all-finite and interior visits run without the sample mask)")
     ap.add_argument("--small-f64", action="store_true",
                     help="image to align with full float64 pixels (not float32-exact): times the TS = double kernel")
     ap.add_argument("--launch", choices=["ranks", "threads"], default="ranks",
@@ -302,7 +308,7 @@ def main():
         block = (np.arange(lo1, hi1)[:, None] * lag2.size + np.arange(lo2, hi2)[None, :]).astype(np.float64).ravel()
     else:
         t0 = time.time()
-        small, hs, large, hl, truth = synthetic.make_scene(float32_exact=not args.small_f64)
+        small, hs, large, hl, truth = synthetic.make_scene(float32_exact=not args.small_f64, nan_frac=args.nan_frac)
         if rank == 0:
             log(f"[bench] scene built in {time.time() - t0:.1f} s; L = {L}")
         # `--streams S` sweeps are in flight at a time, each on its own HIP stream with its own library context: the
@@ -501,6 +507,7 @@ def main():
     visits = None
     if world == 1 and not dry and have_lags and not by_points:
         visits = h.last_visit_counts()
+    if world == 1 and not dry and have_lags and not by_points and not args.no_all_finite:
         filled = np.where(np.isfinite(small_m), small_m, np.float64(np.nanmedian(small_m)))
         if not args.small_f64:
             filled = filled.astype(np.float32).astype(np.float64)
@@ -596,6 +603,7 @@ def main():
                                        if by_points else f"lag-plane blocks x{world} + 1 all-gather ({backend})"),
                        "resident": True, "sweeps_in_flight": n_streams,
                        "small_stored_f32": bool(stats["small_is_f32"]), "use_lds": bool(stats["used_lds"]),
+                       "nan_pixel_fraction": args.nan_frac,
                        "lag_sharding": "points" if by_points else ("blocks" if world > 1 else "none")},
             "one_sweep_in_flight": None if one_in_flight is None else
             {"value": L / one_in_flight, "unit": "lag-points/s", "ms_per_step": 1e3 * one_in_flight},
