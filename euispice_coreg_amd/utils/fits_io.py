@@ -86,29 +86,47 @@ def _data_size(hdr):
     return n, shape
 
 
-def _read_all(path, with_data=True):
+def _decode(hdr, buf, nbytes, shape):
+    """Pixels of an image HDU from its raw big-endian bytes (one pass: the byte swap), None for anything else."""
+    is_image = hdr.get("SIMPLE") is not None or str(hdr.get("XTENSION", "")).strip() == "IMAGE"
+    if not (is_image and shape):
+        return None
+    dt = _BITPIX_DTYPE[int(hdr["BITPIX"])]
+    arr = np.frombuffer(buf, dtype=dt, count=nbytes // np.dtype(dt).itemsize).reshape(shape)  # (a view, no copy)
+    bscale, bzero = hdr.get("BSCALE", 1), hdr.get("BZERO", 0)
+    if bscale != 1 or bzero != 0:
+        return arr.astype(np.float64) * bscale + bzero
+    return arr.astype(arr.dtype.newbyteorder("="))
+
+
+def _read_all(path, with_data=True, only=None):
+    """[(header, data)] of every HDU.  with_data=False: headers only (data skipped with a seek); only=<window>: the pixel
+    data of that HDU alone are read and decoded (an index, or an EXTNAME)."""
     hdus = []
     with open(path, "rb") as f:
+        raw = []
         while True:
             hdr, _ = _read_header(f)
             if hdr is None:
                 break
             nbytes, shape = _data_size(hdr)
             data = None
-            if nbytes and not with_data:
-                f.seek(((nbytes + BLOCK - 1) // BLOCK) * BLOCK, os.SEEK_CUR)
+            padded = ((nbytes + BLOCK - 1) // BLOCK) * BLOCK
+            if nbytes and (not with_data or only is not None):
+                raw.append((f.tell(), nbytes, shape))
+                f.seek(padded, os.SEEK_CUR)
             elif nbytes:
-                buf = f.read(((nbytes + BLOCK - 1) // BLOCK) * BLOCK)
-                is_image = hdr.get("SIMPLE") is not None or str(hdr.get("XTENSION", "")).strip() == "IMAGE"
-                if is_image and shape:
-                    arr = np.frombuffer(buf[:nbytes], dtype=_BITPIX_DTYPE[int(hdr["BITPIX"])]).reshape(shape)
-                    bscale, bzero = hdr.get("BSCALE", 1), hdr.get("BZERO", 0)
-                    if bscale != 1 or bzero != 0:
-                        arr = arr.astype(np.float64) * bscale + bzero
-                    else:
-                        arr = arr.astype(arr.dtype.newbyteorder("="))
-                    data = arr
+                raw.append(None)
+                data = _decode(hdr, f.read(padded), nbytes, shape)
+            else:
+                raw.append(None)
             hdus.append((hdr, data))
+        if with_data and only is not None and hdus:
+            i = _select(hdus, only)
+            if raw[i] is not None:
+                pos, nbytes, shape = raw[i]
+                f.seek(pos)
+                hdus[i] = (hdus[i][0], _decode(hdus[i][0], f.read(nbytes), nbytes, shape))
     return hdus
 
 
@@ -150,7 +168,7 @@ def read_image(path, window=-1):
             return np.array(hdu.data), Header({k: hdu.header[k] for k in hdu.header.keys() if k})
     if not os.path.exists(str(path)):
         raise FileNotFoundError(path)
-    hdus = _read_all(path)
+    hdus = _read_all(path, only=window)
     hdr, data = hdus[_select(hdus, window)]
     if data is None:
         if "ZIMAGE" in hdr or str(hdr.get("XTENSION", "")).strip() == "BINTABLE":

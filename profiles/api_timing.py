@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""
+Wall time of the drop-in call itself -- FITS files in, AlignmentResults out -- on the headline workload (2048^2 image to
+align, 3072^2 reference, float32 FITS, 2048^2 Carrington grid, 60 x 60 CRVAL lags), next to what bench.py's
+`pcie_inclusive` measures underneath it (host arrays in, map out).  Three calls: the first in a process (library load,
+context, buffers), a second Alignment on the same files (warm context; the prepared reference is still resident and its
+file is not decoded again), a third on a different image to align against the same reference.
+usage: python profiles/api_timing.py          ->  one JSON line
+"""
+import cProfile
+import io
+import json
+import os
+import pstats
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from euispice_coreg_amd import synthetic  # noqa: E402
+from euispice_coreg_amd.hdrshift import Alignment  # noqa: E402
+from euispice_coreg_amd.utils import fits_io  # noqa: E402
+
+
+def main():
+    d = tempfile.mkdtemp(prefix="coreg_api_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    small, hs, large, hl, truth = synthetic.make_scene()
+    p_small, p_small2, p_large = (os.path.join(d, n) for n in ("hri.fits", "hri2.fits", "fsi.fits"))
+    fits_io.write_images(p_small, [(None, {}), (small.astype(np.float32), hs)])
+    fits_io.write_images(p_small2, [(None, {}), ((small * 1.01).astype(np.float32), hs)])
+    fits_io.write_images(p_large, [(None, {}), (large.astype(np.float32), hl)])
+    lag = np.arange(-30, 30, 1.0)
+
+    def call(path, profile=False):
+        t0 = time.perf_counter()
+        A = Alignment(large_fov_known_pointing=p_large, small_fov_to_correct=path, lag_crval1=lag, lag_crval2=lag,
+                      lag_cdelt1=[0], lag_cdelt2=[0], lag_crota=[0], parallelism=True)
+        t1 = time.perf_counter()
+        pr = cProfile.Profile() if profile else None
+        if pr:
+            pr.enable()
+        res = A.align_using_carrington(lonlims=(200, 300), latlims=(-20, 20), shape=(2048, 2048))
+        if pr:
+            pr.disable()
+        t2 = time.perf_counter()
+        shift = res.shift_arcsec if hasattr(res, "shift_arcsec") else None
+        top = None
+        if pr:
+            s = io.StringIO()
+            pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(14)
+            top = [ln.strip() for ln in s.getvalue().splitlines() if ln.strip() and ("{" in ln or ".py" in ln)][:14]
+        return {"constructor_ms": 1e3 * (t1 - t0), "align_ms": 1e3 * (t2 - t1),
+                "sweep_kernel_ms": A.last_stats["sweep_kernel_ms"], "shift": None if shift is None else list(map(float, np.ravel(shift)[:2])),
+                "profile_top": top}
+
+    out = {"workload": "headline through Alignment.align_using_carrington, float32 FITS files in /dev/shm",
+           "first_call": call(p_small), "same_files_again": call(p_small),
+           "other_image_same_reference": call(p_small2), "other_image_profiled": call(p_small, profile=True)}
+    # best of a few warm calls
+    warm = [call(p_small2 if i % 2 else p_small)["align_ms"] for i in range(6)]
+    out["warm_calls_ms"] = warm
+    print(json.dumps(out))
+    for p in (p_small, p_small2, p_large):
+        os.remove(p)
+    os.rmdir(d)
+
+
+if __name__ == "__main__":
+    main()
