@@ -860,6 +860,12 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
             case 217: SWP(MODE_TRANSLATE, 2, float, false, false, 217); break;
             default: SW(MODE_TRANSLATE, 2, float, false, false); break;
         }
+    } else if (mode == MODE_TRANSLATE && order == 2 && !h->small_f32 && method != COREG_METHOD_RESIDUS &&
+               (pitch_sel == 89 || pitch_sel == 121 || pitch_sel == 153)) {
+        // the same with float64 pixels (values that are not float32-exact): the three smallest pitches
+        if (pitch_sel == 89) SWP(MODE_TRANSLATE, 2, double, false, false, 89);
+        else if (pitch_sel == 121) SWP(MODE_TRANSLATE, 2, double, false, false, 121);
+        else SWP(MODE_TRANSLATE, 2, double, false, false, 153);
     } else if ((mode == MODE_HOMOGRAPHY_SERIES || mode == MODE_HOMOGRAPHY) && order == 2 && h->small_f32 &&
                method != COREG_METHOD_RESIDUS && (pitch_sel == 89 || pitch_sel == 121)) {
         // the common helioprojective sweeps likewise
