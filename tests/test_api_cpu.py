@@ -196,6 +196,41 @@ def test_fits_header_only_read_and_identity(tmp_path):
     assert fits_io.file_identity((img, {}), -1) is None
 
 
+def test_fits_reader_decodes_the_selected_hdu_of_several(tmp_path):
+    """read_image decodes only the HDU asked for (index from either end, or EXTNAME) of a file with several image HDUs of
+    different types; BSCALE / BZERO scaling (written by hand: the writer never emits it) gives float64 like astropy."""
+    from euispice_coreg_amd.utils import fits_io
+    p = str(tmp_path / "m.fits")
+    a = (np.arange(35, dtype=np.float32).reshape(5, 7) - 3.5) * 1.25
+    b = np.arange(24, dtype=np.int16).reshape(4, 6) - 7
+    c = np.linspace(-1.0, 1.0, 6).reshape(2, 3)
+    fits_io.write_images(p, [(None, {}), (a, {"EXTNAME": "A"}), (b, {"EXTNAME": "B"}), (c, {"EXTNAME": "C"})])
+    for win, want in ((1, a), ("A", a), (-3, a), (2, b), ("B", b), (-1, c), (3, c), ("C", c)):
+        d, h = fits_io.read_image(p, win)
+        assert d.dtype == want.dtype and d.dtype.isnative and np.array_equal(d, want), win
+        assert h["NAXIS1"] == want.shape[1] and h["NAXIS2"] == want.shape[0]
+    everything = fits_io.read_all(p)
+    assert everything[0][0] is None and [None if d is None else d.shape for d, _ in everything[1:]] == [a.shape, b.shape, c.shape]
+    with pytest.raises((KeyError, IndexError)):
+        fits_io.read_image(p, "nope")
+    with pytest.raises(IndexError):
+        fits_io.read_image(p, 7)
+    with pytest.raises(ValueError):
+        fits_io.read_image(p, 0)  # the primary HDU holds no image
+    # BSCALE / BZERO: patch the int16 HDU's header in place (its cards are padded to a whole block)
+    raw = bytearray(open(p, "rb").read())
+    i = raw.index(b"EXTNAME = 'B")
+    end = raw.index(b"END" + b" " * 77, i)
+    cards = ("BSCALE  = %20s" % "0.5").ljust(80) + ("BZERO   = %20s" % "100.0").ljust(80) + "END".ljust(80)
+    assert raw[end + 80:end + 80 + 160] == b" " * 160  # room left in the block
+    raw[end:end + len(cards)] = cards.encode("ascii")
+    p2 = str(tmp_path / "s.fits")
+    open(p2, "wb").write(bytes(raw))
+    d, h = fits_io.read_image(p2, "B")
+    assert d.dtype == np.float64 and np.array_equal(d, b.astype(np.float64) * 0.5 + 100.0) and h["BZERO"] == 100.0
+    assert np.array_equal(fits_io.read_image(p2, "C")[0], c)
+
+
 def test_jitter_session_spreads_images_over_ranks_gloo_world2(tmp_path):
     """N > 1 schedule of the jitter session on CPU (gloo, 2 ranks): images of a sublist are dealt round-robin, ranks
     meet between sublists, every corrected file is written exactly once.  The GPU sweep is replaced by a stand-in
