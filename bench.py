@@ -14,7 +14,9 @@ driver's contract defines `value` on (inputs resident when the timed region star
 map on the host -- is measured right after the timed region AT EVERY N and printed as `pcie_inclusive` (never as
 `value`).  `--streams` (default 2) steps are in flight at a time, each on its own HIP stream and library context, so that
 the drain of one sweep overlaps the start of the next; every step is a complete sweep, and the rate with ONE sweep in
-flight is printed as `one_sweep_in_flight`.
+flight is printed as `one_sweep_in_flight`.  The scene masks 0.5 % of the pixels of the image to align at random (SURVEY
+8d); the same sweep on that image with the NaN pixels filled in is printed as `all_finite_image` (its interior tile
+visits run without the sample mask; `--nan-frac 0` makes that the scene of the whole run, for profiling).
 
 N > 1: `python bench.py --gpus N` starts its own N rank processes (torch.distributed.run, one rank per GPU) as CHILDREN,
 before anything in this process has touched the GPU, and exits with their return code; launched under torchrun
@@ -50,7 +52,8 @@ LDS_CYCLES_PEAK = 256 * 2.4e9            # LDS-array cycles/s, all CUs
 # Counted float64 operations of k_sweep<TRANSLATE, 2> per (grid point, lag), interior-window path (kernels.hpp
 # point_lag): 2 add (coordinate) + 2 fract + 10 (doubled spline weights, 5 per axis) + 3 x (mul + 2 fma) rows
 # + (mul + 2 fma) column + sums (2 add + 3 fma) = 31 float64 instructions = 42 flop with fma = 2.  (The whole loop
-# body is ~38.7 VALU instructions: + 2 cvt, 1 class test, the integer count and address arithmetic.)
+# body is 37 VALU instructions: + 2 cvt, 1 class test, the integer count and 2 of address arithmetic; the same 42 is
+# used for the all-finite variant, which executes 39 of them per sample and the other 3 per chunk of four points.)
 FLOP_PER_POINT_LAG = 42.0
 F64_INSTR_PER_POINT_LAG = 31.0
 
