@@ -497,9 +497,9 @@ class CoregHandle:
 
     def last_visit_counts(self) -> dict:
         """(tile, lag batch) visits of the sweep kernel's last launch by kind (diagnostics; waits for the stream)."""
-        c = (C.c_int64 * 4)()
+        c = (C.c_int64 * 5)()
         self._chk(self._lib.coreg_last_visit_counts(self._h, c))
-        return {"visits": c[0], "lds": c[1], "interior": c[2], "all_finite": c[3]}
+        return {"visits": c[0], "lds": c[1], "interior": c[2], "all_finite": c[3], "refined_lag_points": c[4]}
 
 
 class _HandleView(CoregHandle):

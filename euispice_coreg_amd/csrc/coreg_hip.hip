@@ -117,6 +117,7 @@ struct coreg_handle {
     int pin_img_next = 0;
     // precompute outputs
     DevBuf pts, tile_count, tile_list, tile_cum, group_first, tile_info, tile_bbox;
+    DevBuf counters;  // [0]: lag-points re-evaluated by k_finalize during the sweep in flight (reset by its prologue)
     // sweep
     DevBuf lane_params, out_index, partials, out_dev, tmp_img;
     DevBuf up_f64, up_flag;  // upload staging on the device (float64 copy, exactness flag)
@@ -149,7 +150,7 @@ struct coreg_handle {
     // options
     int64_t opt_crop_reference = 1;
     int64_t opt_taper_min = 128, opt_taper_frac = -1, opt_taper_rounds = 6;  // tapered group shares (pick_taper)
-    int64_t opt_use_lds = 1, opt_clean_path = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
+    int64_t opt_use_lds = 1, opt_clean_path = 1, opt_refine = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
 
     coreg_stats stats;
     bool stats_pending = false;   // a device-output sweep is in flight: timings are collected on demand
@@ -961,7 +962,25 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
         HIPCHK(hipGetLastError());
     }
 
-    FinalizeArgs f;
+    FinalizeArgs f = {};
+    // ill-conditioned lag-points are re-evaluated by k_finalize itself (kernels.hpp: RefineArgs) -- not for method
+    // 'residus' (another statistic), not when the sums are shares of the grid (the other GPUs hold the rest), and not
+    // in a launch whose noise-decided border pixels were taken out of the sums by an extra slab
+    f.refine.enabled = (h->opt_refine && method != COREG_METHOD_RESIDUS && !sharded && !fixing) ? 1 : 0;
+    f.refine.mode = mode;
+    f.refine.order = order;
+    f.refine.small_f32 = h->small_f32 ? 1 : 0;
+    f.refine.img = h->small.p;
+    f.refine.W = h->sW;
+    f.refine.H = h->sH;
+    f.refine.pts = h->pts.as<Pt>();
+    f.refine.tile_list = h->tile_list.as<int>();
+    f.refine.tile_count = h->tile_count.as<int>();
+    f.refine.tile_info = h->tile_info.as<long long>();
+    f.refine.lane_params = params_dev;
+    f.refine.pivots = h->pivots.as<double>();
+    f.refine.car_inv = a.car_inv;
+    f.refine_count = h->counters.as<long long>();  // (null before the first plan: no sweep without one)
     f.partials = h->partials.as<double>();
     f.n_groups = g_per + (fixing ? 1 : 0);
     f.part_stride = n_slots;
@@ -1254,6 +1273,8 @@ int upload_plan(coreg_handle* h, const std::vector<double>& params, const std::v
     p.n_outidx = (long long)outidx.size();
     p.out = out_dev;
     p.n_out = n_out;
+    HIPCHK(h->counters.reserve(8 * sizeof(long long)));
+    p.refine_count = h->counters.as<long long>();
     return COREG_OK;
 }
 
@@ -1325,7 +1346,7 @@ void coreg_destroy(coreg_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->small, &h->ref, &h->pivots, &h->red_sum, &h->red_cnt, &h->t_sin_lon, &h->t_cos_lon,
                       &h->t_cos_lat, &h->t_sin_lat, &h->pts, &h->tile_count, &h->tile_list, &h->tile_cum, &h->group_first,
-                      &h->tile_info, &h->tile_bbox, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
+                      &h->tile_info, &h->tile_bbox, &h->counters, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
                       &h->tmp_img, &h->up_f64, &h->up_flag, &h->border_dev, &h->sums, &h->fin_outidx, &h->border_flags, &h->fix_partial};
     for (DevBuf* b : bufs) b->release();
     for (int k = 0; k < 2; ++k) {
@@ -1379,6 +1400,8 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         h->opt_use_lds = value ? 1 : 0;
     } else if (n == "clean_path") {
         h->opt_clean_path = value ? 1 : 0;
+    } else if (n == "refine") {
+        h->opt_refine = value ? 1 : 0;
     } else if (n == "tile_w") {
         if (value != 0 && (value < 1 || value > kTilePts || (value & (value - 1)) != 0))
             return fail(h, COREG_EINVAL, "tile_w must be 0 or a power of two <= 1024");
@@ -2360,7 +2383,7 @@ int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device,
         HIPCHK(hipGetLastError());
     }
     for (const coreg_handle::PendingFinalize& pf : h->pending_fin) {
-        FinalizeArgs f;
+        FinalizeArgs f = {};  // (refine.enabled = 0: these are sums over shares of the grid)
         f.partials = h->sums.as<double>() + pf.slot_off;
         f.n_groups = 1;
         f.n_slots = pf.n_slots;
@@ -2426,13 +2449,16 @@ int coreg_car_map(const coreg_wcs2d* from, const coreg_wcs2d* to, int64_t n, con
     return COREG_OK;
 }
 
-int coreg_last_visit_counts(coreg_handle* h, int64_t* counts4) {
-    if (!h || !counts4) return COREG_EINVAL;
+int coreg_last_visit_counts(coreg_handle* h, int64_t* counts5) {
+    if (!h || !counts5) return COREG_EINVAL;
     RETCHK(bind_device(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     long long info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (h->tile_info.p) HIPCHK(hipMemcpy(info, h->tile_info.p, 7 * sizeof(long long), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 4; ++k) counts4[k] = info[3 + k];
+    for (int k = 0; k < 4; ++k) counts5[k] = info[3 + k];
+    long long refined = 0;
+    if (h->counters.p) HIPCHK(hipMemcpy(&refined, h->counters.p, sizeof(refined), hipMemcpyDeviceToHost));
+    counts5[4] = refined;
     return COREG_OK;
 }
 

@@ -572,9 +572,11 @@ struct PrologueArgs {
     long long n_outidx;
     double* out;
     long long n_out;
+    long long* refine_count;  // the sweep's counter of re-evaluated lag-points (k_finalize), reset here
 };
 __device__ __forceinline__ void run_prologue(const PrologueArgs& p) {
     if (!p.src) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.refine_count) *p.refine_count = 0;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     for (long long i = i0; i < p.n_params; i += stride) p.dst_params[i] = p.src[i];
@@ -1761,6 +1763,26 @@ __global__ void k_parity_fix_final(const ParityFixArgs a) {
 }
 
 // ---- finalize: add the tile-group slabs in a fixed order, Pearson coefficient (c_correlate.py:39-72) -------------
+// Ill-conditioned lag-points.  The coefficient comes from six sums taken about two GLOBAL pivots (the images' means); when
+// the samples of a lag-point lie far from a pivot compared with their own spread -- a handful of samples, or an overlap
+// inside a flat region -- the subtraction  sum xx - (sum x)^2 / n  cancels (relative error eps * sum xx / (n var)).
+// k_finalize notices (both quotients are at hand) and re-evaluates such a lag-point the way c_correlate.py:39-72 does:
+// means first, centred sums second, over every compacted point, with the arithmetic of the sweep's per-point path.
+struct RefineArgs {
+    int enabled;  // 0: never (method 'residus', grid shares across GPUs, launches with noise-decided border pixels)
+    int mode, order, small_f32;
+    const void* img;  // image to align, float / double [H][W]
+    int W, H;
+    const Pt* pts;
+    const int* tile_list;
+    const int* tile_count;
+    const long long* tile_info;
+    const double* lane_params;  // SoA [2 or 9][n_slots]
+    const double* pivots;
+    LaunchU car_inv;
+};
+constexpr double kRefineCond = 1e5;  // sum xx / (n var) above which a lag-point is re-evaluated (error below: < 1e-11)
+
 struct FinalizeArgs {
     const double* partials;
     int n_groups;  // number of partial slabs (tile groups x point groups)
@@ -1776,13 +1798,104 @@ struct FinalizeArgs {
     double* sums_out;
     long long sums_stride, sums_off;
     long long part_stride;  // distance between the six sums of a slab (n_slots, or sums_stride when reading reduced sums)
+    RefineArgs refine;
+    long long* refine_count;  // device counter of re-evaluated lag-points (diagnostics), or null
 };
 constexpr int kFinLanes = 16;  // threads per lag slot in k_finalize
 constexpr int kFinSlots = 16;  // lag slots per block: 256-thread blocks, 16 of them per 256-lag batch -- a sweep of two
                                // batches (one GPU's share of the headline at N = 8) still spreads over 32 CUs
-__global__ void __launch_bounds__(kFinSlots * kFinLanes) k_finalize(const FinalizeArgs a) {
+constexpr int kFinThreads = kFinSlots * kFinLanes;
+
+// One lag-point, two centred passes over all compacted points, by the whole block (fixed thread -> point assignment and
+// a fixed reduction tree: deterministic).  point_lag on a zeroed accumulator hands back (valid, a - pivot, sample - pivot).
+template <int MODE, int ORDER, typename TS>
+__device__ double refine_slot(const FinalizeArgs& a, long long slot, double (*sh)[kFinThreads]) {
+    constexpr bool ROUND = MODE != MODE_TRANSLATE;
+    const RefineArgs& r = a.refine;
+    double px0 = 0.0, py0 = 0.0;
+    H9 hm;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) hm.h[k] = 0.0;
+    if (MODE == MODE_TRANSLATE) {
+        px0 = r.lane_params[slot];
+        py0 = r.lane_params[a.n_slots + slot];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) hm.h[k] = r.lane_params[(long long)k * a.n_slots + slot];
+    }
+    const TS* __restrict__ img = (const TS*)r.img;
+    const double wmax = (double)(r.W - 1), hmax = (double)(r.H - 1), pivot_b = r.pivots[1];
+    const int n_list = (int)r.tile_info[0];
+    double mean_a = 0.0, mean_b = 0.0, res = __builtin_nan("");
+    for (int pass = 0; pass < 2; ++pass) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;  // pass 0: n, sum a, sum b; pass 1: sum da^2, sum db^2, sum da db
+        for (int tl = 0; tl < n_list; ++tl) {
+            const int tile = r.tile_list[tl];
+            const int cnt = r.tile_count[tile];
+            const Pt* __restrict__ pts = r.pts + (size_t)tile * kTilePts;
+            for (int p = threadIdx.x; p < cnt; p += kFinThreads) {
+                const Pt pt = pts[p];
+                Acc t = {0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                point_lag<MODE, ORDER, TS, false, ROUND, false>(t, 0u, img, 0, 0, 0, r.W, r.H, wmax, hmax, px0, py0, 0.0, 0.0,
+                                                                hm, r.car_inv, pt.b0, pt.b1, pt.a, pt.pad, pivot_b);
+                if (t.n) {
+                    if (pass == 0) {
+                        s0 += 1.0;
+                        s1 += t.a;
+                        s2 += t.b;
+                    } else {
+                        const double da = t.a - mean_a, db = t.b - mean_b;
+                        s0 = fma(da, da, s0);
+                        s1 = fma(db, db, s1);
+                        s2 = fma(da, db, s2);
+                    }
+                }
+            }
+        }
+        sh[0][threadIdx.x] = s0;
+        sh[1][threadIdx.x] = s1;
+        sh[2][threadIdx.x] = s2;
+        __syncthreads();
+        for (int o = kFinThreads / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+            }
+            __syncthreads();
+        }
+        const double t0 = sh[0][0], t1 = sh[1][0], t2 = sh[2][0];
+        __syncthreads();
+        if (pass == 0) {
+            if (!(t0 > 0.0)) break;  // (uniform)
+            mean_a = t1 / t0;
+            mean_b = t2 / t0;
+        } else {
+            res = t2 / sqrt(t0 * t1);
+        }
+    }
+    return res;
+}
+template <int MODE, typename TS>
+__device__ double refine_order(const FinalizeArgs& a, long long slot, double (*sh)[kFinThreads]) {
+    if (a.refine.order == 2) return refine_slot<MODE, 2, TS>(a, slot, sh);
+    if (a.refine.order == 1) return refine_slot<MODE, 1, TS>(a, slot, sh);
+    return refine_slot<MODE, ORDER_RT, TS>(a, slot, sh);
+}
+template <typename TS>
+__device__ double refine_mode(const FinalizeArgs& a, long long slot, double (*sh)[kFinThreads]) {
+    switch (a.refine.mode) {
+        case MODE_TRANSLATE: return refine_order<MODE_TRANSLATE, TS>(a, slot, sh);
+        case MODE_HOMOGRAPHY: return refine_order<MODE_HOMOGRAPHY, TS>(a, slot, sh);
+        case MODE_HOMOGRAPHY_SERIES: return refine_order<MODE_HOMOGRAPHY_SERIES, TS>(a, slot, sh);
+        default: return refine_order<MODE_CAR, TS>(a, slot, sh);
+    }
+}
+
+__global__ void __launch_bounds__(kFinThreads) k_finalize(const FinalizeArgs a) {
     // kFinLanes threads per slot each add every kFinLanes-th slab, then one adds them in order
     __shared__ double red[kFinLanes - 1][kNumSums][kFinSlots];
+    __shared__ int s_flag[kFinSlots];
+    __shared__ double s_ref[3][kFinThreads];
     const int ls = threadIdx.x % kFinSlots, j = threadIdx.x / kFinSlots;
     const long long slot = (long long)blockIdx.x * kFinSlots + ls;
     double s[kNumSums];
@@ -1800,32 +1913,49 @@ __global__ void __launch_bounds__(kFinSlots * kFinLanes) k_finalize(const Finali
         for (int k = 0; k < kNumSums; ++k) red[j - 1][k][ls] = s[k];
     }
     __syncthreads();
-    if (j != 0 || slot >= a.n_slots) return;
-    for (int g = 0; g < kFinLanes - 1; ++g) {
+    int flag = 0;
+    if (j == 0 && slot < a.n_slots) {
+        for (int g = 0; g < kFinLanes - 1; ++g) {
 #pragma unroll
-        for (int k = 0; k < kNumSums; ++k) s[k] += red[g][k][ls];
-    }
-    if (a.sums_out) {
-#pragma unroll
-        for (int k = 0; k < kNumSums; ++k) a.sums_out[(size_t)k * a.sums_stride + a.sums_off + slot] = s[k];
-        return;
-    }
-    const long long idx = a.out_index[slot];
-    if (idx < 0) return;
-    const double n = s[0];
-    double r = __builtin_nan("");
-    if (a.residus) {
-        if (n == (double)a.n_required) {
-            const double m = s[2] / n;
-            r = sqrt(fmax(s[4] / n - m * m, 0.0));
+            for (int k = 0; k < kNumSums; ++k) s[k] += red[g][k][ls];
         }
-    } else if (n > 0.0) {
-        const double cov = s[5] - s[1] * s[2] / n;
-        const double va = s[3] - s[1] * s[1] / n;
-        const double vb = s[4] - s[2] * s[2] / n;
-        r = cov / sqrt(va * vb);
+        if (a.sums_out) {
+#pragma unroll
+            for (int k = 0; k < kNumSums; ++k) a.sums_out[(size_t)k * a.sums_stride + a.sums_off + slot] = s[k];
+        } else {
+            const long long idx = a.out_index[slot];
+            if (idx >= 0) {
+                const double n = s[0];
+                double r = __builtin_nan("");
+                if (a.residus) {
+                    if (n == (double)a.n_required) {
+                        const double m = s[2] / n;
+                        r = sqrt(fmax(s[4] / n - m * m, 0.0));
+                    }
+                } else if (n > 0.0) {
+                    const double cov = s[5] - s[1] * s[2] / n;
+                    const double va = s[3] - s[1] * s[1] / n;
+                    const double vb = s[4] - s[2] * s[2] / n;
+                    r = cov / sqrt(va * vb);
+                    // (negated comparisons: a NaN or non-positive variance is flagged too)
+                    flag = !(va > 0.0) || !(vb > 0.0) || !(s[3] <= kRefineCond * va) || !(s[4] <= kRefineCond * vb);
+                }
+                a.out[idx - a.lag_begin] = r;
+            }
+        }
     }
-    a.out[idx - a.lag_begin] = r;
+    if (!a.refine.enabled) return;  // (uniform)
+    if (j == 0) s_flag[ls] = flag;
+    __syncthreads();
+    for (int q = 0; q < kFinSlots; ++q) {
+        if (!s_flag[q]) continue;  // (uniform: shared)
+        const long long sq = (long long)blockIdx.x * kFinSlots + q;
+        const double r2 = a.refine.small_f32 ? refine_mode<float>(a, sq, s_ref) : refine_mode<double>(a, sq, s_ref);
+        if (threadIdx.x == 0) {
+            a.out[a.out_index[sq] - a.lag_begin] = r2;
+            if (a.refine_count) atomicAdd((unsigned long long*)a.refine_count, 1ull);
+        }
+    }
 }
 
 }  // namespace coreg

@@ -224,15 +224,20 @@ int coreg_set_pivots(coreg_handle* h, const double* pivots2);
 /* Waits for an in-flight device-output sweep (those return without synchronising the stream). */
 int coreg_last_stats(coreg_handle* h, coreg_stats* out);
 
-/* Diagnostics of the sweep kernel's LAST launch: (tile, lag batch) visits of its workgroups -- counts4[0] all,
- * [1] gathered from an LDS window, [2] of those, "interior" (every sample inside the image: no bounds rule),
- * [3] of those, all-finite windows (no sample mask either).  Waits for the stream. */
-int coreg_last_visit_counts(coreg_handle* h, int64_t* counts4);
+/* Diagnostics.  counts5[0..3]: (tile, lag batch) visits of the sweep kernel's workgroups in the LAST launch of the last
+ * sweep -- all; gathered from an LDS window; of those, "interior" (every sample inside the image: no bounds rule); of
+ * those, all-finite windows (no sample mask either).  counts5[4]: lag-points of the WHOLE last sweep whose six sums
+ * were too ill-conditioned for the one-pass Pearson formula and were re-evaluated with centred sums ("refine").
+ * Waits for the stream. */
+int coreg_last_visit_counts(coreg_handle* h, int64_t* counts5);
 
 /* Tuning / test knobs (name -> integer value). Known names:
  *   "use_lds"      1 (default) stage the gather window in LDS, 0 gather from global memory
  *   "clean_path"   1 (default) interior visits whose LDS window holds only finite values skip the per-sample mask and
  *                  take the count and the reference moments from per-chunk sums; 0: always the masked arithmetic
+ *   "refine"       1 (default) lag-points whose sums are ill-conditioned (sum xx / (n var) > 1e5: a handful of samples, an
+ *                  overlap inside a flat region) are re-evaluated with means first and centred sums second, as
+ *                  c_correlate.py:39-72 does; 0: the one-pass formula everywhere
  *   "tile_w"       0 (default, auto) or a power of two in [4, 256]: grid-tile width in points (tile = 1024 pts)
  *   "n_groups"     0 (default, auto): tile groups (partial-sum slabs) per lag batch
  *   "lds_bytes"    dynamic LDS per workgroup for the float64 gather window (default and max 159 KiB)

@@ -17,7 +17,8 @@ def main():
     scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # image / grid size multiplier
     h = _lib.CoregHandle(-1)
     bad = 0
-    kinds = {"visits": 0, "lds": 0, "interior": 0, "all_finite": 0}  # tile visits of each case's LAST sweep launch
+    # tile visits of each case's LAST sweep launch; lag-points re-evaluated with centred sums (whole sweeps)
+    kinds = {"visits": 0, "lds": 0, "interior": 0, "all_finite": 0, "refined_lag_points": 0}
     t0 = time.time()
     for seed in range(seed0, seed0 + n):
         small, hs, large, hl, lags, rng = _random_case(seed, scale)

@@ -581,3 +581,33 @@ def test_all_finite_windows_take_the_unmasked_path_and_agree(gpu_handle, order):
                         "carrington, NaN block")
     H.assert_corr_close(got_h, H.oracle_helio(holed, hs, large, hl, lags, order=order), 1e-7,
                         "helioprojective, NaN block")
+
+
+def test_ill_conditioned_lag_points_are_re_evaluated_with_centred_sums(gpu_handle):
+    """Six active grid points, lag-points with a handful of samples whose coefficient is +-1 by construction: the
+    one-pass formula about the global pivots loses seven digits there (1.6e-9 on this case, tests/deep_fuzz.py seed
+    80246); k_finalize notices and re-evaluates those lag-points the way c_correlate.py:39-72 does."""
+    from tests.test_gpu_fuzz import _random_case
+    small, hs, large, hl, lags, _ = _random_case(80246)
+    lags = list(lags)
+    lags[3] = [0.0, -0.02]
+    grid = dict(shape=(23, 25), lonlims=(200.0, 234.0), latlims=(-72.0, 22.0), order=2)
+    want = H.oracle_carrington(small, hs, large, hl, lags, grid["shape"], grid["lonlims"], grid["latlims"], order=2,
+                               solar_r=(1.004,))
+    got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, **grid)
+    counts = gpu_handle.last_visit_counts()
+    assert gpu_handle.last_stats()["n_active_points"] == 6
+    assert counts["refined_lag_points"] > 0, counts
+    H.assert_corr_close(got, want, 1e-13, "ill-conditioned lag-points, refined")
+    gpu_handle.set_option("refine", 0)
+    try:
+        raw = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, **grid)
+        assert gpu_handle.last_visit_counts()["refined_lag_points"] == 0
+    finally:
+        gpu_handle.set_option("refine", 1)
+    assert np.array_equal(np.isnan(raw), np.isnan(want))
+    assert 1e-10 < np.nanmax(np.abs(raw - want)) < 1e-7  # what the one-pass formula gives here
+    # a well-conditioned sweep is not touched
+    small, hs, large, hl, _ = H.scene()
+    H.gpu_carrington(gpu_handle, small, hs, large, hl, _lags(7, 6), (72, 64))
+    assert gpu_handle.last_visit_counts()["refined_lag_points"] == 0
