@@ -150,7 +150,7 @@ struct coreg_handle {
     // options
     int64_t opt_crop_reference = 1;
     int64_t opt_taper_min = 128, opt_taper_frac = -1, opt_taper_rounds = 6;  // tapered group shares (pick_taper)
-    int64_t opt_use_lds = 1, opt_clean_path = 1, opt_refine = 1, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
+    int64_t opt_use_lds = 1, opt_clean_path = 1, opt_refine = 1, opt_refine_cond_log10 = 5, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
 
     coreg_stats stats;
     bool stats_pending = false;   // a device-output sweep is in flight: timings are collected on demand
@@ -967,6 +967,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     // 'residus' (another statistic), not when the sums are shares of the grid (the other GPUs hold the rest), and not
     // in a launch whose noise-decided border pixels were taken out of the sums by an extra slab
     f.refine.enabled = (h->opt_refine && method != COREG_METHOD_RESIDUS && !sharded && !fixing) ? 1 : 0;
+    f.refine.cond = std::pow(10.0, (double)h->opt_refine_cond_log10);
     f.refine.mode = mode;
     f.refine.order = order;
     f.refine.small_f32 = h->small_f32 ? 1 : 0;
@@ -1402,6 +1403,9 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         h->opt_clean_path = value ? 1 : 0;
     } else if (n == "refine") {
         h->opt_refine = value ? 1 : 0;
+    } else if (n == "refine_cond_log10") {
+        if (value < -3 || value > 15) return fail(h, COREG_EINVAL, "refine_cond_log10 must be in [-3, 15]");
+        h->opt_refine_cond_log10 = value;
     } else if (n == "tile_w") {
         if (value != 0 && (value < 1 || value > kTilePts || (value & (value - 1)) != 0))
             return fail(h, COREG_EINVAL, "tile_w must be 0 or a power of two <= 1024");

@@ -1770,6 +1770,7 @@ __global__ void k_parity_fix_final(const ParityFixArgs a) {
 // means first, centred sums second, over every compacted point, with the arithmetic of the sweep's per-point path.
 struct RefineArgs {
     int enabled;  // 0: never (method 'residus', grid shares across GPUs, launches with noise-decided border pixels)
+    double cond;  // sum xx / (n var) above which a lag-point is re-evaluated (kRefineCond; tests lower it)
     int mode, order, small_f32;
     const void* img;  // image to align, float / double [H][W]
     int W, H;
@@ -1781,7 +1782,7 @@ struct RefineArgs {
     const double* pivots;
     LaunchU car_inv;
 };
-constexpr double kRefineCond = 1e5;  // sum xx / (n var) above which a lag-point is re-evaluated (error below: < 1e-11)
+constexpr double kRefineCond = 1e5;  // default threshold on sum xx / (n var) (one-pass error below it: < 1e-11)
 
 struct FinalizeArgs {
     const double* partials;
@@ -1938,7 +1939,7 @@ __global__ void __launch_bounds__(kFinThreads) k_finalize(const FinalizeArgs a) 
                     const double vb = s[4] - s[2] * s[2] / n;
                     r = cov / sqrt(va * vb);
                     // (negated comparisons: a NaN or non-positive variance is flagged too)
-                    flag = !(va > 0.0) || !(vb > 0.0) || !(s[3] <= kRefineCond * va) || !(s[4] <= kRefineCond * vb);
+                    flag = !(va > 0.0) || !(vb > 0.0) || !(s[3] <= a.refine.cond * va) || !(s[4] <= a.refine.cond * vb);
                 }
                 a.out[idx - a.lag_begin] = r;
             }

@@ -238,6 +238,7 @@ int coreg_last_visit_counts(coreg_handle* h, int64_t* counts5);
  *   "refine"       1 (default) lag-points whose sums are ill-conditioned (sum xx / (n var) > 1e5: a handful of samples, an
  *                  overlap inside a flat region) are re-evaluated with means first and centred sums second, as
  *                  c_correlate.py:39-72 does; 0: the one-pass formula everywhere
+ *   "refine_cond_log10"  5 (default): log10 of that threshold; -1 re-evaluates every lag-point (tests)
  *   "tile_w"       0 (default, auto) or a power of two in [4, 256]: grid-tile width in points (tile = 1024 pts)
  *   "n_groups"     0 (default, auto): tile groups (partial-sum slabs) per lag batch
  *   "lds_bytes"    dynamic LDS per workgroup for the float64 gather window (default and max 159 KiB)

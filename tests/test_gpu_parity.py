@@ -611,3 +611,48 @@ def test_ill_conditioned_lag_points_are_re_evaluated_with_centred_sums(gpu_handl
     small, hs, large, hl, _ = H.scene()
     H.gpu_carrington(gpu_handle, small, hs, large, hl, _lags(7, 6), (72, 64))
     assert gpu_handle.last_visit_counts()["refined_lag_points"] == 0
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("f32_exact", [True, False])
+def test_re_evaluating_every_lag_point_gives_the_oracle_map(gpu_handle, order, f32_exact):
+    """The two-pass re-evaluation of k_finalize (refine_slot) forced onto EVERY lag-point (threshold 0.1): all three
+    frames, compile-time and run-time spline orders, float32 and float64 pixels, CROTA / CDELT lags -- the maps the
+    oracle gives, and the maps of the one-pass sums to summation rounding."""
+    small, hs, large, hl, _ = H.scene(small_n=72, large_n=112, float32_exact=f32_exact)
+    lags = _lags(4, 3, crota=[0.0, 0.3], cdelt1=[0.0, 0.03])
+    from euispice_coreg_amd import _lib, synthetic
+    cs, chs, cl, chl, _ = synthetic.make_car_scene(small_shape=(60, 70), large_shape=(90, 100))
+    clags = (np.array([0.0, 0.018]), np.array([-0.011, 0.004]), None, None, None)
+    cls = _lib.LagSet(*clags)
+
+    def run_all():
+        out = [H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, (40, 36), order=order)]
+        n_ref = [gpu_handle.last_visit_counts()["refined_lag_points"]]
+        # (lags that do not pass through zero: no noise-decided border pixels, whose launches are not re-evaluated)
+        out.append(H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order))
+        n_ref.append(gpu_handle.last_visit_counts()["refined_lag_points"])
+        gpu_handle.set_small(cs)
+        gpu_handle.set_reference_on_grid(np.asarray(cl, dtype=np.float32))
+        out.append(gpu_handle.sweep_helioprojective(chl, chs, cls, order=order).reshape(cls.shape + (1,)))
+        n_ref.append(gpu_handle.last_visit_counts()["refined_lag_points"])
+        return out, n_ref
+
+    one_pass, n0 = run_all()
+    gpu_handle.set_option("refine_cond_log10", -1)
+    try:
+        two_pass, n1 = run_all()
+    finally:
+        gpu_handle.set_option("refine_cond_log10", 5)
+    assert n0 == [0, 0, 0]
+    for k, (a, b) in enumerate(zip(one_pass, two_pass)):
+        assert n1[k] == int(np.isfinite(b).sum()) or n1[k] >= int(np.isfinite(b).sum()), (k, n1)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), k
+        assert np.nanmax(np.abs(a - b)) <= 1e-12, (k, np.nanmax(np.abs(a - b)))
+    H.assert_corr_close(two_pass[0], H.oracle_carrington(small, hs, large, hl, lags, (40, 36), order=order), 1e-9,
+                        f"carrington order={order}, every lag-point re-evaluated")
+    H.assert_corr_close(two_pass[1], H.oracle_helio(small, hs, large, hl, lags, order=order), 1e-7,
+                        f"helio order={order}, every lag-point re-evaluated")
+    H.assert_corr_close(two_pass[2], H.oracle_helio(cs.astype(np.float64), chs, cl.astype(np.float64), chl, clags, order=order,
+                                                    parallelism=False, unit_lag="deg"), 1e-7,
+                        f"CAR order={order}, every lag-point re-evaluated")
