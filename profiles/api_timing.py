@@ -62,6 +62,29 @@ def main():
     # best of a few warm calls
     warm = [call(p_small2 if i % 2 else p_small)["align_ms"] for i in range(6)]
     out["warm_calls_ms"] = warm
+    # the two host stages of a warm call on their own (no profiler: cProfile inflates the many small scipy calls)
+    from euispice_coreg_amd.hdrshift.alignment_results import AlignmentResults
+    A = Alignment(large_fov_known_pointing=p_large, small_fov_to_correct=p_small, lag_crval1=lag, lag_crval2=lag,
+                  lag_cdelt1=[0], lag_cdelt2=[0], lag_crota=[0], parallelism=True)
+    corr = A.align_using_carrington(lonlims=(200, 300), latlims=(-20, 20), shape=(2048, 2048), return_type="corr")
+    t = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        AlignmentResults(corr, lag, lag, [0], [0], [0], "arcsec")
+        t.append(1e3 * (time.perf_counter() - t0))
+    out["gaussian_fit_ms"] = min(t)
+    t = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        fits_io.read_image(p_small, -1)
+        t.append(1e3 * (time.perf_counter() - t0))
+    out["fits_decode_small_ms"] = min(t)
+    t = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        A.align_using_carrington(lonlims=(200, 300), latlims=(-20, 20), shape=(2048, 2048), return_type="corr")
+        t.append(1e3 * (time.perf_counter() - t0))
+    out["align_without_fit_ms"] = min(t)
     print(json.dumps(out))
     for p in (p_small, p_small2, p_large):
         os.remove(p)
