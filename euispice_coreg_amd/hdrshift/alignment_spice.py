@@ -141,20 +141,31 @@ class AlignmentSpice(Alignment):
 
     def _prepare_spice_from_l2(self, cube, hdr):
         """alignment_spice.py:250-323."""
-        data = np.array(cube, dtype=np.float64)
-        if data.ndim != 4:
+        cube = np.asarray(cube)
+        if cube.ndim != 4:
             raise ValueError("a SPICE L2 window is a 4-D cube [time, wavelength, y, x]")
         ymin, ymax = spice_header.vertical_edges_limits(hdr)
         self.hdr_small = spice_header.celestial_header(hdr)
-        data[:, :, :ymin, :] = np.nan
-        data[:, :, ymax:, :] = np.nan
+        # np.nansum(float64(cube)[0, sel], axis=0) of the reference, plane by plane in the same order (a reduction over
+        # the outer axis is a sequential accumulation, so the sums are the same to the bit) without a float64 copy of the
+        # whole cube; the rows outside [ymin, ymax) are NaN in the result either way
         if isinstance(self.wavelength_interval_to_sum, str) and self.wavelength_interval_to_sum == "all":
-            self.data_small = np.nansum(data[0, :, :, :], axis=0)
+            planes = cube[0]
         elif isinstance(self.wavelength_interval_to_sum, (list, tuple)):
             wave = spice_header.wavelengths_angstrom(hdr)
             lo, hi = (_angstrom(v) for v in self.wavelength_interval_to_sum)
-            sel = np.logical_and(wave >= lo, wave <= hi)
-            self.data_small = np.nansum(data[0, sel, :, :], axis=0)
+            planes = cube[0][np.logical_and(wave >= lo, wave <= hi)]
+        else:
+            planes = None
+        if planes is not None:
+            self.data_small = np.zeros(cube.shape[2:], dtype=np.float64) if len(planes) == 0 else None
+            for plane in planes:
+                q = plane.astype(np.float64)
+                np.copyto(q, 0.0, where=np.isnan(q))
+                if self.data_small is None:
+                    self.data_small = q
+                else:
+                    self.data_small += q
         else:
             raise ValueError("wavelength_interval_to_sum must be a [wave_min * u.angstrom, wave_max * u.angstrom] "
                              "or 'all' str ")
@@ -182,8 +193,7 @@ class AlignmentSpice(Alignment):
 
     def _prepare_spice_from_l3(self, cube, hdr, coeff):
         """alignment_spice.py:340-355.  (NAXIS1/2 are set here; the reference leaves them out of the 2-D header.)"""
-        data = np.array(cube, dtype=np.float64)
-        self.data_small = data[coeff, ...]
+        self.data_small = np.array(np.asarray(cube)[coeff, ...], dtype=np.float64)  # (only the plane asked for)
         ymin, ymax = spice_header.vertical_edges_limits(hdr)
         self.data_small[:ymin, :] = np.nan
         self.data_small[ymax:, :] = np.nan

@@ -91,6 +91,38 @@ def test_prepare_spice_from_l2_collapses_cube():
         AlignmentSpice((large, hl), (cube, h4), level=None)._extract_spice_data_header(level=None)
 
 
+def test_prepare_spice_from_l2_equals_the_reference_nansum_to_the_bit():
+    """The plane-by-plane collapse equals the reference's np.nansum(float64(cube)[0, sel], axis=0)
+    (alignment_spice.py:250-323) bit for bit -- NaN, infinity and signed zeros included -- for big-endian float32 cubes,
+    a wavelength interval, and an interval that selects nothing."""
+    from euispice_coreg_amd import synthetic
+    from euispice_coreg_amd.hdrshift import AlignmentSpice
+    from euispice_coreg_amd.utils import spice_header as S
+    cube, h4, large, hl, _ = synthetic.make_spice_l2()
+    rng = np.random.default_rng(3)
+    cube = np.array(cube, dtype=np.float32)
+    cube[rng.random(cube.shape) < 0.05] = np.nan
+    cube[0, 3, 40, 7] = np.inf
+    cube[0, 4, 41, 9] = -0.0
+    cube[0, :, 42, 11] = np.nan  # a pixel with no finite plane: sum 0
+    ymin, ymax = S.vertical_edges_limits(h4)
+    wave = S.wavelengths_angstrom(h4)
+    for dtype in (np.float32, ">f4", np.float64):
+        c = cube.astype(dtype)
+        for interval in ("all", [wave[3] - 1e-6, wave[8] + 1e-6], [wave[-1] + 1.0, wave[-1] + 2.0]):
+            A = AlignmentSpice((large, hl), (c, h4), lag_crval1=[0.0], lag_crval2=[0.0], level=2,
+                               wavelength_interval_to_sum=interval)
+            A._extract_spice_data_header(level=2)
+            data = np.array(c, dtype=np.float64)
+            sel = slice(None) if interval == "all" else np.logical_and(wave >= interval[0], wave <= interval[1])
+            want = np.nansum(data[0, sel, :, :], axis=0)
+            want[:ymin] = np.nan
+            want[ymax:] = np.nan
+            assert A.data_small.dtype == np.float64 and A.data_small.shape == want.shape
+            assert np.array_equal(A.data_small, want, equal_nan=True), (dtype, interval)
+            assert np.array_equal(np.signbit(A.data_small), np.signbit(want))
+
+
 def test_correct_solar_rotation_shrinks_cdelt1():
     """alignment_spice.py:223-248 (extend_pixel_size=True)."""
     from euispice_coreg_amd import synthetic
