@@ -111,6 +111,9 @@ SYMBOLS = [
     ("coreg_car_map", C.c_int, [_WP, _WP, C.c_int64, _P, _P, _P, _P]),
     ("coreg_wcslib_pixel_to_pixel", C.c_int, [_WP, _WP, C.c_int64, _P, _P, _P, _P, _P, _P]),
     ("coreg_car_tile_margin", C.c_int, [_WP, _WP, C.c_int32, C.c_double, C.POINTER(C.c_double)]),
+    ("coreg_fit_gaussian2d", C.c_int,
+     [C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, _P,
+      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     # all GPUs of the node from one process
     ("coreg_device_count", C.c_int, []),
     ("coreg_multi_create", C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(C.c_int)]),
@@ -801,6 +804,26 @@ def wcslib_pixel_to_pixel(hdr_from, hdr_to, px, py):
     if rc != COREG_OK:
         raise CoregError(rc, "coreg_wcslib_pixel_to_pixel")
     return tuple(out)
+
+
+def fit_gaussian2d(x, y, z, p0, lb, ub, jac="2-point", ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=0):
+    """Bounded least-squares fit of the 2-D Gaussian of AlignmentResults.py:12-21 by the library's restatement of scipy's
+    `curve_fit(..., bounds=...)` (host, no GPU).  Returns (popt, status, nfev): status as scipy's least_squares (0 =
+    max_nfev reached, -1 = non-finite input / residuals)."""
+    lib = load_library()
+    arrs = [np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel()) for a in (x, y, z, p0, lb, ub)]
+    if not (arrs[0].size == arrs[1].size == arrs[2].size) or any(a.size != 6 for a in arrs[3:]):
+        raise ValueError("fit_gaussian2d: x, y, z must have one length; p0, lb, ub six entries")
+    if jac not in ("2-point", "analytic"):
+        raise ValueError("jac must be '2-point' or 'analytic'")
+    popt = np.empty(6)
+    nfev, status = C.c_int32(0), C.c_int32(0)
+    rc = lib.coreg_fit_gaussian2d(arrs[0].size, *[a.ctypes.data for a in arrs], int(jac == "analytic"), float(ftol),
+                                  float(xtol), float(gtol), int(max_nfev), popt.ctypes.data, C.byref(nfev),
+                                  C.byref(status))
+    if rc != COREG_OK:
+        raise CoregError(rc, "coreg_fit_gaussian2d: bad arguments (sizes, bounds, or p0 outside the bounds)")
+    return popt, int(status.value), int(nfev.value)
 
 
 def carrington_origin(hdr):

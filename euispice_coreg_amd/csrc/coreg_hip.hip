@@ -16,6 +16,7 @@
 #include <thread>
 #include <vector>
 
+#include "fit.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
 
@@ -2520,6 +2521,20 @@ int coreg_wcslib_pixel_to_pixel(const coreg_wcs2d* from, const coreg_wcs2d* to, 
 int coreg_carrington_origin(const coreg_wcs2d* hdr, double* x0, double* y0) {
     if (!hdr || !x0 || !y0) return COREG_EINVAL;
     carr_origin(*hdr, x0, y0);
+    return COREG_OK;
+}
+
+int coreg_fit_gaussian2d(int32_t m, const double* x, const double* y, const double* z, const double* p0,
+                         const double* lb, const double* ub, int32_t jac, double ftol, double xtol, double gtol,
+                         int32_t max_nfev, double* popt, int32_t* nfev, int32_t* status) {
+    if (!x || !y || !z || !p0 || !lb || !ub || !popt || !status || m < 1 || m > coregfit::MMAX) return COREG_EINVAL;
+    coregfit::Problem P{m, x, y, z};
+    int n = 0;
+    const int st = coregfit::fit(P, p0, lb, ub, jac != 0, ftol > 0 ? ftol : 1e-8, xtol > 0 ? xtol : 1e-8,
+                                 gtol > 0 ? gtol : 1e-8, max_nfev, popt, &n, nullptr);
+    if (st == -2) return COREG_EINVAL;
+    if (nfev) *nfev = n;
+    *status = st;
     return COREG_OK;
 }
 

@@ -1,15 +1,18 @@
 """
 `AlignmentResults` -- drop-in for euispice_coreg.hdrshift.AlignmentResults (hdrshift/AlignmentResults.py:23-354):
-argmax of the 6-D correlation array, 2-D Gaussian sub-lag refinement (scipy.optimize.curve_fit, CPU, a few dozen
-points), corrected-header / corrected-FITS output.  `plot_correlation` draws the correlation map (matplotlib, optional);
+argmax of the 6-D correlation array, 2-D Gaussian sub-lag refinement (the reference's `curve_fit` call restated in the
+library, `coreg_fit_gaussian2d`: same algorithm, same stopping rule, ~0.1 ms instead of ~20 ms; `fit="scipy"` makes the
+literal scipy call), corrected-header / corrected-FITS output.  `plot_correlation` draws the correlation map (matplotlib, optional);
 `plot_co_alignment` (image overlays, plot/plot.py) is presentation code outside the path and raises NotImplementedError.
 """
 from __future__ import annotations
 
+import os
 import warnings
 
 import numpy as np
 
+from .. import _lib
 from ..utils import fits_io, header as hdrutil
 
 
@@ -26,7 +29,14 @@ class AlignmentResults:
 
     def __init__(self, corr, lag_crval1, lag_crval2, lag_cdelt1, lag_cdelt2, lag_crota, unit_lag,
                  image_to_align_path=None, image_to_align_window=None, reference_image_path=None,
-                 reference_image_window=None):
+                 reference_image_window=None, fit=None):
+        # fit: "native" (default; COREG_GAUSSIAN_FIT overrides) = csrc/fit.hpp, "scipy" = scipy.optimize.curve_fit
+        fit = fit or os.environ.get("COREG_GAUSSIAN_FIT", "native")
+        if fit not in ("native", "scipy"):
+            raise ValueError("fit must be 'native' or 'scipy'")
+        self.fit = fit
+        self.fit_info = None
+
         def arr(v):
             return np.array([0.0]) if v is None else np.atleast_1d(np.asarray(v, dtype=np.float64))
 
@@ -61,7 +71,6 @@ class AlignmentResults:
                              p["lag_cdelt2"][mi[3]], p["lag_crota"][mi[4]])
 
     def _compute_shift(self, method="fitting_gaussian"):
-        from scipy.optimize import curve_fit
         if method != "fitting_gaussian":
             raise NotImplementedError
         mi = self.max_index
@@ -86,7 +95,23 @@ class AlignmentResults:
             # the un-excluded index -2 wraps around; on an axis shorter than 2 it is out of range and the reference
             # dies with IndexError -- here that case falls back to the argmax like a failed fit does
             B = np.float64(corr2d[px, py].ravel())
-            popt, _ = curve_fit(f=twoD_Gaussian, xdata=A, ydata=B, p0=p0, bounds=bounds)
+            if self.fit == "scipy":
+                from scipy.optimize import curve_fit
+                popt, _ = curve_fit(f=twoD_Gaussian, xdata=A, ydata=B, p0=p0, bounds=bounds)
+            else:
+                # curve_fit's own checks, in its order: finite data (check_finite=True), p0 inside the bounds,
+                # finite residuals at p0 -- all ValueError, i.e. the reference's argmax fallback
+                if not (np.all(np.isfinite(B)) and np.all(np.isfinite(p0))):
+                    raise ValueError("array must not contain infs or NaNs")
+                if not all(lo <= v <= hi for v, lo, hi in zip(p0, *bounds)):
+                    raise ValueError("`x0` is infeasible.")
+                popt, status, nfev = _lib.fit_gaussian2d(A[0], A[1], B, p0, bounds[0], bounds[1])
+                self.fit_info = {"status": status, "nfev": nfev}
+                if status == -1:
+                    raise ValueError("Residuals are not finite in the initial point.")
+                if status == 0:  # curve_fit: `if not res.success: raise RuntimeError` -- not caught by the reference
+                    raise RuntimeError("Optimal parameters not found: The maximum number of function evaluations is "
+                                       "exceeded.")
         except (ValueError, IndexError):
             warnings.warn("Gaussian fitting failed, setting shift params as the pixel of the maximal correlation")
             self._argmax_shift()

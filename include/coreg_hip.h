@@ -292,6 +292,24 @@ int coreg_car_tile_margin(const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_
                           double tile_abs_lat_rad, double* margin_px);
 
 
+/* Sub-lag refinement of the correlation peak (host only, no GPU): the bounded least-squares fit of
+ *     g(x, y) = offset + amplitude * exp(-((x - xo)^2 / (2 sigma_x^2) + (y - yo)^2 / (2 sigma_y^2)))
+ * that AlignmentResults._compute_shift (hdrshift/AlignmentResults.py:12-21, :218-341) hands to
+ * scipy.optimize.curve_fit(f=twoD_Gaussian, xdata, ydata, p0, bounds) -- i.e. least_squares(method='trf',
+ * jac='2-point', x_scale=1, ftol = xtol = gtol = 1e-8, max_nfev = 600).  csrc/fit.hpp restates that algorithm
+ * (third-party scipy; trust-region reflective, exact SVD trust-region solver, scipy's forward-difference step rule and
+ * termination tests) so that the fit stops where the reference's call stops.
+ *   m points (x, y, z), m <= 64; p0 / lb / ub / popt: (amplitude, xo, yo, sigma_x, sigma_y, offset);
+ *   jac: 0 = forward differences as scipy's default (the reference's call), 1 = analytic Jacobian;
+ *   ftol / xtol / gtol <= 0 and max_nfev <= 0 select scipy's defaults.
+ *   *status: scipy's termination status (1 gtol, 2 ftol, 3 xtol, 4 ftol and xtol, 0 = max_nfev reached: curve_fit
+ *   raises RuntimeError there), -1 = a non-finite value among the inputs or the residuals at p0 (curve_fit raises
+ *   ValueError: the reference falls back to the argmax).  Returns COREG_EINVAL for bad arguments / p0 outside the bounds. */
+int coreg_fit_gaussian2d(int32_t m, const double* x, const double* y, const double* z, const double* p0,
+                         const double* lb, const double* ub, int32_t jac, double ftol, double xtol, double gtol,
+                         int32_t max_nfev, double* popt, int32_t* nfev, int32_t* status);
+
+
 /* ---- All GPUs of the node from ONE process ------------------------------------------------------------------------
  * The reference's `Alignment(..., parallelism=True, counts_cpu_max=N)` uses the whole machine from a plain
  * `python script.py`: its lag loop is fanned out over a process pool (hdrshift/alignment.py:692-744, README.md:47-87).

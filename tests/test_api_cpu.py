@@ -23,10 +23,15 @@ def test_alignment_results_reference_fixture():
     assert abs(R.shift_arcsec[0] - (15 + R.shift_pixels[0])) < 1e-9
     assert R.shift_arcsec[4] == 0.75
     assert "Shift" in str(R)
-    # agrees with the oracle's restatement of the same routine
+    # agrees with the oracle's restatement of the same routine (which calls scipy): the literal scipy call to the last
+    # digit, the library's restatement of it (the default, csrc/fit.hpp) to 1e-6 px on this well-conditioned peak
     from oracle import coreg_oracle as O
     _, px, _ = O.compute_shift(REF_CORR, np.arange(15, 26, 1.0), np.arange(5, 11, 1.0))
-    assert abs(px[0] - R.shift_pixels[0]) < 1e-9 and abs(px[1] - R.shift_pixels[1]) < 1e-9
+    assert R.fit == "native" and R.fit_info["status"] > 0
+    assert abs(px[0] - R.shift_pixels[0]) < 1e-6 and abs(px[1] - R.shift_pixels[1]) < 1e-6
+    S = AlignmentResults(corr=REF_CORR, lag_crval1=np.arange(15, 26, 1), lag_crval2=np.arange(5, 11, 1),
+                         lag_cdelt1=None, lag_cdelt2=[0], lag_crota=[0.75], unit_lag="arcsec", fit="scipy")
+    assert abs(px[0] - S.shift_pixels[0]) < 1e-9 and abs(px[1] - S.shift_pixels[1]) < 1e-9
 
 
 def test_alignment_results_too_few_points_falls_back_to_argmax():
