@@ -60,6 +60,22 @@ class Stats(C.Structure):
                 ("n_sweep_launches", C.c_int64), ("small_is_f32", C.c_int32), ("used_lds", C.c_int32)]
 
 
+class FitsPixels(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("bitpix", C.c_int32), ("reserved", C.c_int32), ("bscale", C.c_double),
+                ("bzero", C.c_double)]
+
+
+def _is_raw(img):
+    """utils.fits_io.RawImage (duck-typed: the binding does not import the FITS reader)."""
+    return hasattr(img, "bitpix") and hasattr(img, "ptr")
+
+
+def _fits_pixels(raw) -> FitsPixels:
+    if len(raw.shape) != 2:
+        raise ValueError("image must be 2-D")
+    return FitsPixels(raw.ptr, int(raw.bitpix), 0, float(raw.bscale), float(raw.bzero))
+
+
 # every symbol include/coreg_hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 _WP = C.POINTER(Wcs2d)
@@ -72,6 +88,11 @@ SYMBOLS = [
     ("coreg_synchronize", C.c_int, [_P]),
     ("coreg_set_small", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     ("coreg_set_small_f32", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    ("coreg_set_small_fits", C.c_int, [_P, C.POINTER(FitsPixels), C.c_int32, C.c_int32]),
+    ("coreg_prepare_reference_carrington_fits", C.c_int,
+     [_P, C.POINTER(FitsPixels), C.c_int32, C.c_int32, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
+    ("coreg_prepare_reference_helioprojective_fits", C.c_int,
+     [_P, C.POINTER(FitsPixels), C.c_int32, C.c_int32, _WP, _WP, C.c_int]),
     ("coreg_threshold_small", C.c_int, [_P, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_longlong)]),
     ("coreg_set_reference_on_grid", C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32]),
     ("coreg_prepare_reference_carrington", C.c_int,
@@ -125,6 +146,11 @@ SYMBOLS = [
     ("coreg_multi_last_mode", C.c_int, [_P]),
     ("coreg_multi_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("coreg_multi_set_small", C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32]),
+    ("coreg_multi_set_small_fits", C.c_int, [_P, C.POINTER(FitsPixels), C.c_int32, C.c_int32]),
+    ("coreg_multi_prepare_reference_carrington_fits", C.c_int,
+     [_P, C.POINTER(FitsPixels), C.c_int32, C.c_int32, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
+    ("coreg_multi_prepare_reference_helioprojective_fits", C.c_int,
+     [_P, C.POINTER(FitsPixels), C.c_int32, C.c_int32, _WP, _WP, C.c_int]),
     ("coreg_multi_threshold_small", C.c_int, [_P, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_longlong)]),
     ("coreg_multi_set_reference_on_grid", C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32]),
     ("coreg_multi_prepare_reference_carrington", C.c_int,
@@ -317,7 +343,12 @@ class CoregHandle:
 
     # -- images
     def set_small(self, img):
-        """Image to align.  float32 arrays (FITS BITPIX=-32 pixels) go up as they are; anything else as float64."""
+        """Image to align.  A RawImage (utils/fits_io.py) goes up as the file stores it and is decoded on the GPU;
+        float32 arrays (FITS BITPIX=-32 pixels) go up as they are; anything else as float64."""
+        if _is_raw(img):
+            px = _fits_pixels(img)
+            self._chk(self._lib.coreg_set_small_fits(self._h, C.byref(px), img.shape[0], img.shape[1]))
+            return
         img = np.asarray(img)
         if img.ndim != 2:
             raise ValueError("small image must be 2-D")
@@ -355,17 +386,28 @@ class CoregHandle:
         return np.ascontiguousarray(large, dtype=np.float64), False
 
     def prepare_reference_carrington(self, large, hdr_large, grid: Grid, solar_r, order=2):
-        large, f32 = self._reference_pixels(large)
         w = wcs_from_header(hdr_large, carrington=True)
         self.reference_tag = None
+        if _is_raw(large):
+            px = _fits_pixels(large)
+            self._chk(self._lib.coreg_prepare_reference_carrington_fits(
+                self._h, C.byref(px), large.shape[0], large.shape[1], C.byref(w), C.byref(grid.c), float(solar_r),
+                int(order)))
+            return
+        large, f32 = self._reference_pixels(large)
         fn = self._lib.coreg_prepare_reference_carrington_f32 if f32 else self._lib.coreg_prepare_reference_carrington
         self._chk(fn(self._h, large.ctypes.data, large.shape[0], large.shape[1], C.byref(w), C.byref(grid.c),
                      float(solar_r), int(order)))
 
     def prepare_reference_helioprojective(self, large, hdr_large, hdr_small, order=2):
-        large, f32 = self._reference_pixels(large)
         wl, ws = wcs_from_header(hdr_large), wcs_from_header(hdr_small)
         self.reference_tag = None
+        if _is_raw(large):
+            px = _fits_pixels(large)
+            self._chk(self._lib.coreg_prepare_reference_helioprojective_fits(
+                self._h, C.byref(px), large.shape[0], large.shape[1], C.byref(wl), C.byref(ws), int(order)))
+            return
+        large, f32 = self._reference_pixels(large)
         fn = self._lib.coreg_prepare_reference_helioprojective_f32 if f32 else \
             self._lib.coreg_prepare_reference_helioprojective
         self._chk(fn(self._h, large.ctypes.data, large.shape[0], large.shape[1], C.byref(wl), C.byref(ws), int(order)))
@@ -609,6 +651,10 @@ class MultiHandle:
         return np.ascontiguousarray(img, dtype=np.float64), COREG_F64
 
     def set_small(self, img):
+        if _is_raw(img):
+            px = _fits_pixels(img)
+            self._chk(self._lib.coreg_multi_set_small_fits(self._m, C.byref(px), img.shape[0], img.shape[1]))
+            return
         img, dt = self._pixels(img)
         self._chk(self._lib.coreg_multi_set_small(self._m, img.ctypes.data, dt, img.shape[0], img.shape[1]))
 
@@ -627,17 +673,28 @@ class MultiHandle:
             self._m, ref.ctypes.data, COREG_F32 if ref.dtype == np.float32 else COREG_F64, ref.shape[0], ref.shape[1]))
 
     def prepare_reference_carrington(self, large, hdr_large, grid: Grid, solar_r, order=2):
-        large, dt = self._pixels(large)
         w = wcs_from_header(hdr_large, carrington=True)
         self.reference_tag = None
+        if _is_raw(large):
+            px = _fits_pixels(large)
+            self._chk(self._lib.coreg_multi_prepare_reference_carrington_fits(
+                self._m, C.byref(px), large.shape[0], large.shape[1], C.byref(w), C.byref(grid.c), float(solar_r),
+                int(order)))
+            return
+        large, dt = self._pixels(large)
         self._chk(self._lib.coreg_multi_prepare_reference_carrington(
             self._m, large.ctypes.data, dt, large.shape[0], large.shape[1], C.byref(w), C.byref(grid.c), float(solar_r),
             int(order)))
 
     def prepare_reference_helioprojective(self, large, hdr_large, hdr_small, order=2):
-        large, dt = self._pixels(large)
         wl, ws = wcs_from_header(hdr_large), wcs_from_header(hdr_small)
         self.reference_tag = None
+        if _is_raw(large):
+            px = _fits_pixels(large)
+            self._chk(self._lib.coreg_multi_prepare_reference_helioprojective_fits(
+                self._m, C.byref(px), large.shape[0], large.shape[1], C.byref(wl), C.byref(ws), int(order)))
+            return
+        large, dt = self._pixels(large)
         self._chk(self._lib.coreg_multi_prepare_reference_helioprojective(
             self._m, large.ctypes.data, dt, large.shape[0], large.shape[1], C.byref(wl), C.byref(ws), int(order)))
 

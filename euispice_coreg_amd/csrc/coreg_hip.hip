@@ -82,6 +82,22 @@ enum SrcKind {
     SRC_DEVICE = 2,  // memory of the handle's GPU: read where it is
 };
 
+// what the pixels of an upload are: native float32 / float64, or a FITS data unit's big-endian elements
+struct PixFmt {
+    int bitpix = 0;  // 0: native pixels (`f32` says which); else the FITS BITPIX of raw big-endian pixels
+    bool f32 = false;
+    double bscale = 1.0, bzero = 0.0;
+    bool raw() const { return bitpix != 0; }
+    bool scaled() const { return bscale != 1.0 || bzero != 0.0; }  // (as utils/fits_io.py decides it)
+    size_t elem() const { return raw() ? (size_t)(bitpix < 0 ? -bitpix : bitpix) / 8 : (f32 ? 4 : 8); }
+    bool swap_only() const { return bitpix == -32 && !scaled(); }  // decoded in place: float32 pixels
+    static PixFmt native(bool is_f32) {
+        PixFmt f;
+        f.f32 = is_f32;
+        return f;
+    }
+};
+
 constexpr int kMaxDevices = 64;
 std::mutex g_attr_mutex;
 
@@ -122,6 +138,7 @@ struct coreg_handle {
     // sweep
     DevBuf lane_params, out_index, partials, out_dev, tmp_img;
     DevBuf up_f64, up_flag;  // upload staging on the device (float64 copy, exactness flag)
+    DevBuf up_raw;           // raw FITS elements awaiting their decode (BITPIX other than an unscaled -32)
     PrologueArgs pending_prologue = {};  // set by upload_plan, consumed by the sweep's first k_precompute launch
     DevBuf bbox_buf;         // reference_crop: partial bounding boxes
     hipStream_t aux_stream = nullptr;  // side stream of reference_crop (created on first use)
@@ -397,6 +414,37 @@ int upload_image(coreg_handle* h, const double* img, size_t n, DevBuf& buf, bool
         std::swap(buf.p, h->up_f64.p);  // the float64 copy becomes the image
         std::swap(buf.cap, h->up_f64.cap);
     }
+    return COREG_OK;
+}
+
+// raw FITS elements on the device -> the pixels the kernels read.  BITPIX = -32 without scaling: `raw_dev` IS buf.p, the
+// byte swap runs in place and the image is float32.  Everything else: float64(stored) * bscale + bzero into up_f64, then
+// the same float32-exactness test and conversion a float64 upload gets (upload_image).
+int fits_decode(coreg_handle* h, const PixFmt& fmt, void* raw_dev, size_t n, DevBuf& buf, bool* is_f32) {
+    const int nb = (int)std::min<size_t>((n + 255) / 256, 4096);
+    if (fmt.swap_only()) {
+        hipLaunchKernelGGL(k_fits_swap32, dim3(nb), dim3(256), 0, h->stream, (unsigned int*)raw_dev, (long long)n);
+        HIPCHK(hipGetLastError());
+        *is_f32 = true;
+        return COREG_OK;
+    }
+    HIPCHK(h->up_f64.reserve(n * sizeof(double)));
+    hipLaunchKernelGGL(k_fits_to_f64, dim3(nb), dim3(256), 0, h->stream, (const void*)raw_dev, fmt.bitpix,
+                       fmt.scaled() ? 1 : 0, fmt.bscale, fmt.bzero, (long long)n, h->up_f64.as<double>());
+    HIPCHK(hipGetLastError());
+    return upload_image(h, h->up_f64.as<double>(), n, buf, is_f32, SRC_DEVICE);
+}
+
+int check_fits(coreg_handle* h, const coreg_fits_pixels* px, PixFmt* fmt) {
+    if (!px || !px->data) return fail(h, COREG_EINVAL, "fits pixels: null pointer");
+    const int b = px->bitpix;
+    if (b != 8 && b != 16 && b != 32 && b != 64 && b != -32 && b != -64)
+        return fail(h, COREG_EINVAL, "fits pixels: BITPIX must be 8, 16, 32, 64, -32 or -64");
+    if (!std::isfinite(px->bscale) || !std::isfinite(px->bzero))
+        return fail(h, COREG_EINVAL, "fits pixels: BSCALE / BZERO not finite");
+    fmt->bitpix = b;
+    fmt->bscale = px->bscale;
+    fmt->bzero = px->bzero;
     return COREG_OK;
 }
 
@@ -1349,7 +1397,7 @@ void coreg_destroy(coreg_handle* h) {
     DevBuf* bufs[] = {&h->small, &h->ref, &h->pivots, &h->red_sum, &h->red_cnt, &h->t_sin_lon, &h->t_cos_lon,
                       &h->t_cos_lat, &h->t_sin_lat, &h->pts, &h->tile_count, &h->tile_list, &h->tile_cum, &h->group_first,
                       &h->tile_info, &h->tile_bbox, &h->counters, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
-                      &h->tmp_img, &h->up_f64, &h->up_flag, &h->border_dev, &h->sums, &h->fin_outidx, &h->border_flags, &h->fix_partial};
+                      &h->tmp_img, &h->up_f64, &h->up_flag, &h->up_raw, &h->border_dev, &h->sums, &h->fin_outidx, &h->border_flags, &h->fix_partial};
     for (DevBuf* b : bufs) b->release();
     for (int k = 0; k < 2; ++k) {
         h->pin_img[k].release();
@@ -1509,6 +1557,29 @@ int coreg_set_small_from_device(coreg_handle* h, const void* dev_img, int dtype,
     return set_small_direct(h, dev_img, dtype, ny, nx, SRC_DEVICE);
 }
 
+// image to align as the FITS data unit stores it (host or page-locked memory): raw bytes up, decode on the GPU
+static int set_small_fits(coreg_handle* h, const coreg_fits_pixels* px, int32_t ny, int32_t nx, SrcKind kind) {
+    if (!h) return COREG_EINVAL;
+    PixFmt fmt;
+    RETCHK(check_fits(h, px, &fmt));
+    if (ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "set_small_fits: bad image size");
+    RETCHK(bind_device(h));
+    const size_t n = (size_t)ny * nx, eb = fmt.elem();
+    DevBuf& dst = fmt.swap_only() ? h->small : h->up_raw;
+    HIPCHK(dst.reserve(n * eb));
+    if (kind == SRC_PINNED) HIPCHK(hipMemcpyAsync(dst.p, px->data, n * eb, hipMemcpyHostToDevice, h->stream));
+    else RETCHK(staged_upload(h, dst.p, px->data, n * eb));
+    RETCHK(fits_decode(h, fmt, dst.p, n, h->small, &h->small_f32));
+    h->sW = nx;
+    h->sH = ny;
+    if (h->small_f32) return device_mean<float>(h, h->small.as<float>(), (long long)n, h->pivots.as<double>() + 1);
+    return device_mean<double>(h, h->small.as<double>(), (long long)n, h->pivots.as<double>() + 1);
+}
+
+int coreg_set_small_fits(coreg_handle* h, const coreg_fits_pixels* px, int32_t ny, int32_t nx) {
+    return set_small_fits(h, px, ny, nx, SRC_HOST);
+}
+
 int coreg_threshold_small(coreg_handle* h, int has_min, double vmin, int has_max, double vmax, long long* n_finite) {
     if (!h) return COREG_EINVAL;
     if (!h->small.p) return fail(h, COREG_ESTATE, "coreg_set_small has not been called");
@@ -1629,19 +1700,35 @@ static int staged_upload_rect(coreg_handle* h, void* dev, const void* host, size
     return COREG_OK;
 }
 
-// the reference image's pixels: float64 from the caller (tested for float32-exactness on the GPU), or the float32
-// pixels a BITPIX=-32 FITS file holds (half the PCIe bytes; the reference's float64 cast of them is exact)
+// the reference image's pixels: float64 from the caller (tested for float32-exactness on the GPU), the float32
+// pixels a BITPIX=-32 FITS file holds (half the PCIe bytes; the reference's float64 cast of them is exact), or the raw
+// big-endian elements of the FITS data unit (decoded on the GPU)
 // (src_on_device: the pixels are read where they are, by the resample kernel on the handle's stream -- no copy)
-static int upload_reference_source(coreg_handle* h, const void* large, size_t n, bool src_f32, bool* f32,
+static int upload_reference_source(coreg_handle* h, const void* large, size_t n, const PixFmt& fmt, bool* f32,
                                    SrcKind kind, const void** img_dev, int W = 0, const CropRect* crop = nullptr) {
+    const bool src_f32 = fmt.f32;
     if (kind == SRC_DEVICE) {
+        if (fmt.raw()) return fail(h, COREG_ENOTIMPL, "raw FITS pixels must come from host memory");
         *f32 = src_f32;
         *img_dev = large;
         return COREG_OK;
     }
-    if (crop && kind == SRC_HOST && (size_t)crop->w * crop->h < n) {
+    const bool cropped = crop && kind == SRC_HOST && (size_t)crop->w * crop->h < n;
+    const size_t nc = cropped ? (size_t)crop->w * crop->h : n;
+    if (fmt.raw()) {
+        // only the rectangle the resample can touch crosses PCIe, as stored in the file; decoded on the device
+        const size_t eb = fmt.elem();
+        DevBuf& dst = fmt.swap_only() ? h->tmp_img : h->up_raw;
+        HIPCHK(dst.reserve(nc * eb));
+        if (cropped) RETCHK(staged_upload_rect(h, dst.p, large, eb, W, *crop));
+        else if (kind == SRC_PINNED) HIPCHK(hipMemcpyAsync(dst.p, large, n * eb, hipMemcpyHostToDevice, h->stream));
+        else RETCHK(staged_upload(h, dst.p, large, n * eb));
+        RETCHK(fits_decode(h, fmt, dst.p, nc, h->tmp_img, f32));
+        *img_dev = h->tmp_img.p;
+        return COREG_OK;
+    }
+    if (cropped) {
         // only the rectangle the resample can touch crosses PCIe
-        const size_t nc = (size_t)crop->w * crop->h;
         if (src_f32) {
             HIPCHK(h->tmp_img.reserve(nc * sizeof(float)));
             RETCHK(staged_upload_rect(h, h->tmp_img.p, large, sizeof(float), W, *crop));
@@ -1668,7 +1755,7 @@ static int upload_reference_source(coreg_handle* h, const void* large, size_t n,
     return COREG_OK;
 }
 
-static int prepare_carrington(coreg_handle* h, const void* large, bool src_f32, int32_t ny, int32_t nx,
+static int prepare_carrington(coreg_handle* h, const void* large, const PixFmt& fmt, int32_t ny, int32_t nx,
                               const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r, int order,
                               SrcKind kind = SRC_HOST) {
     if (!h) return COREG_EINVAL;
@@ -1688,7 +1775,7 @@ static int prepare_carrington(coreg_handle* h, const void* large, bool src_f32, 
     if (kind == SRC_HOST) RETCHK(reference_crop(h, MODE_TRANSLATE, a, order, &crop));
     bool f32;
     const void* img_dev = nullptr;
-    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, src_f32, &f32, kind, &img_dev, nx, &crop));
+    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, fmt, &f32, kind, &img_dev, nx, &crop));
     a.img = img_dev;
     if (crop.w != nx || crop.h != ny) a.crop = {crop.x0, crop.y0, crop.w};
     HIPCHK(h->ref.reserve((size_t)a.gw * a.gh * sizeof(double)));
@@ -1704,16 +1791,16 @@ static int prepare_carrington(coreg_handle* h, const void* large, bool src_f32, 
 
 int coreg_prepare_reference_carrington(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
                                        const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r, int order) {
-    return prepare_carrington(h, large, false, ny, nx, hdr, grid, solar_r, order);
+    return prepare_carrington(h, large, PixFmt::native(false), ny, nx, hdr, grid, solar_r, order);
 }
 
 int coreg_prepare_reference_carrington_f32(coreg_handle* h, const float* large, int32_t ny, int32_t nx,
                                            const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r,
                                            int order) {
-    return prepare_carrington(h, large, true, ny, nx, hdr, grid, solar_r, order);
+    return prepare_carrington(h, large, PixFmt::native(true), ny, nx, hdr, grid, solar_r, order);
 }
 
-static int prepare_helioprojective(coreg_handle* h, const void* large, bool src_f32, int32_t ny, int32_t nx,
+static int prepare_helioprojective(coreg_handle* h, const void* large, const PixFmt& fmt, int32_t ny, int32_t nx,
                                    const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order,
                                    SrcKind kind = SRC_HOST) {
     if (!h) return COREG_EINVAL;
@@ -1735,7 +1822,7 @@ static int prepare_helioprojective(coreg_handle* h, const void* large, bool src_
     if (kind == SRC_HOST) RETCHK(reference_crop(h, MODE_HOMOGRAPHY, a, order, &crop));
     bool f32;
     const void* img_dev = nullptr;
-    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, src_f32, &f32, kind, &img_dev, nx, &crop));
+    RETCHK(upload_reference_source(h, large, (size_t)ny * nx, fmt, &f32, kind, &img_dev, nx, &crop));
     a.img = img_dev;
     if (crop.w != nx || crop.h != ny) a.crop = {crop.x0, crop.y0, crop.w};
     HIPCHK(h->ref.reserve((size_t)a.gw * a.gh * sizeof(float)));
@@ -1750,27 +1837,46 @@ static int prepare_helioprojective(coreg_handle* h, const void* large, bool src_
 
 int coreg_prepare_reference_helioprojective(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
                                             const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order) {
-    return prepare_helioprojective(h, large, false, ny, nx, hdr_large, hdr_small, order);
+    return prepare_helioprojective(h, large, PixFmt::native(false), ny, nx, hdr_large, hdr_small, order);
 }
 
 int coreg_prepare_reference_helioprojective_f32(coreg_handle* h, const float* large, int32_t ny, int32_t nx,
                                                 const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small,
                                                 int order) {
-    return prepare_helioprojective(h, large, true, ny, nx, hdr_large, hdr_small, order);
+    return prepare_helioprojective(h, large, PixFmt::native(true), ny, nx, hdr_large, hdr_small, order);
 }
 
 int coreg_prepare_reference_carrington_from_device(coreg_handle* h, const void* dev_large, int dtype, int32_t ny,
                                                    int32_t nx, const coreg_wcs2d* hdr_large,
                                                    const coreg_carr_grid* grid, double solar_r, int order) {
     if (h && dtype != COREG_F32 && dtype != COREG_F64) return fail(h, COREG_EINVAL, "prepare_reference: bad dtype");
-    return prepare_carrington(h, dev_large, dtype == COREG_F32, ny, nx, hdr_large, grid, solar_r, order, SRC_DEVICE);
+    return prepare_carrington(h, dev_large, PixFmt::native(dtype == COREG_F32), ny, nx, hdr_large, grid, solar_r, order,
+                              SRC_DEVICE);
 }
 
 int coreg_prepare_reference_helioprojective_from_device(coreg_handle* h, const void* dev_large, int dtype, int32_t ny,
                                                         int32_t nx, const coreg_wcs2d* hdr_large,
                                                         const coreg_wcs2d* hdr_small, int order) {
     if (h && dtype != COREG_F32 && dtype != COREG_F64) return fail(h, COREG_EINVAL, "prepare_reference: bad dtype");
-    return prepare_helioprojective(h, dev_large, dtype == COREG_F32, ny, nx, hdr_large, hdr_small, order, SRC_DEVICE);
+    return prepare_helioprojective(h, dev_large, PixFmt::native(dtype == COREG_F32), ny, nx, hdr_large, hdr_small, order,
+                                   SRC_DEVICE);
+}
+
+int coreg_prepare_reference_carrington_fits(coreg_handle* h, const coreg_fits_pixels* px, int32_t ny, int32_t nx,
+                                            const coreg_wcs2d* hdr_large, const coreg_carr_grid* grid, double solar_r,
+                                            int order) {
+    if (!h) return COREG_EINVAL;
+    PixFmt fmt;
+    RETCHK(check_fits(h, px, &fmt));
+    return prepare_carrington(h, px->data, fmt, ny, nx, hdr_large, grid, solar_r, order);
+}
+
+int coreg_prepare_reference_helioprojective_fits(coreg_handle* h, const coreg_fits_pixels* px, int32_t ny, int32_t nx,
+                                                 const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order) {
+    if (!h) return COREG_EINVAL;
+    PixFmt fmt;
+    RETCHK(check_fits(h, px, &fmt));
+    return prepare_helioprojective(h, px->data, fmt, ny, nx, hdr_large, hdr_small, order);
 }
 
 int coreg_get_reference_on_grid(coreg_handle* h, void* out, int dtype) {

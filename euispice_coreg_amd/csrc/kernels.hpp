@@ -464,6 +464,32 @@ __global__ void __launch_bounds__(256) k_f64_to_f32(const double* __restrict__ v
         out[i] = (float)v[i];
 }
 
+// ---- pixels as a FITS data unit stores them (alignment.py:299-314 reads them through astropy.io.fits) -----------------
+// big-endian; BITPIX 8 = unsigned bytes, 16 / 32 / 64 = two's complement integers, -32 / -64 = IEEE floats.
+// BITPIX = -32 without BSCALE / BZERO: the byte swap IS the decode, in place (the float64 cast of alignment.py:314 is
+// exact, the sweep takes float32 pixels as they are).
+__global__ void __launch_bounds__(256) k_fits_swap32(unsigned int* __restrict__ v, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        v[i] = __builtin_bswap32(v[i]);
+}
+// everything else: float64(stored) [* bscale + bzero, two roundings as NumPy's `a.astype(float64) * bscale + bzero`]
+__global__ void __launch_bounds__(256) k_fits_to_f64(const void* __restrict__ raw, int bitpix, int scaled, double bscale,
+                                                     double bzero, long long n, double* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        double x;
+        switch (bitpix) {
+            case 8: x = (double)((const unsigned char*)raw)[i]; break;
+            case 16: x = (double)(short)__builtin_bswap16(((const unsigned short*)raw)[i]); break;
+            case 32: x = (double)(int)__builtin_bswap32(((const unsigned int*)raw)[i]); break;
+            case 64: x = (double)(long long)__builtin_bswap64(((const unsigned long long*)raw)[i]); break;
+            case -32: x = (double)__uint_as_float(__builtin_bswap32(((const unsigned int*)raw)[i])); break;
+            default: x = __longlong_as_double((long long)__builtin_bswap64(((const unsigned long long*)raw)[i])); break;
+        }
+        if (scaled) x = __dadd_rn(__dmul_rn(x, bscale), bzero);
+        out[i] = x;
+    }
+}
+
 // alignment.py:876-887 in place: |v| < vmin or |v| > vmax -> NaN (comparisons with NaN are false, NaN stays NaN)
 template <typename T>
 __global__ void __launch_bounds__(256) k_threshold(T* __restrict__ v, long long n, int has_min, double vmin, int has_max,

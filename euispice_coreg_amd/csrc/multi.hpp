@@ -551,7 +551,8 @@ int coreg_multi_prepare_reference_carrington(coreg_multi* m, const void* large, 
     // every device sends its own copy of the rectangle the grid can touch (reference_crop: usually a few hundred KB;
     // when the grid covers most of the image, N whole uploads through the devices' own staging buffers)
     return multi_run(m, [&](int k) {
-        return prepare_carrington(m->h[k], large, dtype == COREG_F32, ny, nx, hdr_large, grid, solar_r, order, SRC_HOST);
+        return prepare_carrington(m->h[k], large, PixFmt::native(dtype == COREG_F32), ny, nx, hdr_large, grid, solar_r,
+                                  order, SRC_HOST);
     });
 }
 
@@ -561,7 +562,47 @@ int coreg_multi_prepare_reference_helioprojective(coreg_multi* m, const void* la
     if (!large || ny < 1 || nx < 1 || (dtype != COREG_F32 && dtype != COREG_F64))
         return mfail(m, COREG_EINVAL, "multi_prepare_reference: bad argument");
     return multi_run(m, [&](int k) {
-        return prepare_helioprojective(m->h[k], large, dtype == COREG_F32, ny, nx, hdr_large, hdr_small, order, SRC_HOST);
+        return prepare_helioprojective(m->h[k], large, PixFmt::native(dtype == COREG_F32), ny, nx, hdr_large, hdr_small,
+                                       order, SRC_HOST);
+    });
+}
+
+// the same three with the pixels as the FITS data unit stores them (raw big-endian bytes up, decode on each GPU)
+int coreg_multi_set_small_fits(coreg_multi* m, const coreg_fits_pixels* px, int32_t ny, int32_t nx) {
+    if (!m) return COREG_EINVAL;
+    PixFmt fmt;
+    if (check_fits(nullptr, px, &fmt) != COREG_OK || ny < 1 || nx < 1)
+        return mfail(m, COREG_EINVAL, "multi_set_small_fits: bad argument");
+    if (m->n == 1) {
+        int rc;
+        m->w[0]->post([&] { rc = coreg_set_small_fits(m->h[0], px, ny, nx); });
+        m->w[0]->wait();
+        return rc == COREG_OK ? rc : mfail(m, rc, coreg_last_error(m->h[0]));
+    }
+    RETCHK(multi_stage(m, px->data, (size_t)ny * nx * fmt.elem()));
+    coreg_fits_pixels staged = *px;
+    staged.data = m->stage.p;
+    return multi_run(m, [&](int k) {
+        RETCHK(set_small_fits(m->h[k], &staged, ny, nx, SRC_PINNED));
+        return coreg_synchronize(m->h[k]);  // the shared staging is free again on return
+    });
+}
+
+int coreg_multi_prepare_reference_carrington_fits(coreg_multi* m, const coreg_fits_pixels* px, int32_t ny, int32_t nx,
+                                                  const coreg_wcs2d* hdr_large, const coreg_carr_grid* grid,
+                                                  double solar_r, int order) {
+    if (!m) return COREG_EINVAL;
+    return multi_run(m, [&](int k) {
+        return coreg_prepare_reference_carrington_fits(m->h[k], px, ny, nx, hdr_large, grid, solar_r, order);
+    });
+}
+
+int coreg_multi_prepare_reference_helioprojective_fits(coreg_multi* m, const coreg_fits_pixels* px, int32_t ny,
+                                                       int32_t nx, const coreg_wcs2d* hdr_large,
+                                                       const coreg_wcs2d* hdr_small, int order) {
+    if (!m) return COREG_EINVAL;
+    return multi_run(m, [&](int k) {
+        return coreg_prepare_reference_helioprojective_fits(m->h[k], px, ny, nx, hdr_large, hdr_small, order);
     });
 }
 

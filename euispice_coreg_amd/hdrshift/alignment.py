@@ -69,6 +69,8 @@ class Alignment:
             raise ValueError("cdelt_semantics must be 'intended' or 'reference'")
         self.cdelt_semantics = cdelt_semantics
         self.device = device
+        # plain image HDUs of local files go to the GPU as the file stores them (COREG_RAW_FITS=0: decode on the host)
+        self.raw_fits_upload = os.environ.get("COREG_RAW_FITS", "1") != "0"
         self.last_stats = None
         self.last_sharding = None       # how the last sweep was spread over the GPUs (parallel.lag_sharding)
         # set by the jitter-correction session (jitter_correction/jitter_correction.py):
@@ -88,22 +90,27 @@ class Alignment:
         self.hdr_large = fits_io.Header(fits_io.read_header(self.large_fov_known_pointing, self.large_fov_window))
         if self._preloaded_small is not None:
             ds, hs = self._preloaded_small
-            self.data_small = np.asarray(ds)  # float32 (BITPIX=-32) pixels stay float32: the float64 cast is exact
         else:
-            ds, hs = fits_io.read_image(self.small_fov_to_correct, self.small_fov_window)
-            ds = np.asarray(ds)
-            # alignment.py:198 / :314 cast to float64 (exact for float32 pixels, which are kept as they are)
-            self.data_small = fits_io.native_pixels(ds)
+            # a plain image HDU of a local file is not decoded on the host at all: its bytes are memory-mapped and go
+            # to the GPU as the file stores them (fits_io.RawImage; byte swap, BSCALE / BZERO and the float conversion
+            # of alignment.py:198 / :314 run there).  Anything else (in-memory pairs, compressed images, URLs with
+            # astropy) is read and decoded as before.
+            raw = fits_io.open_raw(self.small_fov_to_correct, self.small_fov_window) if self.raw_fits_upload else None
+            ds, hs = (raw, raw.header) if raw is not None else fits_io.read_image(self.small_fov_to_correct,
+                                                                                  self.small_fov_window)
+        # float32 (BITPIX=-32) pixels stay float32: the float64 cast of alignment.py:198 / :314 is exact
+        self.data_small = fits_io.native_pixels(ds)
         self.hdr_small = fits_io.Header(hs)
         hdrutil.check_and_create_pcij_matrix(self.hdr_small, self.force_crota_0)  # alignment.py:232 / :310
         hdrutil.check_and_create_pcij_matrix(self.hdr_large, self.force_crota_0)
 
     def _large_pixels(self):
         if self.data_large is None:
-            dl, _ = fits_io.read_image(self.large_fov_known_pointing, self.large_fov_window)
-            dl = np.asarray(dl)
+            raw = fits_io.open_raw(self.large_fov_known_pointing, self.large_fov_window) if self.raw_fits_upload else None
+            dl = raw if raw is not None else fits_io.read_image(self.large_fov_known_pointing, self.large_fov_window)[0]
             # alignment.py:191 / :301 cast to float64; float32 pixels (BITPIX=-32) are kept as they are -- the cast is
-            # exact and the library does it on the GPU, half the bytes cross PCIe
+            # exact and the library does it on the GPU, half the bytes cross PCIe; a memory-mapped data unit (RawImage)
+            # goes up as stored, and only the rectangle the target grid can touch
             self.data_large = fits_io.native_pixels(dl)
         return self.data_large
 
@@ -308,6 +315,8 @@ class Alignment:
         spread = world > 1
 
         def upload_small(data):
+            if spread and isinstance(data, fits_io.RawImage):
+                data = fits_io.native_pixels(data.decode())  # row shares + all-gather work on decoded pixels
             t = parallel.replicate_image(data) if spread and np.asarray(data).dtype in (np.float32, np.float64) else None
             if t is None:
                 h.set_small(data)

@@ -144,23 +144,28 @@ class AlignmentResults:
             if self.image_to_align_path is None:
                 raise ValueError("Please provide a path_to_l2_input parameter")
             path_to_l2_input = self.image_to_align_path
-        if isinstance(path_to_l2_input, (tuple, list)):
-            hdus = [(np.asarray(path_to_l2_input[0]), fits_io.Header(path_to_l2_input[1]))]
-        else:
-            hdus = fits_io.read_all(path_to_l2_input)
         s = self.shift_arcsec
-        out, n_corrected = [], 0
-        for ii, (data, hdr) in enumerate(hdus):
+
+        def selected(ii, n, hdr):
             extname = hdr.get("EXTNAME", "nothing98695")
-            if (extname in window_list_to_apply_shift) or (ii in window_list_to_apply_shift) or \
-                    ((ii - len(hdus)) in window_list_to_apply_shift):
-                hdr = hdr.copy()
-                hdrutil.correct_pointing_header(hdr, lag_crval1=s[0], lag_crval2=s[1], lag_cdelt1=s[2],
-                                                lag_cdelt2=s[3], lag_crota=s[4])
-                data = None if data is None else np.array(data, dtype="<f4")
-                n_corrected += 1
-            out.append((data, hdr))
-        fits_io.write_images(path_to_l3_output, out, overwrite=True)
+            return (extname in window_list_to_apply_shift) or (ii in window_list_to_apply_shift) or \
+                ((ii - n) in window_list_to_apply_shift)
+
+        def correct(hdr):
+            hdrutil.correct_pointing_header(hdr, lag_crval1=s[0], lag_crval2=s[1], lag_cdelt1=s[2], lag_cdelt2=s[3],
+                                            lag_crota=s[4])
+        if isinstance(path_to_l2_input, (tuple, list)):
+            hdr = fits_io.Header(path_to_l2_input[1])
+            data = np.asarray(path_to_l2_input[0])
+            n_corrected = 0
+            if selected(0, 1, hdr):
+                correct(hdr)
+                data = np.array(data, dtype="<f4")
+                n_corrected = 1
+            fits_io.write_images(path_to_l3_output, [(data, hdr)], overwrite=True)
+        else:
+            # headers re-written, data units copied as they are (no decode / encode of the pixels)
+            n_corrected = fits_io.rewrite_with_corrected_headers(path_to_l2_input, path_to_l3_output, selected, correct)
         if n_corrected == 0:
             raise ValueError("has not corrected any window.")
 

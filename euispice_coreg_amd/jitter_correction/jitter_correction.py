@@ -118,7 +118,7 @@ def jitter_correction_imagers(list_files_input, path_files_output, lonlims=None,
                 while len(inflight) >= prefetch + depth:
                     i0, f0 = inflight.pop(0)
                     done.append((i0, index_ref, f0.result().result()))
-                img = reader.submit(fits_io.read_image, list_files_input[index_to_align], window_files_input)
+                img = reader.submit(fits_io.load_for_upload, list_files_input[index_to_align], window_files_input)
                 inflight.append((index_to_align, drivers.submit(drive, index_to_align, index_ref, path_reference, img)))
             for i0, f0 in inflight:
                 # surfaces exceptions; every output of this sublist is on disk before the next one starts

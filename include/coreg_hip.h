@@ -122,6 +122,25 @@ int coreg_set_small(coreg_handle* h, const double* img, int32_t ny, int32_t nx);
  * jitter-correction session (jitter_correction/jitter_correction.py:101-138), which uploads one image per sweep. */
 int coreg_set_small_f32(coreg_handle* h, const float* img, int32_t ny, int32_t nx);
 
+/* Pixels exactly as a FITS data unit stores them: big-endian, BITPIX 8 (unsigned) / 16 / 32 / 64 (two's complement) /
+ * -32 / -64 (IEEE), physical value = bscale * stored + bzero.  The reference decodes them on the host through
+ * astropy.io.fits and casts to float64 (alignment.py:299-314, :191-208); here the RAW bytes cross PCIe (`data` may be a
+ * read-only mmap of the file: it is copied into page-locked staging by a thread pool and is free again on return) and
+ * the byte swap, BSCALE / BZERO and the float conversion run on the GPU.  Results are bit-identical to handing the
+ * decoded float32 / float64 pixels to coreg_set_small[_f32] / coreg_prepare_reference_*[_f32]. */
+typedef struct coreg_fits_pixels {
+    const void* data; /* first byte of the data unit (ny * nx elements of |bitpix| / 8 bytes, row-major) */
+    int32_t bitpix;
+    int32_t reserved;
+    double bscale, bzero; /* 1, 0 when the header has neither */
+} coreg_fits_pixels;
+int coreg_set_small_fits(coreg_handle* h, const coreg_fits_pixels* px, int32_t ny, int32_t nx);
+int coreg_prepare_reference_carrington_fits(coreg_handle* h, const coreg_fits_pixels* px, int32_t ny, int32_t nx,
+                                            const coreg_wcs2d* hdr_large, const coreg_carr_grid* grid, double solar_r,
+                                            int order);
+int coreg_prepare_reference_helioprojective_fits(coreg_handle* h, const coreg_fits_pixels* px, int32_t ny, int32_t nx,
+                                                 const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order);
+
 /* Alignment._set_threshold_minmax_to_nan (alignment.py:876-887) on the resident image to align:
  * |v| < vmin -> NaN when has_min, |v| > vmax -> NaN when has_max.  *n_finite (optional) receives the number of finite
  * pixels left: 0 is the reference's "minimum or maximum value have set all small FOV to nan" error (alignment.py:655). */
@@ -337,6 +356,14 @@ const char* coreg_multi_collective(const coreg_multi* m); /* "rccl", "host-copy"
 int coreg_multi_last_mode(const coreg_multi* m);          /* partition of the last sweep: 0 none, 1 blocks, 2 slices, 3 points */
 int coreg_multi_set_option(coreg_multi* m, const char* name, int64_t value);
 int coreg_multi_set_small(coreg_multi* m, const void* img, int dtype, int32_t ny, int32_t nx);
+/* the same with the pixels as the FITS data unit stores them (coreg_fits_pixels above) */
+int coreg_multi_set_small_fits(coreg_multi* m, const coreg_fits_pixels* px, int32_t ny, int32_t nx);
+int coreg_multi_prepare_reference_carrington_fits(coreg_multi* m, const coreg_fits_pixels* px, int32_t ny, int32_t nx,
+                                                  const coreg_wcs2d* hdr_large, const coreg_carr_grid* grid,
+                                                  double solar_r, int order);
+int coreg_multi_prepare_reference_helioprojective_fits(coreg_multi* m, const coreg_fits_pixels* px, int32_t ny,
+                                                       int32_t nx, const coreg_wcs2d* hdr_large,
+                                                       const coreg_wcs2d* hdr_small, int order);
 int coreg_multi_threshold_small(coreg_multi* m, int has_min, double vmin, int has_max, double vmax, long long* n_finite);
 int coreg_multi_set_reference_on_grid(coreg_multi* m, const void* ref, int dtype, int32_t gy, int32_t gx);
 int coreg_multi_prepare_reference_carrington(coreg_multi* m, const void* large, int dtype, int32_t ny, int32_t nx,

@@ -327,3 +327,89 @@ def test_bench_self_launches_its_ranks_gloo_world2():
     assert out["dry_run_map_ok"] is True  # gathered blocks + permutation == C-order raveled lag map
     assert [r["rank"] for r in out["per_rank"]] == [0, 1] and sum(r["lags"] for r in out["per_rank"]) == 3600
     assert out["scaling"] == "strong" and out["config"]["resident"] is True
+
+
+def _several_hdus(tmp_path):
+    """A file with an empty primary, a float32 image, an int16 image with BSCALE / BZERO and a float64 image."""
+    from euispice_coreg_amd.utils import fits_io
+    from tests import helpers as H
+    small, hs, _, _, _ = H.scene(small_n=40, large_n=32)
+    rng = np.random.default_rng(5)
+    h16 = dict(hs, EXTNAME="RAW16", BSCALX=0.25, BZERX=100.0)  # (write_images drops the real keywords: renamed below)
+    p = str(tmp_path / "several.fits")
+    fits_io.write_images(p, [(None, {"ORIGIN": "test"}), (small.astype(np.float32), dict(hs, EXTNAME="IMAGE")),
+                             (rng.integers(-3000, 3000, (40, 40)).astype(np.int16), h16),
+                             (small.astype(np.float64) * (1 + 1e-9), dict(hs, EXTNAME="F64"))])
+    blob = open(p, "rb").read()
+    assert blob.count(b"BSCALX  =") == 1 and blob.count(b"BZERX   =") == 1
+    open(p, "wb").write(blob.replace(b"BSCALX  =", b"BSCALE  =").replace(b"BZERX   =", b"BZERO   ="))
+    return p, hs
+
+
+def test_raw_image_is_the_file_s_bytes_and_decodes_like_read_image(tmp_path):
+    from euispice_coreg_amd.utils import fits_io
+    p, _ = _several_hdus(tmp_path)
+    whole = open(p, "rb").read()
+    for window in (1, 2, 3, -1, "IMAGE"):
+        raw = fits_io.open_raw(p, window)
+        data, hdr = fits_io._read_all(p, only=window)[fits_io._select(
+            [(h, None) for h in fits_io._scan(p)[0]], window)][::-1]
+        assert raw is not None and raw.shape == data.shape and raw.header == hdr
+        got = np.asarray(raw)
+        assert got.dtype == data.dtype == raw.dtype and np.array_equal(got, data, equal_nan=True)
+        # the mapped bytes are the data unit itself
+        mapped = bytes(np.frombuffer(raw._bytes, dtype=np.uint8))
+        assert whole.count(mapped) >= 1 and len(mapped) == data.size * abs(raw.bitpix) // 8
+        assert fits_io.native_pixels(raw) is raw
+        raw.close()
+    assert fits_io.open_raw(p, 2).bscale == 0.25 and fits_io.open_raw(p, 2).bzero == 100.0
+    assert fits_io.open_raw(p, 0) is None            # no data unit
+    assert fits_io.open_raw((np.zeros((2, 2)), {}), 0) is None
+    assert fits_io.open_raw(str(tmp_path / "missing.fits")) is None
+    assert fits_io.open_raw(p, 9) is None and fits_io.open_raw(p, "NOPE") is None
+
+
+def test_write_corrected_fits_copies_data_units_and_rewrites_only_the_selected_headers(tmp_path):
+    """utils/Util.py:106-159: selected windows get corrected keywords and float32 data, everything else is copied."""
+    from euispice_coreg_amd.hdrshift import AlignmentResults
+    from euispice_coreg_amd.utils import fits_io, header as hdrutil
+    p, hs = _several_hdus(tmp_path)
+    R = AlignmentResults(REF_CORR, np.arange(15, 26, 1), np.arange(5, 11, 1), None, [0], [0.75], "arcsec",
+                         image_to_align_path=p)
+    out = str(tmp_path / "out.fits")
+    R.write_corrected_fits(["IMAGE", 2], out)
+    src, dst = open(p, "rb").read(), open(out, "rb").read()
+    (h_in, sp_in), (h_out, sp_out) = fits_io._scan(p), fits_io._scan(out)
+    assert len(h_out) == 4
+    # HDU 0 and 3: byte for byte, header included
+    pad = lambda n: (n + 2879) // 2880 * 2880
+    assert dst[:2880] == src[:2880]
+    a, b = sp_in[2][0] + pad(sp_in[2][1]), sp_out[2][0] + pad(sp_out[2][1])   # where HDU 3's header starts
+    assert src[a:] == dst[b:] and len(src) - a > 2880 + 40 * 40 * 8
+    # HDU 1 (float32): the data unit is the input's, bit for bit
+    n = sp_in[1][1]
+    assert src[sp_in[1][0]:sp_in[1][0] + n] == dst[sp_out[1][0]:sp_out[1][0] + n]
+    # HDU 2 (int16, scaled): converted to float32 as np.array(data, dtype="<f4") does
+    want = np.array(np.asarray(fits_io.open_raw(p, 2)), dtype="<f4")
+    got, h2 = fits_io.read_image(out, 2)
+    assert got.dtype == np.float32 and np.array_equal(got, want) and "BSCALE" not in h2 and h2["BITPIX"] == -32
+    # the corrected headers are what the decode -> correct -> encode path writes
+    ref_out = str(tmp_path / "ref.fits")
+    hdus = []
+    for ii, (d, h) in enumerate(fits_io.read_all(p)):
+        if ii in (1, 2):
+            h = h.copy()
+            s = R.shift_arcsec
+            hdrutil.correct_pointing_header(h, lag_crval1=s[0], lag_crval2=s[1], lag_cdelt1=s[2], lag_cdelt2=s[3],
+                                            lag_crota=s[4])
+            d = np.array(d, dtype="<f4")
+        hdus.append((d, h))
+    fits_io.write_images(ref_out, hdus)
+    h_ref = fits_io._scan(ref_out)[0]
+    assert h_out[1] == h_ref[1] and h_out[2] == h_ref[2]
+    assert h_out[1]["CRVAL1"] == pytest.approx(hs["CRVAL1"] + R.shift_arcsec[0], rel=1e-14)
+    # in place
+    R.write_corrected_fits([1], out, path_to_l2_input=out)
+    assert fits_io._scan(out)[0][1]["CRVAL1"] == pytest.approx(hs["CRVAL1"] + 2 * R.shift_arcsec[0], rel=1e-13)
+    with pytest.raises(ValueError):
+        R.write_corrected_fits(["no-such-window"], out)

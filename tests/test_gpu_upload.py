@@ -98,3 +98,101 @@ def test_device_source_uploads_equal_host_uploads(gpu_handle):
         gpu_handle.synchronize()
         assert np.array_equal(got_c, want_c, equal_nan=True) and np.array_equal(got_h, want_h, equal_nan=True)
         assert gpu_handle.last_stats()["small_is_f32"] == int(s_img.dtype == np.float32)
+
+
+def _write_fits(path, data, hdr, bscale=None, bzero=None):
+    """One image HDU behind an empty primary; BSCALE / BZERO renamed into place (write_images treats them as its own)."""
+    from euispice_coreg_amd.utils import fits_io
+    h = dict(hdr)
+    if bscale is not None:
+        h["BSCALX"], h["BZERX"] = float(bscale), float(bzero)
+    fits_io.write_images(path, [(None, {}), (data, h)])
+    if bscale is not None:
+        blob = open(path, "rb").read()
+        open(path, "wb").write(blob.replace(b"BSCALX  =", b"BSCALE  =").replace(b"BZERX   =", b"BZERO   ="))
+
+
+RAW_CASES = [("f4", None), ("f4", (0.5, 10.0)), ("f8", None), ("i2", None), ("i2", (0.25, 100.0)), ("i4", None),
+             ("i4", (1e-3, -7.0)), ("u1", None), ("i8", None)]
+
+
+@pytest.mark.parametrize("kind,scale", RAW_CASES)
+def test_raw_fits_uploads_are_bit_identical_to_decoded_uploads(gpu_handle, tmp_path, kind, scale):
+    """coreg_set_small_fits / coreg_prepare_reference_*_fits (raw big-endian data units, decoded on the GPU) against the
+    pixels utils/fits_io.py decodes on the host: same resident reference, same maps, every BITPIX, with and without
+    BSCALE / BZERO, reference cropped and whole."""
+    from euispice_coreg_amd import _lib
+    from euispice_coreg_amd.utils import fits_io
+    small, hs, large, hl, _ = H.scene(small_n=96, large_n=200)
+
+    def cast(a):
+        if kind == "f4":
+            return a.astype(np.float32)
+        if kind == "f8":
+            return a + 1e-9 * np.arange(a.size).reshape(a.shape)  # not float32-exact
+        b = np.nan_to_num(a, nan=0.0)
+        if kind == "u1":
+            return np.clip(b / 16.0, 0, 255).astype(np.uint8)
+        if kind == "i2":
+            return np.clip(b * 4.0 - 2000.0, -32768, 32767).astype(np.int16)
+        if kind == "i4":
+            return (b * 70001.0).astype(np.int32)       # beyond 2^24: not float32-exact
+        return (b * 3.0e9).astype(np.int64)
+    ps, pl = str(tmp_path / "s.fits"), str(tmp_path / "l.fits")
+    _write_fits(ps, cast(small), hs, *(scale or (None, None)))
+    _write_fits(pl, cast(large), hl, *(scale or (None, None)))
+    raw_s, raw_l = fits_io.open_raw(ps, -1), fits_io.open_raw(pl, -1)
+    dec_s, dec_l = fits_io.native_pixels(fits_io.read_image(ps, -1)[0]), fits_io.native_pixels(fits_io.read_image(pl, -1)[0])
+    assert raw_s is not None and raw_l is not None and np.array_equal(np.asarray(raw_s), dec_s, equal_nan=True)
+    grid = _lib.Grid(H.CARR_LON, H.CARR_LAT, SHAPE)
+    lags = _lib.LagSet(17.0 + 2.0 * (np.arange(5) - 2), -9.0 + 2.0 * (np.arange(4) - 2), None, None, [0.0, 0.3])
+    res = {}
+    for name, s_img, l_img in (("decoded", dec_s, dec_l), ("raw", raw_s, raw_l)):
+        gpu_handle.set_small(s_img)
+        out = [None]
+        for crop in (1, 0):
+            gpu_handle.set_option("crop_reference", crop)
+            try:
+                gpu_handle.prepare_reference_carrington(l_img, hl, grid, 1.004, 2)
+                out.append(gpu_handle.get_reference_on_grid((grid.n_lat, grid.n_lon), np.float64))
+            finally:
+                gpu_handle.set_option("crop_reference", 1)
+        out.append(gpu_handle.sweep_carrington(hs, grid, 1.004, lags))
+        gpu_handle.prepare_reference_helioprojective(l_img, hl, hs, 2)
+        out.append(gpu_handle.get_reference_on_grid((hs["NAXIS2"], hs["NAXIS1"]), np.float32))
+        out.append(gpu_handle.sweep_helioprojective(hs, hs, lags))
+        out.append(gpu_handle.resample_helioprojective(hs, hs, order=2, dtype=np.float64))  # the resident image itself
+        out[0] = gpu_handle.last_stats()["small_is_f32"]
+        res[name] = out
+    assert res["raw"][0] == res["decoded"][0]
+    for a, b in zip(res["raw"][1:], res["decoded"][1:]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.isfinite(res["raw"][3]).any()
+    # thresholds on the device see the same pixels
+    gpu_handle.set_small(raw_s)
+    n_raw = gpu_handle.threshold_small(None, float(np.nanpercentile(np.abs(dec_s), 90)))
+    gpu_handle.set_small(dec_s)
+    assert n_raw == gpu_handle.threshold_small(None, float(np.nanpercentile(np.abs(dec_s), 90)))
+
+
+def test_alignment_raw_fits_path_equals_host_decode(tmp_path, monkeypatch):
+    """`Alignment` on float32 FITS files: memory-mapped raw upload (default) and host decode (COREG_RAW_FITS=0) give the
+    same correlation array, in both frames; the image to align is never decoded on the host in the default path."""
+    from euispice_coreg_amd.hdrshift import Alignment
+    from euispice_coreg_amd.utils import fits_io
+    small, hs, large, hl, _ = H.scene()
+    ps, pl = str(tmp_path / "s.fits"), str(tmp_path / "l.fits")
+    _write_fits(ps, small.astype(np.float32), hs)
+    _write_fits(pl, large.astype(np.float32), hl)
+    lag1, lag2 = 17.0 + 2.0 * (np.arange(5) - 2), -9.0 + 2.0 * (np.arange(4) - 2)
+    out = {}
+    for raw in ("1", "0"):
+        monkeypatch.setenv("COREG_RAW_FITS", raw)
+        A = Alignment(pl, ps, lag1, lag2, [0], [0], [0], parallelism=True, small_fov_value_max=2500.0)
+        c = A.align_using_carrington(lonlims=H.CARR_LON, latlims=H.CARR_LAT, shape=SHAPE, return_type="corr")
+        assert isinstance(A.data_small, fits_io.RawImage) == (raw == "1")
+        B = Alignment(pl, ps, lag1, lag2, [0], [0], [0], parallelism=True)
+        out[raw] = (c, B.align_using_helioprojective(return_type="corr"))
+    assert np.array_equal(out["1"][0], out["0"][0], equal_nan=True)
+    assert np.array_equal(out["1"][1], out["0"][1], equal_nan=True)
+    assert np.isfinite(out["1"][0]).all()
