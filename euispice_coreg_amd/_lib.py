@@ -143,6 +143,7 @@ SYMBOLS = [
     ("coreg_multi_handle", _P, [_P, C.c_int]),
     ("coreg_multi_last_error", C.c_char_p, [_P]),
     ("coreg_multi_collective", C.c_char_p, [_P]),
+    ("coreg_multi_rccl_status", C.c_char_p, [_P]),
     ("coreg_multi_last_mode", C.c_int, [_P]),
     ("coreg_multi_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("coreg_multi_set_small", C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32]),
@@ -161,7 +162,8 @@ SYMBOLS = [
     ("coreg_multi_sweep_helioprojective", C.c_int, [_P, _WP, _WP, C.POINTER(Lags), C.c_int, C.c_int, C.c_int, _P]),
     ("coreg_multi_last_stats", C.c_int, [_P, C.c_int, C.POINTER(Stats)]),
     ("coreg_multi_plan", C.c_int,
-     [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+     [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+      C.POINTER(C.c_int32)]),
 ]
 
 _lib = None
@@ -559,7 +561,7 @@ class _HandleView(CoregHandle):
         self._h = None
 
 
-MULTI_MODES = {0: "none", 1: "blocks", 2: "slices", 3: "points"}
+MULTI_MODES = {0: "none", 1: "blocks", 2: "slices", 3: "points", 4: "combos"}
 
 
 def device_count() -> int:
@@ -568,13 +570,14 @@ def device_count() -> int:
 
 
 def multi_plan(n_crval1, n_crval2, n_inner, world):
-    """(mode, g1, g2) the in-library multi-GPU driver gives a lag set (host-only helper; mirrors parallel.py)."""
-    mode, g1, g2 = C.c_int32(), C.c_int32(), C.c_int32()
+    """(mode, g_combo, g1, g2) the in-library multi-GPU driver gives a lag set (host-only helper; mirrors
+    parallel.lag_plan)."""
+    mode, gc, g1, g2 = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
     rc = load_library().coreg_multi_plan(int(n_crval1), int(n_crval2), int(n_inner), int(world), C.byref(mode),
-                                         C.byref(g1), C.byref(g2))
+                                         C.byref(gc), C.byref(g1), C.byref(g2))
     if rc != COREG_OK:
         raise CoregError(rc, "coreg_multi_plan: bad arguments")
-    return MULTI_MODES[mode.value], g1.value, g2.value
+    return MULTI_MODES[mode.value], gc.value, g1.value, g2.value
 
 
 class MultiHandle:
@@ -623,6 +626,10 @@ class MultiHandle:
     @property
     def collective(self) -> str:
         return self._lib.coreg_multi_collective(self._m).decode()
+
+    @property
+    def rccl_status(self) -> str:
+        return self._lib.coreg_multi_rccl_status(self._m).decode()
 
     @property
     def last_mode(self) -> str:

@@ -154,6 +154,9 @@ struct coreg_handle {
     // tile groups and leaves the six sums per lag slot in `sums`; coreg_finalize_sums turns the all-reduced sums into
     // coefficients
     int64_t opt_shard_world = 1, opt_shard_rank = 0;
+    // multi-GPU combination sharding ("combo_begin" / "combo_end"): the NEXT sweep covers only the (cdelt1, cdelt2, crota)
+    // combinations [begin, end) of the lag set's inner C-order index; consumed (reset to "all") by that sweep
+    int64_t opt_combo_begin = 0, opt_combo_end = 0;
     DevBuf sums;
     long long sums_slots = 0;  // slots of the pending sharded sweep (all its launches)
     struct PendingFinalize {
@@ -545,8 +548,15 @@ int check_order(coreg_handle* h, int order) {
 // ---- lag batching ---------------------------------------------------------------------------------------------
 struct LagDims {
     int n1, n2, n3, n4, n5;
-    long long nc;  // n3*n4*n5
+    long long nc;  // (cdelt1, cdelt2, crota) combinations this sweep covers: n3*n4*n5, or the "combo_begin/_end" range
+    long long c0;  // first of them in the lag set's inner C-order index ((i3 * n4 + i4) * n5 + i5)
     long long total() const { return (long long)n1 * n2 * nc; }
+    void inner(long long c, int* i3, int* i4, int* i5) const {  // c in [0, nc)
+        const long long g = c + c0;
+        *i5 = (int)(g % n5);
+        *i4 = (int)((g / n5) % n4);
+        *i3 = (int)(g / ((long long)n5 * n4));
+    }
 };
 
 int check_lags(coreg_handle* h, const coreg_lags* l, LagDims* d, int64_t begin, int64_t end) {
@@ -560,6 +570,18 @@ int check_lags(coreg_handle* h, const coreg_lags* l, LagDims* d, int64_t begin, 
     d->n4 = l->n_cdelt2;
     d->n5 = l->n_crota;
     d->nc = (long long)d->n3 * d->n4 * d->n5;
+    d->c0 = 0;
+    {
+        // one-shot combination range of a multi-GPU sweep: consumed here, whatever happens next
+        const long long cb = h->opt_combo_begin, ce = h->opt_combo_end;
+        h->opt_combo_begin = h->opt_combo_end = 0;
+        if (cb != 0 || ce != 0) {
+            if (cb < 0 || ce <= cb || ce > d->nc)
+                return fail(h, COREG_EINVAL, "combo_begin/combo_end outside [0, n_cdelt1 * n_cdelt2 * n_crota]");
+            d->c0 = cb;
+            d->nc = ce - cb;
+        }
+    }
     if (begin < 0 || end > d->total() || begin > end)
         return fail(h, COREG_EINVAL, "lag_begin/lag_end outside [0, n_lags]");
     return COREG_OK;
@@ -1468,6 +1490,12 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         if (value < 1 || value > 64) return fail(h, COREG_EINVAL, "shard_world must be in [1, 64]");
         h->opt_shard_world = value;
         if (h->opt_shard_rank >= value) h->opt_shard_rank = 0;
+    } else if (n == "combo_begin") {
+        if (value < 0) return fail(h, COREG_EINVAL, "combo_begin must be >= 0");
+        h->opt_combo_begin = value;
+    } else if (n == "combo_end") {
+        if (value < 0) return fail(h, COREG_EINVAL, "combo_end must be >= 0");
+        h->opt_combo_end = value;
     } else if (n == "shard_rank") {
         if (value < 0 || value >= h->opt_shard_world) return fail(h, COREG_EINVAL, "shard_rank must be in [0, shard_world)");
         h->opt_shard_rank = value;
@@ -2026,7 +2054,8 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
             const long long first = (lag_begin - c + d.nc - 1) / d.nc;  // smallest k with k*nc + c >= begin
             if (first * d.nc + c >= lag_end) continue;
         }
-        const int i5 = (int)(c % d.n5), i4 = (int)((c / d.n5) % d.n4), i3 = (int)(c / ((long long)d.n5 * d.n4));
+        int i3, i4, i5;
+        d.inner(c, &i3, &i4, &i5);
         coreg_wcs2d hc;
         if (shift_header(*hdr_small, 0.0, 0.0, lags->cdelt1[i3], lags->cdelt2[i4], lags->crota[i5], cdelt_semantics,
                          &hc))
@@ -2193,7 +2222,8 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
     for (long long c = 0; c < d.nc; ++c) {
         const long long first = (lag_begin - c + d.nc - 1) / d.nc;
         if (first * d.nc + c >= lag_end) continue;
-        const int i5 = (int)(c % d.n5), i4 = (int)((c / d.n5) % d.n4), i3 = (int)(c / ((long long)d.n5 * d.n4));
+        int i3, i4, i5;
+        d.inner(c, &i3, &i4, &i5);
         coreg_wcs2d hc;
         if (shift_header(*hdr_small, 0.0, 0.0, lags->cdelt1[i3], lags->cdelt2[i4], lags->crota[i5], cdelt_semantics,
                          &hc))
@@ -2340,7 +2370,8 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     for (long long c = 0; c < d.nc; ++c) {
         const long long first = (lag_begin - c + d.nc - 1) / d.nc;
         if (first * d.nc + c >= lag_end) continue;
-        const int i5 = (int)(c % d.n5), i4 = (int)((c / d.n5) % d.n4), i3 = (int)(c / ((long long)d.n5 * d.n4));
+        int i3, i4, i5;
+        d.inner(c, &i3, &i4, &i5);
         coreg_wcs2d hc;
         if (shift_header(*hdr_small, 0.0, 0.0, lags->cdelt1[i3], lags->cdelt2[i4], lags->crota[i5], cdelt_semantics,
                          &hc))

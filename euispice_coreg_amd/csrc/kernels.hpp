@@ -475,6 +475,7 @@ __global__ void __launch_bounds__(256) k_fits_swap32(unsigned int* __restrict__ 
 // everything else: float64(stored) [* bscale + bzero, two roundings as NumPy's `a.astype(float64) * bscale + bzero`]
 __global__ void __launch_bounds__(256) k_fits_to_f64(const void* __restrict__ raw, int bitpix, int scaled, double bscale,
                                                      double bzero, long long n, double* __restrict__ out) {
+#pragma clang fp contract(off)  // multiply, round, add, round -- as NumPy does; an FMA would differ in the last bit
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         double x;
         switch (bitpix) {
@@ -485,7 +486,7 @@ __global__ void __launch_bounds__(256) k_fits_to_f64(const void* __restrict__ ra
             case -32: x = (double)__uint_as_float(__builtin_bswap32(((const unsigned int*)raw)[i])); break;
             default: x = __longlong_as_double((long long)__builtin_bswap64(((const unsigned long long*)raw)[i])); break;
         }
-        if (scaled) x = __dadd_rn(__dmul_rn(x, bscale), bzero);
+        if (scaled) x = x * bscale + bzero;
         out[i] = x;
     }
 }

@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is dlopen()ed, never linked
 
+#include <chrono>
 #include <functional>
 #include <memory>
 #include <queue>
@@ -29,6 +30,7 @@ struct RcclApi {
     void* lib = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;  // optional: gives up a communicator whose collective never returns
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -67,6 +69,7 @@ struct RcclApi {
 #define COREG_RCCL_SYM(F) a.F = (decltype(a.F))dlsym(a.lib, "nccl" #F)
                 COREG_RCCL_SYM(CommInitAll);
                 COREG_RCCL_SYM(CommDestroy);
+                COREG_RCCL_SYM(CommAbort);
                 COREG_RCCL_SYM(AllGather);
                 COREG_RCCL_SYM(AllReduce);
                 COREG_RCCL_SYM(GroupStart);
@@ -134,7 +137,7 @@ private:
 };
 
 // ---- the partition (mirror of euispice_coreg_amd/parallel.py: block_grid / block_bounds / lag_sharding) -----------
-enum { MULTI_NONE = 0, MULTI_BLOCKS = 1, MULTI_SLICES = 2, MULTI_POINTS = 3 };
+enum { MULTI_NONE = 0, MULTI_BLOCKS = 1, MULTI_SLICES = 2, MULTI_POINTS = 3, MULTI_COMBOS = 4 };
 constexpr long long kPointShardMaxLagsPerRank = 128;  // parallel.POINT_SHARD_MAX_LAGS_PER_RANK
 
 void multi_block_grid(int n1, int n2, int world, int* g1_out, int* g2_out) {
@@ -166,16 +169,68 @@ void multi_block_bounds(int n1, int n2, int world, int rank, int b[4]) {
     b[2] = std::min(r2 * b2, n2);
     b[3] = std::min((r2 + 1) * b2, n2);
 }
-int multi_lag_sharding(int n1, int n2, long long inner, int world) {
-    const long long n = (long long)n1 * n2 * inner;
-    if (world <= 1) return MULTI_NONE;
-    if (n < kPointShardMaxLagsPerRank * world) return MULTI_POINTS;
-    for (int r = 0; r < world; ++r) {
-        int b[4];
-        multi_block_bounds(n1, n2, world, r, b);
-        if (!(b[1] > b[0] && b[3] > b[2])) return MULTI_SLICES;
+// mirror of parallel.lag_batches / combo_bounds / lag_plan (checked against them on the CPU, tests/test_host_abi.py)
+constexpr double kLaunchOverheadBatches = 0.75;  // parallel.LAUNCH_OVERHEAD_BATCHES
+long long multi_lag_batches(int b1, int b2) {
+    if (b1 < 1 || b2 < 1) return 0;
+    long long best = -1;
+    for (int sw = 1; sw <= std::min(b1, 256); ++sw) {
+        const int sh = std::min(b2, 256 / sw);
+        const long long n = (long long)((b1 + sw - 1) / sw) * ((b2 + sh - 1) / sh);
+        if (best < 0 || n < best) best = n;
     }
-    return MULTI_BLOCKS;
+    return best;
+}
+void multi_combo_bounds(long long inner, int g_combo, int k, long long* lo, long long* hi) {
+    const long long q = inner / g_combo, r = inner % g_combo;
+    *lo = k * q + std::min<long long>(k, r);
+    *hi = *lo + q + (k < r ? 1 : 0);
+}
+struct MultiPlan {
+    int mode = MULTI_NONE, g_combo = 1, g1 = 1, g2 = 1;
+};
+MultiPlan multi_lag_plan(int n1, int n2, long long inner, int world) {
+    MultiPlan p;
+    const long long n = (long long)n1 * n2 * inner;
+    if (world <= 1) return p;
+    if (n < kPointShardMaxLagsPerRank * world) {
+        p.mode = MULTI_POINTS;
+        return p;
+    }
+    double best = -1.0;
+    for (int gc = 1; gc <= world; ++gc) {
+        if (world % gc || gc > inner) continue;
+        const int gb = world / gc;
+        bool full = true;
+        for (int r = 0; r < gb && full; ++r) {
+            int b[4];
+            multi_block_bounds(n1, n2, gb, r, b);
+            full = b[1] > b[0] && b[3] > b[2];
+        }
+        if (!full) continue;
+        int g1, g2;
+        multi_block_grid(n1, n2, gb, &g1, &g2);
+        const double cost = (double)((inner + gc - 1) / gc) *
+                            (kLaunchOverheadBatches + (double)multi_lag_batches((n1 + g1 - 1) / g1, (n2 + g2 - 1) / g2));
+        if (best < 0 || cost < best - 1e-9 || (std::fabs(cost - best) <= 1e-9 && gc > p.g_combo)) {
+            best = cost;
+            p.g_combo = gc;
+            p.g1 = g1;
+            p.g2 = g2;
+        }
+    }
+    if (best < 0) {
+        p.mode = MULTI_SLICES;
+        return p;
+    }
+    p.mode = p.g_combo > 1 ? MULTI_COMBOS : MULTI_BLOCKS;
+    return p;
+}
+// device k's share under a blocks / combos plan: block b[4] of the plane, combinations [c_lo, c_hi)
+void multi_grid_share(const MultiPlan& p, int n1, int n2, long long inner, int k, int b[4], long long* c_lo, long long* c_hi) {
+    const int gb = p.g1 * p.g2;
+    multi_block_bounds(n1, n2, gb, k % gb, b);
+    multi_combo_bounds(inner, p.g_combo, k / gb, c_lo, c_hi);
 }
 
 }  // namespace
@@ -194,6 +249,8 @@ struct coreg_multi {
     PinBuf host_gather;  // peer-copy collective: the devices' blocks, chunk doubles each
     std::vector<DevBuf> blk, gat;
     int last_mode = MULTI_NONE;
+    int force_mode = -1;            // coreg_multi_set_option "force_mode": tests of one partition on any lag set
+    std::string rccl_error;         // why RCCL was given up on this handle ("" = it was not)
     bool force_collective = false;  // COREG_MULTI_FORCE_RCCL=1 with ONE device: the RCCL calls run with a one-rank group
 };
 
@@ -237,6 +294,14 @@ int multi_sync_pivots(coreg_multi* m) {
     return multi_run(m, [&](int k) { return k == 0 ? COREG_OK : coreg_set_pivots(m->h[k], piv); });
 }
 
+// RCCL has failed (or never worked) on this multi-handle: from now on the blocks reach the host by one copy per device.
+// The streams are drained first so that nothing of the failed group is still queued behind the sweeps.
+void multi_drop_rccl(coreg_multi* m, const char* why) {
+    m->use_rccl = false;
+    m->rccl_error = why;
+    (void)multi_run(m, [&](int k) { return coreg_synchronize(m->h[k]); });
+}
+
 // one sweep on every device + the collective; `launch(k, lags_k, begin, end, out_dev)` = the per-device sweep call
 int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out,
                 const std::function<int(int, const coreg_lags*, int64_t, int64_t, double*)>& launch) {
@@ -248,7 +313,25 @@ int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out,
     const long long inner = (long long)lags->n_cdelt1 * lags->n_cdelt2 * lags->n_crota;
     const long long n_lags = (long long)n1 * n2 * inner;
     if (!corr_out && n_lags > 0) return mfail(m, COREG_EINVAL, "corr_out is null");
-    int mode = multi_lag_sharding(n1, n2, inner, world);
+    MultiPlan plan = multi_lag_plan(n1, n2, inner, world);
+    if (m->force_mode >= 0 && world > 1) {  // tests: "force_mode" 1 = blocks, 2 = slices, 4 = combos over the whole plane
+        if (m->force_mode == MULTI_SLICES) plan.mode = MULTI_SLICES;
+        if (m->force_mode == MULTI_BLOCKS || m->force_mode == MULTI_COMBOS) {
+            MultiPlan f;
+            f.mode = m->force_mode;
+            f.g_combo = m->force_mode == MULTI_COMBOS ? (int)std::min<long long>(world, inner) : 1;
+            while (world % f.g_combo) --f.g_combo;
+            multi_block_grid(n1, n2, world / f.g_combo, &f.g1, &f.g2);
+            bool full = true;
+            for (int r = 0; r < f.g1 * f.g2 && full; ++r) {
+                int bb[4];
+                multi_block_bounds(n1, n2, f.g1 * f.g2, r, bb);
+                full = bb[1] > bb[0] && bb[3] > bb[2];
+            }
+            if (full) plan = f;
+        }
+    }
+    int mode = plan.mode;
     if (mode == MULTI_NONE && m->force_collective) mode = MULTI_SLICES;  // one slice, one-rank all-gather
     m->last_mode = mode;
     if (mode == MULTI_NONE) {
@@ -259,12 +342,23 @@ int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out,
         if (rc != COREG_OK) return mfail(m, rc, coreg_last_error(m->h[0]));
         return COREG_OK;
     }
-    const bool rccl = m->use_rccl;
+    bool rccl = m->use_rccl;
     m->collective = rccl ? "rccl" : "host-copy";
 
     if (mode == MULTI_POINTS) {
         // every device sweeps ALL lag-points over its share of the grid; the six sums per lag slot are added over the
-        // devices (all-reduce), device 0 evaluates the coefficients
+        // devices (all-reduce), device 0 evaluates the coefficients.  Whatever happens in between, every context is
+        // back to "unsharded" and drained when this branch is left (a later sweep on the same contexts must not run as
+        // a grid share).
+        struct Unshard {
+            coreg_multi* m;
+            ~Unshard() {
+                (void)multi_run(m, [&](int k) {
+                    (void)coreg_set_option(m->h[k], "shard_world", 1);
+                    return coreg_synchronize(m->h[k]);
+                });
+            }
+        } unshard{m};
         RETCHK(multi_sync_pivots(m));
         RETCHK(multi_run(m, [&](int k) {
             coreg_handle* h = m->h[k];
@@ -277,18 +371,25 @@ int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out,
         int rc = COREG_OK;
         int64_t n6 = 0;
         coreg_sums_size(m->h[0], &n6);
+        bool reduced_on_device = false;
         if (rccl && n6 > 0) {
             ncclResult_t e = RcclApi::get().GroupStart();
             for (int k = 0; k < world && e == ncclSuccess; ++k)
                 e = RcclApi::get().AllReduce(m->h[k]->sums.p, m->h[k]->sums.p, (size_t)n6, ncclDouble, ncclSum, m->comms[k],
                                              m->h[k]->stream);
             const ncclResult_t e2 = RcclApi::get().GroupEnd();
-            if (e != ncclSuccess || e2 != ncclSuccess) rc = mfail(m, COREG_EHIP, "RCCL all-reduce failed");
-            if (rc == COREG_OK) {
-                m->w[0]->post([&] { rc = coreg_finalize_sums(m->h[0], m->h[0]->sums.as<double>(), 1, corr_out, 0); });
-                m->w[0]->wait();
-                if (rc != COREG_OK) mfail(m, rc, coreg_last_error(m->h[0]));
+            if (e != ncclSuccess || e2 != ncclSuccess) {
+                // (an all-reduce that failed half-way may have touched the sums: this sweep cannot be salvaged, the
+                // next one goes through the host)
+                multi_drop_rccl(m, "RCCL all-reduce failed");
+                return mfail(m, COREG_EHIP, "RCCL all-reduce failed (later sweeps of this handle add the sums on the host)");
             }
+            reduced_on_device = true;
+        }
+        if (reduced_on_device) {
+            m->w[0]->post([&] { rc = coreg_finalize_sums(m->h[0], m->h[0]->sums.as<double>(), 1, corr_out, 0); });
+            m->w[0]->wait();
+            if (rc != COREG_OK) mfail(m, rc, coreg_last_error(m->h[0]));
         } else if (n6 > 0) {
             std::vector<std::vector<double>> part(world, std::vector<double>((size_t)n6));
             rc = multi_run(m, [&](int k) { return coreg_copy_sums(m->h[k], part[k].data(), 0); });
@@ -310,57 +411,60 @@ int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out,
             });
             m->w[0]->wait();
         }
-        // back to unsharded contexts, and every stream drained before the caller's buffers go
-        const int rc2 = multi_run(m, [&](int k) {
-            RETCHK(coreg_set_option(m->h[k], "shard_world", 1));
-            return coreg_synchronize(m->h[k]);
-        });
-        return rc != COREG_OK ? rc : rc2;
+        return rc;  // (~Unshard: back to unsharded contexts, every stream drained before the caller's buffers go)
     }
 
-    // ---- lag sharding: blocks of the (CRVAL1, CRVAL2) plane, or contiguous slices of the raveled index
+    // ---- lag sharding: a g_combo x (g1 x g2) grid of (combination run) x (block of the CRVAL plane), or contiguous
+    //      slices of the raveled index
+    const bool grid = mode == MULTI_BLOCKS || mode == MULTI_COMBOS;
     long long chunk;
-    if (mode == MULTI_BLOCKS) {
-        int g1, g2;
-        multi_block_grid(n1, n2, world, &g1, &g2);
-        chunk = (long long)((n1 + g1 - 1) / g1) * ((n2 + g2 - 1) / g2) * inner;
-    } else {
+    if (grid)
+        chunk = (long long)((n1 + plan.g1 - 1) / plan.g1) * ((n2 + plan.g2 - 1) / plan.g2) *
+                ((inner + plan.g_combo - 1) / plan.g_combo);
+    else
         chunk = (n_lags + world - 1) / world;
-    }
-    if (!rccl && m->host_gather.reserve((size_t)chunk * world * sizeof(double)) != hipSuccess)
+    if (m->host_gather.reserve((size_t)chunk * world * sizeof(double)) != hipSuccess)
         return mfail(m, COREG_ENOMEM, "hipHostMalloc (gather buffer) failed");
     std::vector<long long> n_mine(world, 0);
+    auto to_host = [&](int k) {  // device k's block straight to its place in the host buffer, and its stream drained
+        coreg_handle* h = m->h[k];
+        RETCHK(bind_device(h));
+        if (n_mine[k] > 0)
+            HIPCHK(hipMemcpyAsync((double*)m->host_gather.p + (size_t)k * chunk, m->blk[k].p,
+                                  (size_t)n_mine[k] * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return COREG_OK;
+    };
     RETCHK(multi_run(m, [&](int k) {
         coreg_handle* h = m->h[k];
         RETCHK(bind_device(h));
+        RETCHK(coreg_set_option(h, "shard_world", 1));  // (never a grid share here, whatever an earlier call left)
         HIPCHK(m->blk[k].reserve((size_t)chunk * sizeof(double)));
         if (rccl) HIPCHK(m->gat[k].reserve((size_t)chunk * world * sizeof(double)));
         coreg_lags sub = *lags;
         int64_t lo = 0, hi = 0;
-        if (mode == MULTI_BLOCKS) {
+        if (grid) {
             int b[4];
-            multi_block_bounds(n1, n2, world, k, b);
+            long long c_lo, c_hi;
+            multi_grid_share(plan, n1, n2, inner, k, b, &c_lo, &c_hi);
             sub.crval1 = lags->crval1 + b[0];
             sub.n_crval1 = b[1] - b[0];
             sub.crval2 = lags->crval2 + b[2];
             sub.n_crval2 = b[3] - b[2];
-            hi = (int64_t)sub.n_crval1 * sub.n_crval2 * inner;
+            hi = (int64_t)sub.n_crval1 * sub.n_crval2 * (c_hi - c_lo);
+            if (hi > 0 && (c_lo != 0 || c_hi != inner)) {  // one-shot: consumed by the launch below
+                RETCHK(coreg_set_option(h, "combo_begin", c_lo));
+                RETCHK(coreg_set_option(h, "combo_end", c_hi));
+            }
         } else {
             lo = std::min<long long>((long long)k * chunk, n_lags);
             hi = std::min<long long>((long long)(k + 1) * chunk, n_lags);
         }
         n_mine[k] = hi - lo;
         if (hi > lo) RETCHK(launch(k, &sub, lo, hi, m->blk[k].as<double>()));
-        if (!rccl) {
-            // this device's block straight to its place in the host buffer (asynchronous; drained below)
-            if (hi > lo)
-                HIPCHK(hipMemcpyAsync((double*)m->host_gather.p + (size_t)k * chunk, m->blk[k].p,
-                                      (size_t)(hi - lo) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-        }
+        if (!rccl) RETCHK(to_host(k));
         return COREG_OK;
     }));
-    const double* gathered = (const double*)m->host_gather.p;
     if (rccl) {
         // THE collective: one all-gather of `chunk` doubles per device, all devices in one group, each on the stream its
         // sweep was enqueued on
@@ -368,38 +472,127 @@ int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out,
         for (int k = 0; k < world && e == ncclSuccess; ++k)
             e = RcclApi::get().AllGather(m->blk[k].p, m->gat[k].p, (size_t)chunk, ncclDouble, m->comms[k], m->h[k]->stream);
         const ncclResult_t e2 = RcclApi::get().GroupEnd();
-        if (e != ncclSuccess || e2 != ncclSuccess) return mfail(m, COREG_EHIP, "RCCL all-gather failed");
-        if (m->host_gather.reserve((size_t)chunk * world * sizeof(double)) != hipSuccess)
-            return mfail(m, COREG_ENOMEM, "hipHostMalloc (gather buffer) failed");
-        RETCHK(multi_run(m, [&](int k) {
-            coreg_handle* h = m->h[k];
-            RETCHK(bind_device(h));
-            if (k == 0)  // every device holds the whole map; device 0 hands it to the host
-                HIPCHK(hipMemcpyAsync(m->host_gather.p, m->gat[0].p, (size_t)chunk * world * sizeof(double),
-                                      hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            return COREG_OK;
-        }));
-        gathered = (const double*)m->host_gather.p;
+        if (e != ncclSuccess || e2 != ncclSuccess) {
+            // the blocks themselves are intact on their devices: hand them over through the host instead, now and for
+            // every later sweep of this handle
+            multi_drop_rccl(m, "RCCL all-gather failed");
+            m->collective = "host-copy (RCCL all-gather failed)";
+            rccl = false;
+            RETCHK(multi_run(m, to_host));
+        } else {
+            RETCHK(multi_run(m, [&](int k) {
+                coreg_handle* h = m->h[k];
+                RETCHK(bind_device(h));
+                if (k == 0)  // every device holds the whole map; device 0 hands it to the host
+                    HIPCHK(hipMemcpyAsync(m->host_gather.p, m->gat[0].p, (size_t)chunk * world * sizeof(double),
+                                          hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                return COREG_OK;
+            }));
+        }
     }
+    const double* gathered = (const double*)m->host_gather.p;
     // gathered chunks -> C-order raveled map
-    if (mode == MULTI_SLICES) {
+    if (!grid) {
         for (int k = 0; k < world; ++k)
             if (n_mine[k] > 0)
                 std::memcpy(corr_out + (size_t)k * chunk, gathered + (size_t)k * chunk, (size_t)n_mine[k] * sizeof(double));
     } else {
         for (int k = 0; k < world; ++k) {
             int b[4];
-            multi_block_bounds(n1, n2, world, k, b);
+            long long c_lo, c_hi;
+            multi_grid_share(plan, n1, n2, inner, k, b, &c_lo, &c_hi);
             const int w2 = b[3] - b[2];
+            const long long ncm = c_hi - c_lo;
+            if (ncm <= 0) continue;
             for (int i1 = b[0]; i1 < b[1]; ++i1)
                 for (int i2 = b[2]; i2 < b[3]; ++i2)
-                    std::memcpy(corr_out + ((size_t)i1 * n2 + i2) * inner,
-                                gathered + (size_t)k * chunk + ((size_t)(i1 - b[0]) * w2 + (i2 - b[2])) * inner,
-                                (size_t)inner * sizeof(double));
+                    std::memcpy(corr_out + ((size_t)i1 * n2 + i2) * inner + c_lo,
+                                gathered + (size_t)k * chunk + ((size_t)(i1 - b[0]) * w2 + (i2 - b[2])) * ncm,
+                                (size_t)ncm * sizeof(double));
         }
     }
     return COREG_OK;
+}
+
+// The communicators have never carried data: before any result depends on them, every device contributes (k + 1) * 1.5
+// to ONE grouped all-gather -- the very call a sweep makes -- and checks what it received.  The wait is bounded
+// (COREG_RCCL_SELFTEST_SECONDS, default 20): a group that does not come back is aborted (ncclCommAbort) and the handle
+// falls back to host copies, as it does when the pattern is wrong or a call fails.
+void multi_rccl_selftest(coreg_multi* m) {
+    const int world = m->n;
+    RcclApi& api = RcclApi::get();
+    std::string why;
+    bool ok = multi_run(m, [&](int k) {
+                  coreg_handle* h = m->h[k];
+                  RETCHK(bind_device(h));
+                  HIPCHK(m->blk[k].reserve(sizeof(double)));
+                  HIPCHK(m->gat[k].reserve((size_t)world * sizeof(double)));
+                  const double v = (k + 1) * 1.5;
+                  HIPCHK(hipMemcpyAsync(m->blk[k].p, &v, sizeof(double), hipMemcpyHostToDevice, h->stream));
+                  HIPCHK(hipMemsetAsync(m->gat[k].p, 0, (size_t)world * sizeof(double), h->stream));
+                  HIPCHK(hipStreamSynchronize(h->stream));
+                  return COREG_OK;
+              }) == COREG_OK;
+    if (!ok) why = "self-test setup failed";
+    if (ok) {
+        ncclResult_t e = api.GroupStart();
+        for (int k = 0; k < world && e == ncclSuccess; ++k)
+            e = api.AllGather(m->blk[k].p, m->gat[k].p, 1, ncclDouble, m->comms[k], m->h[k]->stream);
+        const ncclResult_t e2 = api.GroupEnd();
+        if (e != ncclSuccess || e2 != ncclSuccess) {
+            ok = false;
+            why = "self-test all-gather returned an error";
+        }
+    }
+    bool timed_out = false;
+    if (ok) {
+        const char* env = std::getenv("COREG_RCCL_SELFTEST_SECONDS");
+        const double limit = env && std::atof(env) > 0 ? std::atof(env) : 20.0;
+        std::vector<int> state(world, 0);  // 1 = done and right, 2 = done and wrong, 3 = timed out
+        (void)multi_run(m, [&](int k) {
+            coreg_handle* h = m->h[k];
+            RETCHK(bind_device(h));
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                const hipError_t q = hipStreamQuery(h->stream);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) {
+                    state[k] = 2;
+                    return COREG_OK;
+                }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+                    state[k] = 3;
+                    return COREG_OK;
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+            std::vector<double> got((size_t)world);
+            if (hipMemcpy(got.data(), m->gat[k].p, (size_t)world * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+                state[k] = 2;
+                return COREG_OK;
+            }
+            state[k] = 1;
+            for (int j = 0; j < world; ++j)
+                if (got[(size_t)j] != (j + 1) * 1.5) state[k] = 2;
+            return COREG_OK;
+        });
+        for (int k = 0; k < world; ++k) {
+            if (state[k] == 3) timed_out = true;
+            if (state[k] != 1) ok = false;
+        }
+        if (!ok) why = timed_out ? "self-test all-gather did not complete in time" : "self-test all-gather gave wrong values";
+    }
+    if (ok) return;
+    // give the communicators up; an aborted group releases the streams it holds
+    for (ncclComm_t c : m->comms)
+        if (c) {
+            if (timed_out && api.CommAbort) (void)api.CommAbort(c);
+            else (void)api.CommDestroy(c);
+        }
+    m->comms.clear();
+    m->use_rccl = false;
+    m->rccl_error = why;
 }
 
 }  // namespace
@@ -414,14 +607,20 @@ int coreg_device_count(void) {
     return ndev;
 }
 
-int coreg_multi_plan(int32_t n_crval1, int32_t n_crval2, int64_t n_inner, int32_t world, int32_t* mode, int32_t* g1,
-                     int32_t* g2) {
-    if (n_crval1 < 1 || n_crval2 < 1 || n_inner < 1 || world < 1 || !mode || !g1 || !g2) return COREG_EINVAL;
-    *mode = multi_lag_sharding(n_crval1, n_crval2, n_inner, world);
-    int a, b;
-    multi_block_grid(n_crval1, n_crval2, world, &a, &b);
-    *g1 = a;
-    *g2 = b;
+int coreg_multi_plan(int32_t n_crval1, int32_t n_crval2, int64_t n_inner, int32_t world, int32_t* mode, int32_t* g_combo,
+                     int32_t* g1, int32_t* g2) {
+    if (n_crval1 < 1 || n_crval2 < 1 || n_inner < 1 || world < 1 || !mode || !g_combo || !g1 || !g2) return COREG_EINVAL;
+    const MultiPlan p = multi_lag_plan(n_crval1, n_crval2, n_inner, world);
+    *mode = p.mode;
+    *g_combo = p.g_combo;
+    *g1 = p.g1;
+    *g2 = p.g2;
+    if (p.mode != MULTI_BLOCKS && p.mode != MULTI_COMBOS) {  // (what a block partition would be, for the record)
+        int a, b;
+        multi_block_grid(n_crval1, n_crval2, world, &a, &b);
+        *g1 = a;
+        *g2 = b;
+    }
     return COREG_OK;
 }
 
@@ -460,13 +659,21 @@ int coreg_multi_create(coreg_multi** out, int n_devices, const int* device_ids) 
             coreg_multi_destroy(m);
             return r;
         }
-    // one communicator per device, created together (ncclCommInitAll: the single-process form)
+    // one communicator per device, created together (ncclCommInitAll: the single-process form).  COREG_MULTI_COLLECTIVE=host
+    // keeps RCCL out of it (the blocks then reach the host by one copy per device, a few KB each).
     const char* force = std::getenv("COREG_MULTI_FORCE_RCCL");
+    const char* coll = std::getenv("COREG_MULTI_COLLECTIVE");
+    const bool want_rccl = !(coll && std::string(coll) == "host");
     m->force_collective = m->n == 1 && force && std::atoi(force) == 1;
-    if ((m->n > 1 || m->force_collective) && distinct && RcclApi::get().ok()) {
+    if (want_rccl && (m->n > 1 || m->force_collective) && distinct && RcclApi::get().ok()) {
         m->comms.assign(m->n, nullptr);
-        if (RcclApi::get().CommInitAll(m->comms.data(), m->n, m->devices.data()) == ncclSuccess) m->use_rccl = true;
-        else m->comms.clear();
+        if (RcclApi::get().CommInitAll(m->comms.data(), m->n, m->devices.data()) == ncclSuccess) {
+            m->use_rccl = true;
+            multi_rccl_selftest(m);  // a group that does not gather a known pattern is not used for results
+        } else {
+            m->comms.clear();
+            m->rccl_error = "ncclCommInitAll failed";
+        }
     }
     m->collective = m->use_rccl ? "rccl" : (m->n > 1 ? "host-copy" : "none");
     *out = m;
@@ -485,9 +692,9 @@ void coreg_multi_destroy(coreg_multi* m) {
         });
         m->w[k]->wait();
     }
-    if (m->use_rccl)
-        for (ncclComm_t c : m->comms)
-            if (c) (void)RcclApi::get().CommDestroy(c);
+    for (ncclComm_t c : m->comms)  // (empty when RCCL was never set up or has been given up)
+        if (c) (void)RcclApi::get().CommDestroy(c);
+    m->comms.clear();
     for (int k = 0; k < m->n; ++k) {
         if (!m->h[k]) continue;
         m->w[k]->post([m, k] { coreg_destroy(m->h[k]); });
@@ -503,10 +710,21 @@ int coreg_multi_size(const coreg_multi* m) { return m ? m->n : 0; }
 coreg_handle* coreg_multi_handle(coreg_multi* m, int k) { return (m && k >= 0 && k < m->n) ? m->h[k] : nullptr; }
 const char* coreg_multi_last_error(const coreg_multi* m) { return m ? m->err.c_str() : "null multi-handle"; }
 const char* coreg_multi_collective(const coreg_multi* m) { return m ? m->collective.c_str() : ""; }
+const char* coreg_multi_rccl_status(const coreg_multi* m) {
+    if (!m) return "";
+    if (m->use_rccl) return "ok";
+    return m->rccl_error.empty() ? "not used" : m->rccl_error.c_str();
+}
 int coreg_multi_last_mode(const coreg_multi* m) { return m ? m->last_mode : 0; }
 
 int coreg_multi_set_option(coreg_multi* m, const char* name, int64_t value) {
-    if (!m) return COREG_EINVAL;
+    if (!m || !name) return COREG_EINVAL;
+    if (std::string(name) == "force_mode") {  // -1 = the planner decides
+        if (value != -1 && value != MULTI_BLOCKS && value != MULTI_SLICES && value != MULTI_COMBOS)
+            return mfail(m, COREG_EINVAL, "force_mode must be -1, 1 (blocks), 2 (slices) or 4 (combos)");
+        m->force_mode = (int)value;
+        return COREG_OK;
+    }
     return multi_run(m, [&](int k) { return coreg_set_option(m->h[k], name, value); });
 }
 

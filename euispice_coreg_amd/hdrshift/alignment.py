@@ -357,13 +357,22 @@ class Alignment:
         mode = parallel.lag_sharding(lags.shape, world)
         self.last_sharding = mode
         my_lags, lo, hi = lags, 0, lags.size
-        if mode == "blocks":
-            lo1, hi1, lo2, hi2 = parallel.block_bounds(lags.shape[0], lags.shape[1], world, rank)
+        combos = None  # (c_lo, c_hi): this rank's run of (cdelt1, cdelt2, crota) combinations, None = all of them
+        if mode in ("blocks", "combos"):
+            lo1, hi1, lo2, hi2, c_lo, c_hi = parallel.grid_share(lags.shape, world, rank)
             a = lags.arrays
             my_lags = _lib.LagSet(a[0][lo1:hi1], a[1][lo2:hi2], a[2], a[3], a[4])
-            hi = my_lags.size
+            inner = lags.shape[2] * lags.shape[3] * lags.shape[4]
+            if (c_lo, c_hi) != (0, inner):
+                combos = (c_lo, c_hi)
+            hi = my_lags.shape[0] * my_lags.shape[1] * (c_hi - c_lo)
         elif mode == "slices":
             lo, hi, _ = parallel.shard_bounds(lags.size, world, rank)
+
+        def select_combos():
+            if combos is not None:  # one-shot options, consumed by the sweep call that follows
+                h.set_option("combo_begin", combos[0])
+                h.set_option("combo_end", combos[1])
 
         def prepare(kind, *args):
             """Once-only reference preparation.  The library uploads only the rectangle of the reference image the target
@@ -380,6 +389,7 @@ class Alignment:
                     h.reference_tag = tag
 
                 def run(g=grid, sr=solar_r):
+                    select_combos()
                     return h.sweep_carrington(self.hdr_small, g, sr, my_lags, order=self.order, method=method,
                                               cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
             elif self.coordinate_frame == "initial_carrington":
@@ -388,6 +398,7 @@ class Alignment:
                 h.set_reference_on_grid(np.asarray(self._large_pixels(), dtype=np.float32))
 
                 def run():
+                    select_combos()
                     return h.sweep_helioprojective(self.hdr_large, self.hdr_small, my_lags, order=self.order,
                                                    method=method, cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
             else:
@@ -399,11 +410,12 @@ class Alignment:
                     target = self.hdr_large
 
                 def run(t=target):
+                    select_combos()
                     return h.sweep_helioprojective(t, self.hdr_small, my_lags, order=self.order, method=method,
                                                    cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
             if mode == "points":
                 part = parallel.point_sharded_sweep(h, run, lags.size)
-            elif mode == "blocks":
+            elif mode in ("blocks", "combos"):
                 part = parallel.allgather_lag_blocks(run(), lags.shape)
             elif mode == "slices":
                 part = parallel.allgather_lag_slices(run(), lags.size).cpu().numpy()

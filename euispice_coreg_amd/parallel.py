@@ -81,30 +81,115 @@ def block_gather_index(shape5, world: int):
     return perm.reshape(-1), chunk
 
 
-def lag_sharding(shape5, world: int) -> str:
+# Cost model of the partition planner, in units of the sweep time of ONE batch of 256 lags (a workgroup's lag patch):
+# every (cdelt1, cdelt2, crota) combination is one precompute + one sweep launch; its fixed cost -- precompute, tile
+# list, ramp-up and drain of the launch -- was measured at 0.13-0.15 ms against 0.2 ms per batch on the headline
+# (DESIGN.md section 6), the same ratio on the 4096^2 grid of cfg5.
+LAUNCH_OVERHEAD_BATCHES = 0.75
+
+
+def lag_batches(b1: int, b2: int) -> int:
+    """Lag batches (workgroup patches of sw x sh <= 256 lags) the library needs for a b1 x b2 block of the CRVAL plane:
+    the minimum over patch shapes, as csrc/coreg_hip.hip:choose_plan searches it."""
+    if b1 < 1 or b2 < 1:
+        return 0
+    best = None
+    for sw in range(1, min(b1, 256) + 1):
+        sh = min(b2, 256 // sw)
+        n = (-(-b1 // sw)) * (-(-b2 // sh))
+        best = n if best is None else min(best, n)
+    return best
+
+
+def combo_bounds(inner: int, g_combo: int, k: int):
+    """Contiguous, balanced run of inner combinations for combo-rank k of g_combo (np.array_split's sizes)."""
+    q, r = divmod(inner, g_combo)
+    lo = k * q + min(k, r)
+    return lo, lo + q + (1 if k < r else 0)
+
+
+def lag_plan(shape5, world: int):
     """How a sweep over the lag set `shape5` = (n_crval1, n_crval2, n_cdelt1, n_cdelt2, n_crota) is spread over `world`
-    GPUs.  'none' (one GPU); 'points': every rank sweeps all lag-points over its share of the grid (few lag-points per
-    GPU, one all-reduce); 'blocks': the (CRVAL1, CRVAL2) plane cut in `world` near-square blocks (compact lag patches =
-    small LDS windows, no padded lanes; one all-gather) -- whenever a factorisation of `world` gives every rank a
-    non-empty block; 'slices': contiguous slices of the raveled C-order index, the literal np.array_split fan-out of the
-    reference (alignment.py:677-687), for lag sets whose plane is smaller than `world` (e.g. a pure CROTA sweep)."""
-    n = int(np.prod(shape5))
-    if world <= 1:
-        return "none"
-    if use_point_sharding(n, world):
-        return "points"
+    GPUs: (mode, g_combo, g1, g2).  The GPUs form a g_combo x (g1 x g2) grid: rank r = kc * (g1 * g2) + kb sweeps the
+    inner (cdelt1, cdelt2, crota) combinations `combo_bounds(inner, g_combo, kc)` over block kb of the (CRVAL1, CRVAL2)
+    plane.
+      'none'    one GPU;
+      'points'  every rank sweeps all lag-points over its share of the grid (few lag-points per GPU, one all-reduce);
+      'blocks'  g_combo = 1: the plane cut in `world` near-square blocks (compact lag patches = small LDS windows);
+      'combos'  g_combo > 1: the combinations are dealt to the GPUs, each sweeps the whole plane (or a block of it) at
+                one-GPU efficiency and runs 1 / g_combo of the precomputes -- what SURVEY 8(e) sketched for 3-D / 5-D
+                sweeps;
+      'slices'  contiguous slices of the raveled C-order index, the literal np.array_split fan-out of the reference
+                (alignment.py:677-687), when no grid gives every rank work (e.g. 3 x 3 CRVAL lags on 8 GPUs).
+    Among the grids that give every rank a non-empty share the planner takes the cheapest by the model above (cost of
+    the busiest rank: launches x (fixed cost + lag batches)); ties go to the larger g_combo."""
     n1, n2 = int(shape5[0]), int(shape5[1])
-    full = all(b[1] > b[0] and b[3] > b[2] for b in (block_bounds(n1, n2, world, r) for r in range(world)))
-    return "blocks" if full else "slices"
+    inner = int(shape5[2]) * int(shape5[3]) * int(shape5[4])
+    n = n1 * n2 * inner
+    if world <= 1:
+        return "none", 1, 1, 1
+    if use_point_sharding(n, world):
+        return "points", 1, 1, 1
+    best = None
+    for gc in range(1, world + 1):
+        if world % gc or gc > inner:
+            continue
+        gb = world // gc
+        if not all(b[1] > b[0] and b[3] > b[2] for b in (block_bounds(n1, n2, gb, r) for r in range(gb))):
+            continue
+        g1, g2 = block_grid(n1, n2, gb)
+        cost = (-(-inner // gc)) * (LAUNCH_OVERHEAD_BATCHES + lag_batches(-(-n1 // g1), -(-n2 // g2)))
+        if best is None or cost < best[0] - 1e-9 or (abs(cost - best[0]) <= 1e-9 and gc > best[1]):
+            best = (cost, gc, g1, g2)
+    if best is None:
+        return "slices", 1, 1, 1
+    return ("combos" if best[1] > 1 else "blocks"), best[1], best[2], best[3]
+
+
+def lag_sharding(shape5, world: int) -> str:
+    """The mode of `lag_plan` alone ('none', 'points', 'blocks', 'combos', 'slices')."""
+    return lag_plan(shape5, world)[0]
+
+
+def grid_share(shape5, world: int, rank: int):
+    """This rank's share under a 'blocks' / 'combos' plan: (lo1, hi1, lo2, hi2, c_lo, c_hi)."""
+    _, gc, g1, g2 = lag_plan(shape5, world)
+    gb = g1 * g2
+    kc, kb = rank // gb, rank % gb
+    inner = int(shape5[2]) * int(shape5[3]) * int(shape5[4])
+    c_lo, c_hi = combo_bounds(inner, gc, kc)
+    return block_bounds(int(shape5[0]), int(shape5[1]), gb, kb) + (c_lo, c_hi)
+
+
+def grid_gather_index(shape5, world: int):
+    """Index array `perm` (int64, prod(shape5) long) with full.ravel() = gathered[perm], where `gathered` is the
+    concatenation over ranks of each rank's C-order share [hi1-lo1, hi2-lo2, c_hi-c_lo] padded to `chunk` values.
+    Returns (perm, chunk).  With g_combo = 1 this is `block_gather_index`."""
+    n1, n2, n3, n4, n5 = (int(v) for v in shape5)
+    inner = n3 * n4 * n5
+    _, gc, g1, g2 = lag_plan(shape5, world)
+    chunk = (-(-n1 // g1)) * (-(-n2 // g2)) * (-(-inner // gc))
+    perm = np.empty((n1, n2, inner), dtype=np.int64)
+    for r in range(world):
+        lo1, hi1, lo2, hi2, c_lo, c_hi = grid_share(shape5, world, r)
+        if hi1 <= lo1 or hi2 <= lo2 or c_hi <= c_lo:
+            continue
+        w2, nc = hi2 - lo2, c_hi - c_lo
+        i1 = np.arange(lo1, hi1)[:, None, None]
+        i2 = np.arange(lo2, hi2)[None, :, None]
+        k = np.arange(nc)[None, None, :]
+        perm[lo1:hi1, lo2:hi2, c_lo:c_hi] = r * chunk + ((i1 - lo1) * w2 + (i2 - lo2)) * nc + k
+    return perm.reshape(-1), chunk
 
 
 def allgather_lag_blocks(local, shape5, group=None):
-    """Every rank holds the coefficients of its block of the lag plane (C order [hi1-lo1, hi2-lo2, n3, n4, n5], numpy):
-    ONE all-gather of ceil-sized chunks + one index permutation give the full raveled C-order map (numpy) on every rank."""
+    """Every rank holds the coefficients of its share of the lag set -- a block of the (CRVAL1, CRVAL2) plane times a run
+    of inner combinations (`grid_share`; C order [hi1-lo1, hi2-lo2, c_hi-c_lo], numpy): ONE all-gather of ceil-sized chunks
+    + one index permutation give the full raveled C-order map (numpy) on every rank."""
     import torch
     import torch.distributed as dist
     rank, world = world_info(group)
-    perm, chunk = block_gather_index(tuple(int(v) for v in shape5), world)
+    perm, chunk = grid_gather_index(tuple(int(v) for v in shape5), world)
     backend = dist.get_backend(group) if world > 1 else None
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     buf = torch.full((chunk,), float("nan"), dtype=torch.float64, device=dev)

@@ -270,6 +270,10 @@ int coreg_last_visit_counts(coreg_handle* h, int64_t* counts5);
  *   "crop_reference" 1 (default) coreg_prepare_reference_* upload only the rectangle of the reference image the target
  *                  grid can touch (bounding box of the sample coordinates, computed on the GPU; identical results),
  *                  0 the whole image
+ *   "combo_begin", "combo_end"  multi-GPU sharding by (cdelt1, cdelt2, crota) combination: the NEXT sweep call covers
+ *                  only the combinations [begin, end) of the inner C-order index (i_cdelt1 * n_cdelt2 + i_cdelt2) * n_crota
+ *                  + i_crota; its output (and lag_begin / lag_end) is the C-order array [n_crval1][n_crval2][end - begin].
+ *                  One-shot: consumed by that call, which leaves "all combinations" behind whether it succeeds or not.
  * Returns COREG_EINVAL for unknown names. */
 int coreg_set_option(coreg_handle* h, const char* name, int64_t value);
 
@@ -353,7 +357,11 @@ int coreg_multi_size(const coreg_multi* m);
 coreg_handle* coreg_multi_handle(coreg_multi* m, int k); /* device k's context (options, single-device utilities) */
 const char* coreg_multi_last_error(const coreg_multi* m);
 const char* coreg_multi_collective(const coreg_multi* m); /* "rccl", "host-copy" or "none" (what sweeps use / used) */
-int coreg_multi_last_mode(const coreg_multi* m);          /* partition of the last sweep: 0 none, 1 blocks, 2 slices, 3 points */
+/* "ok", "not used" (one device, virtual devices, no library, COREG_MULTI_COLLECTIVE=host), or why RCCL was given up: the
+ * communicators are tried once at creation with a known pattern (bounded wait), and a failing collective during a
+ * sweep makes the handle fall back to host copies for that sweep and all later ones */
+const char* coreg_multi_rccl_status(const coreg_multi* m);
+int coreg_multi_last_mode(const coreg_multi* m);          /* partition of the last sweep: 0 none, 1 blocks, 2 slices, 3 points, 4 combos */
 int coreg_multi_set_option(coreg_multi* m, const char* name, int64_t value);
 int coreg_multi_set_small(coreg_multi* m, const void* img, int dtype, int32_t ny, int32_t nx);
 /* the same with the pixels as the FITS data unit stores them (coreg_fits_pixels above) */
@@ -377,9 +385,11 @@ int coreg_multi_sweep_helioprojective(coreg_multi* m, const coreg_wcs2d* hdr_tar
                                       const coreg_lags* lags, int order, int method, int cdelt_semantics, double* corr_out);
 int coreg_multi_last_stats(coreg_multi* m, int k, coreg_stats* out);
 /* The partition a sweep over (n_crval1, n_crval2, n_inner = n_cdelt1 n_cdelt2 n_crota) lag-points gets on `world` GPUs
- * (host-only; checked against euispice_coreg_amd/parallel.py): mode as coreg_multi_last_mode, (g1, g2) the block grid. */
-int coreg_multi_plan(int32_t n_crval1, int32_t n_crval2, int64_t n_inner, int32_t world, int32_t* mode, int32_t* g1,
-                     int32_t* g2);
+ * (host-only; checked against euispice_coreg_amd/parallel.py): mode as coreg_multi_last_mode; the GPUs form a
+ * g_combo x (g1 x g2) grid: the inner combinations are dealt in g_combo contiguous runs, the (CRVAL1, CRVAL2) plane is
+ * cut in g1 x g2 blocks (mode 1 "blocks": g_combo = 1; mode 4 "combos": g_combo > 1). */
+int coreg_multi_plan(int32_t n_crval1, int32_t n_crval2, int64_t n_inner, int32_t world, int32_t* mode, int32_t* g_combo,
+                     int32_t* g1, int32_t* g2);
 
 #ifdef __cplusplus
 }

@@ -129,12 +129,51 @@ def test_lag_sharding_modes():
     for world in (2, 4, 8):
         assert parallel.lag_sharding((60, 60, 1, 1, 1), world) == "blocks"       # headline
         assert parallel.lag_sharding((121, 121, 1, 1, 1), world) == "blocks"     # cfg3
-        assert parallel.lag_sharding((61, 61, 1, 1, 21), world) == "blocks"      # cfg4
         assert parallel.lag_sharding((1, 2000, 1, 1, 1), world) == "blocks"      # one axis: blocks along the other
         assert parallel.lag_sharding((5, 5, 1, 1, 1), world) == "points"         # few lag-points per GPU
-        assert parallel.lag_sharding((1, 1, 1, 1, 2001), world) == "slices"      # no plane to cut: raveled slices
-    assert parallel.lag_sharding((3, 3, 5, 5, 11), 8) == "slices"                # 9 plane points, 8 GPUs: no full tiling
-    assert parallel.lag_sharding((3, 3, 5, 5, 11), 3) == "blocks"
+        # 3-D / 5-D sweeps: the (cdelt1, cdelt2, crota) combinations are dealt to the GPUs, each sweeps the
+        # whole plane at one-GPU efficiency
+        assert parallel.lag_plan((41, 41, 5, 5, 11), world) == ("combos", world, 1, 1)   # cfg5
+        assert parallel.lag_plan((1, 1, 1, 1, 2001), world) == ("combos", world, 1, 1)   # a pure CROTA sweep
+    assert parallel.lag_plan((61, 61, 1, 1, 21), 8) == ("combos", 8, 1, 1)               # cfg4
+    assert parallel.lag_plan((61, 61, 1, 1, 21), 4)[0] == "combos" and parallel.lag_sharding((61, 61, 1, 1, 21), 2) in (
+        "blocks", "combos")
+    assert parallel.lag_plan((3, 3, 5, 5, 11), 8) == ("combos", 8, 1, 1)
+    assert parallel.lag_plan((3, 3, 1, 1, 2), 8) == ("points", 1, 1, 1)
+    # 7 GPUs, 6 combinations, and a 12 x 15 plane that no 7 x 1 / 1 x 7 grid of ceil-sized blocks covers without an
+    # empty one: the literal np.array_split of the raveled index (alignment.py:677-687)
+    assert parallel.lag_sharding((12, 15, 1, 1, 6), 7) == "slices"
+    # balanced runs of combinations
+    assert [parallel.combo_bounds(21, 8, k) for k in range(8)] == [(0, 3), (3, 6), (6, 9), (9, 12), (12, 15), (15, 17),
+                                                                   (17, 19), (19, 21)]
+    assert parallel.lag_batches(60, 60) == 15 and parallel.lag_batches(41, 41) == 7 and parallel.lag_batches(21, 11) == 1
+
+
+def test_grid_gather_index_covers_every_lag_point_once():
+    """parallel.grid_gather_index: the permutation that turns the all-gathered shares (block of the plane x run of
+    combinations, padded to one chunk per rank) into the C-order map, for block, combo and mixed plans."""
+    from euispice_coreg_amd import parallel
+    for shape5 in ((7, 5, 1, 1, 1), (24, 24, 1, 1, 3), (20, 20, 1, 1, 3), (6, 9, 2, 3, 2), (41, 41, 5, 5, 11),
+                   (61, 61, 1, 1, 21), (1, 1, 1, 1, 2001)):
+        full = np.arange(int(np.prod(shape5)), dtype=np.float64).reshape(shape5)
+        inner = shape5[2] * shape5[3] * shape5[4]
+        for world in (2, 3, 4, 8):
+            mode, gc, g1, g2 = parallel.lag_plan(shape5, world)
+            if mode not in ("blocks", "combos"):
+                continue
+            assert gc * g1 * g2 == world
+            perm, chunk = parallel.grid_gather_index(shape5, world)
+            gathered = np.full(chunk * world, np.nan)
+            for r in range(world):
+                lo1, hi1, lo2, hi2, c_lo, c_hi = parallel.grid_share(shape5, world, r)
+                assert hi1 > lo1 and hi2 > lo2
+                part = full.reshape(shape5[0], shape5[1], inner)[lo1:hi1, lo2:hi2, c_lo:c_hi].ravel()
+                assert part.size <= chunk
+                gathered[r * chunk:r * chunk + part.size] = part
+            assert np.array_equal(gathered[perm], full.ravel()), (shape5, world)
+            if gc == 1:
+                p2, c2 = parallel.block_gather_index(shape5, world)
+                assert c2 == chunk and np.array_equal(p2, perm)
 
 
 def test_allgather_lag_slices_gloo_world2(tmp_path):
@@ -157,6 +196,13 @@ def test_allgather_lag_slices_gloo_world2(tmp_path):
         "    want = np.arange(int(np.prod(shape5)), dtype=np.float64).reshape(shape5) * 0.25 - 3.0\n"
         "    lo1, hi1, lo2, hi2 = parallel.block_bounds(shape5[0], shape5[1], world, rank)\n"
         "    full = parallel.allgather_lag_blocks(want[lo1:hi1, lo2:hi2], shape5)\n"
+        "    assert np.array_equal(full, want.ravel()), (rank, shape5)\n"
+        "for shape5 in [(24, 24, 1, 1, 2), (24, 24, 1, 1, 3), (41, 41, 5, 5, 11), (1, 1, 1, 1, 2001)]:\n"
+        "    assert parallel.lag_sharding(shape5, world) == 'combos'\n"
+        "    inner = shape5[2] * shape5[3] * shape5[4]\n"
+        "    want = np.arange(int(np.prod(shape5)), dtype=np.float64).reshape(shape5[0], shape5[1], inner) * 0.25 - 3.0\n"
+        "    lo1, hi1, lo2, hi2, c_lo, c_hi = parallel.grid_share(shape5, world, rank)\n"
+        "    full = parallel.allgather_lag_blocks(want[lo1:hi1, lo2:hi2, c_lo:c_hi], shape5)\n"
         "    assert np.array_equal(full, want.ravel()), (rank, shape5)\n"
         "assert parallel.replicate_image(np.zeros((4, 4), dtype=np.float32)) is None  # gloo: the caller uploads\n"
         "dist.barrier(); dist.destroy_process_group()\n"

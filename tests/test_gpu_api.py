@@ -162,10 +162,12 @@ def test_bench_two_ranks_point_sharded_gloo():
     assert out["pcie_inclusive"]["n_gpus"] == 2 and out["pcie_inclusive"]["value"] > 0
 
 
-def test_alignment_two_ranks_gloo_both_sharding_modes(tmp_path):
+def test_alignment_two_ranks_gloo_every_sharding_mode(tmp_path):
     """`Alignment` under torch.distributed (two ranks sharing the one GPU, gloo): a 5 x 5 lag set is below the
-    point-sharding threshold (grid shares + one all-reduce of the six sums per lag), a 24 x 24 one above it (blocks of
-    the lag plane + one all-gather, the partition bench.py times); both must give the single-process map on every rank."""
+    point-sharding threshold (grid shares + one all-reduce of the six sums per lag), a 24 x 24 one above it: with one
+    CROTA value blocks of the lag plane + one all-gather (the partition bench.py times), with two or three the CROTA
+    combinations are dealt to the ranks (each sweeps the whole plane); all must give the single-process map on every
+    rank."""
     import os
     import subprocess
     import sys
@@ -179,18 +181,20 @@ def test_alignment_two_ranks_gloo_both_sharding_modes(tmp_path):
         "from euispice_coreg_amd.hdrshift import Alignment\n"
         "from tests import helpers as H\n"
         "small, hs, large, hl, _ = H.scene()\n"
-        "def run(l1, l2, **kw):\n"
+        "def run(l1, l2, crota=(0.0, 0.3)):\n"
         "    A = Alignment((large, hl), (small, hs), lag_crval1=l1, lag_crval2=l2, lag_cdelt1=None, lag_cdelt2=None,\n"
-        "                  lag_crota=[0.0, 0.3], parallelism=True)\n"
+        "                  lag_crota=list(crota), parallelism=True)\n"
         "    return A.align_using_carrington(lonlims=H.CARR_LON, latlims=H.CARR_LAT, shape=(72, 64), return_type='corr')\n"
         "small_set = (17.0 + 2.0 * (np.arange(5) - 2), -9.0 + 2.0 * (np.arange(5) - 2))\n"
         "big_set = (17.0 + 1.0 * (np.arange(24) - 12), -9.0 + 1.0 * (np.arange(24) - 12))\n"
-        "single = [run(*small_set), run(*big_set)]\n"
+        "single = [run(*small_set), run(*big_set), run(*big_set, crota=(0.3,)), run(*big_set, crota=(0.0, 0.3, -0.2))]\n"
         "dist.init_process_group('gloo')\n"
         "rank, world = parallel.world_info()\n"
         "assert parallel.lag_sharding((5, 5, 1, 1, 2), world) == 'points'\n"
-        "assert parallel.lag_sharding((24, 24, 1, 1, 2), world) == 'blocks'\n"
-        "multi = [run(*small_set), run(*big_set)]\n"
+        "assert parallel.lag_plan((24, 24, 1, 1, 2), world) == ('combos', 2, 1, 1)\n"
+        "assert parallel.lag_sharding((24, 24, 1, 1, 1), world) == 'blocks'\n"
+        "assert parallel.lag_plan((24, 24, 1, 1, 3), world)[:2] == ('combos', 2)   # runs of 2 and 1 combinations\n"
+        "multi = [run(*small_set), run(*big_set), run(*big_set, crota=(0.3,)), run(*big_set, crota=(0.0, 0.3, -0.2))]\n"
         "for a, b in zip(single, multi):\n"
         "    assert a.shape == b.shape and np.nanmax(np.abs(a - b)) <= 1e-12, np.nanmax(np.abs(a - b))\n"
         "dist.barrier(); dist.destroy_process_group()\n"

@@ -26,38 +26,102 @@ def _multi_carr(m, small, hs, large, hl, lags, order=2, method=0):
 
 
 @pytest.mark.parametrize("n_virtual", [2, 3, 4])
-def test_multi_blocks_slices_points_equal_single_device(gpu_handle, monkeypatch, n_virtual):
-    from euispice_coreg_amd import _lib
+def test_multi_every_partition_equals_single_device(gpu_handle, monkeypatch, n_virtual):
+    """Blocks of the lag plane, runs of (cdelt1, cdelt2, crota) combinations (alone and mixed with blocks), raveled slices
+    and grid shares: the planner's choice for each lag set, and every lag partition forced on the 3-D lag set."""
+    from euispice_coreg_amd import _lib, parallel
     monkeypatch.setenv("COREG_VIRTUAL_DEVICES", str(n_virtual))
     small, hs, large, hl, _ = H.scene()
     assert _lib.device_count() == n_virtual
-    cases = {
-        "blocks": (17.0 + 1.0 * (np.arange(24) - 12), -9.0 + 1.0 * (np.arange(23) - 11), None, None, [0.0, 0.3]),
-        "slices": ([17.0], [-9.0], [0.0, 0.002], [-0.001, 0.0, 0.001], np.linspace(-1.0, 1.0, 90)),
-        "points": (17.0 + 2.0 * (np.arange(5) - 2), -9.0 + 2.0 * (np.arange(4) - 2), None, None, None),
-    }
+    l24, l23 = 17.0 + 1.0 * (np.arange(24) - 12), -9.0 + 1.0 * (np.arange(23) - 11)
+    cases = [
+        ("plane", (l24, l23, None, None, [0.3]), -1),
+        ("3-D", (l24, l23, None, None, [0.0, 0.3, -0.2]), -1),
+        ("3-D", (l24, l23, None, None, [0.0, 0.3, -0.2]), 1),
+        ("3-D", (l24, l23, None, None, [0.0, 0.3, -0.2]), 2),
+        ("3-D", (l24, l23, None, None, [0.0, 0.3, -0.2]), 4),
+        ("5-D", (l24[:12], l23[:9], [0.0, 0.002], [-0.001, 0.0, 0.001], [0.0, 0.3]), -1),
+        ("inner only", ([17.0], [-9.0], [0.0, 0.002], [-0.001, 0.0, 0.001], np.linspace(-1.0, 1.0, 90)), -1),
+        ("inner only", ([17.0], [-9.0], [0.0, 0.002], [-0.001, 0.0, 0.001], np.linspace(-1.0, 1.0, 90)), 2),
+        ("few", (17.0 + 2.0 * (np.arange(5) - 2), -9.0 + 2.0 * (np.arange(4) - 2), None, None, None), -1),
+    ]
+    seen = set()
     with _lib.MultiHandle() as m:
-        assert m.size == n_virtual and m.collective == "host-copy"
-        for mode, lags in cases.items():
+        assert m.size == n_virtual and m.collective == "host-copy" and m.rccl_status == "not used"
+        for name, lags, force in cases:
+            ls = _lib.LagSet(*lags)
+            m.set_option("force_mode", force)
             got = _multi_carr(m, small, hs, large, hl, lags)
-            assert m.last_mode == mode, (mode, m.last_mode)
+            mode = {-1: parallel.lag_sharding(ls.shape, n_virtual), 1: "blocks", 2: "slices", 4: "combos"}[force]
+            assert m.last_mode == mode, (name, force, mode, m.last_mode)
+            seen.add(mode)
             want = _single_carr(gpu_handle, small, hs, large, hl, lags)
-            assert np.array_equal(np.isnan(got), np.isnan(want)), mode
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (name, mode)
             # (different lag sets cull the grid differently: agreement to rounding, as for slices of one handle)
-            assert np.nanmax(np.abs(got - want)) <= 1e-12, (mode, n_virtual)
+            assert np.nanmax(np.abs(got - want)) <= 1e-12, (name, mode, n_virtual)
             assert np.nanargmax(got) == np.nanargmax(want)
             st = m.last_stats()
             assert st["n_devices"] == n_virtual and st["lag_sharding"] == mode
             assert len(st["per_device_sweep_kernel_ms"]) == n_virtual
+        m.set_option("force_mode", -1)
+        assert seen == {"blocks", "combos", "slices", "points"}
         # method 'residus' through the grid-share mode (sums from different devices add up about the same pivots)
-        got = _multi_carr(m, small, hs, large, hl, cases["points"], method=1)
-        gpu_handle.set_small(small)
-        want = H.gpu_carrington(gpu_handle, small, hs, large, hl, cases["points"], SHAPE).ravel() * 0  # shape only
+        few = cases[-1][1]
+        got = _multi_carr(m, small, hs, large, hl, few, method=1)
         grid = _lib.Grid(H.CARR_LON, H.CARR_LAT, SHAPE)
-        want = gpu_handle.sweep_carrington(hs, grid, 1.004, _lib.LagSet(*cases["points"]), method=1)
+        gpu_handle.set_small(small)
+        gpu_handle.prepare_reference_carrington(large, hl, grid, 1.004, 2)
+        want = gpu_handle.sweep_carrington(hs, grid, 1.004, _lib.LagSet(*few), method=1)
         assert np.array_equal(np.isnan(got), np.isnan(want))
         if np.isfinite(want).any():
             assert np.nanmax(np.abs(got - want)) <= 1e-10
+        # a sweep that fails inside the grid-share branch must not leave the contexts sharded (ADVICE r03): the next
+        # lag-sharded sweep on the same handle gives the whole map
+        m.set_reference_on_grid(np.full((SHAPE[1], SHAPE[0]), np.nan))  # all-NaN reference: the pivot is not finite
+        with pytest.raises(_lib.CoregError):
+            m.sweep_carrington(hs, grid, 1.004, _lib.LagSet(*few))
+        got = _multi_carr(m, small, hs, large, hl, cases[0][1])
+        want = _single_carr(gpu_handle, small, hs, large, hl, cases[0][1])
+        assert m.last_mode == "blocks" and np.nanmax(np.abs(got - want)) <= 1e-12
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+
+
+def test_combo_range_option_is_one_shot_and_selects_the_combinations(gpu_handle):
+    """coreg_set_option "combo_begin" / "combo_end" on a single context: the next sweep covers that run of (cdelt1,
+    cdelt2, crota) combinations only, output [n1][n2][run]; the sweep after it covers everything again; bad ranges are
+    refused and leave nothing behind.  Both frames."""
+    from euispice_coreg_amd import _lib
+    small, hs, large, hl, _ = H.scene()
+    lags = (17.0 + 1.0 * (np.arange(7) - 3), -9.0 + 1.0 * (np.arange(6) - 3), [0.0, 0.002], [-0.001, 0.0, 0.001],
+            [0.0, 0.3, -0.2])
+    ls = _lib.LagSet(*lags)
+    inner = 2 * 3 * 3
+    grid = _lib.Grid(H.CARR_LON, H.CARR_LAT, SHAPE)
+    gpu_handle.set_small(small)
+    gpu_handle.prepare_reference_carrington(large, hl, grid, 1.004, 2)
+    full = gpu_handle.sweep_carrington(hs, grid, 1.004, ls).reshape(7, 6, inner)
+    for c_lo, c_hi in ((0, 5), (5, 6), (7, 18), (0, 18)):
+        gpu_handle.set_option("combo_begin", c_lo)
+        gpu_handle.set_option("combo_end", c_hi)
+        part = gpu_handle.sweep_carrington(hs, grid, 1.004, ls, lag_end=7 * 6 * (c_hi - c_lo)).reshape(7, 6, c_hi - c_lo)
+        assert np.array_equal(np.isnan(part), np.isnan(full[:, :, c_lo:c_hi]))
+        assert np.nanmax(np.abs(part - full[:, :, c_lo:c_hi])) <= 1e-12
+    again = gpu_handle.sweep_carrington(hs, grid, 1.004, ls).reshape(7, 6, inner)  # the range was consumed
+    assert np.array_equal(again, full, equal_nan=True)
+    gpu_handle.set_option("combo_begin", 4)
+    gpu_handle.set_option("combo_end", 19)
+    with pytest.raises(_lib.CoregError):
+        gpu_handle.sweep_carrington(hs, grid, 1.004, ls, lag_end=10)
+    again = gpu_handle.sweep_carrington(hs, grid, 1.004, ls).reshape(7, 6, inner)
+    assert np.array_equal(again, full, equal_nan=True)
+    # helioprojective sub-map semantics, a slice of the restricted index
+    gpu_handle.prepare_reference_helioprojective(large, hl, hs, 2)
+    fullh = gpu_handle.sweep_helioprojective(hs, hs, ls).reshape(7, 6, inner)
+    gpu_handle.set_option("combo_begin", 3)
+    gpu_handle.set_option("combo_end", 11)
+    part = gpu_handle.sweep_helioprojective(hs, hs, ls, lag_begin=8, lag_end=7 * 6 * 8 - 5)
+    want = fullh[:, :, 3:11].ravel()[8:7 * 6 * 8 - 5]
+    assert np.array_equal(np.isnan(part), np.isnan(want)) and np.nanmax(np.abs(part - want)) <= 1e-12
 
 
 def test_multi_helioprojective_with_the_zero_lag(gpu_handle, monkeypatch):
@@ -119,6 +183,11 @@ def test_alignment_uses_every_visible_gpu_from_a_plain_script(tmp_path, monkeypa
         multi, A2 = run()
         assert A2.last_stats["n_devices"] == 2 and A2.last_sharding == "blocks"
         assert np.nanmax(np.abs(multi - single)) <= 1e-12 and np.nanargmax(multi) == np.nanargmax(single)
+        # a 3-D sweep: the CROTA combinations are dealt to the devices
+        A3 = Alignment((large, hl), (small, hs), lag_crval1=lag1, lag_crval2=lag2, lag_cdelt1=None, lag_cdelt2=None,
+                       lag_crota=[0.0, 0.3], parallelism=True)
+        c3 = A3.align_using_carrington(lonlims=H.CARR_LON, latlims=H.CARR_LAT, shape=SHAPE, return_type="corr")
+        assert A3.last_sharding == "combos" and np.nanmax(np.abs(c3[:, :, 0, 0, 0] - single[:, :, 0, 0, 0])) <= 1e-12
         # helioprojective frame, FITS in, through the same driver
         B = Alignment((large, hl), (small, hs), lag_crval1=lag1, lag_crval2=lag2, lag_cdelt1=None, lag_cdelt2=None,
                       lag_crota=None, parallelism=True)

@@ -279,9 +279,18 @@ def test_multi_plan_matches_the_python_partition(lib):
     set the same way: mode and block grid for a spread of lag shapes and GPU counts."""
     from euispice_coreg_amd import parallel
     shapes = [(60, 60, 1), (61, 61, 1), (121, 121, 1), (61, 61, 21), (41, 41, 275), (1, 2000, 1), (2000, 1, 1),
-              (5, 5, 1), (1, 1, 2001), (3, 3, 275), (7, 2, 40), (2, 7, 40), (16, 16, 1), (1, 1, 1), (9, 9, 2)]
+              (5, 5, 1), (1, 1, 2001), (3, 3, 275), (7, 2, 40), (2, 7, 40), (16, 16, 1), (1, 1, 1), (9, 9, 2),
+              (24, 24, 2), (24, 24, 3), (20, 20, 3), (12, 15, 6), (61, 61, 2), (100, 100, 5), (31, 17, 12), (4, 300, 7)]
+    seen = set()
     for n1, n2, inner in shapes:
-        for world in (1, 2, 3, 4, 6, 8):
-            mode, g1, g2 = lib.multi_plan(n1, n2, inner, world)
-            assert mode == parallel.lag_sharding((n1, n2, inner, 1, 1), world), (n1, n2, inner, world)
-            assert (g1, g2) == parallel.block_grid(n1, n2, world), (n1, n2, inner, world)
+        for world in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16):
+            mode, gc, g1, g2 = lib.multi_plan(n1, n2, inner, world)
+            want = parallel.lag_plan((n1, n2, inner, 1, 1), world)
+            seen.add(mode)
+            assert mode == want[0], (n1, n2, inner, world, mode, want)
+            if mode in ("blocks", "combos"):
+                assert (gc, g1, g2) == want[1:] and gc * g1 * g2 == world, (n1, n2, inner, world, (gc, g1, g2), want)
+                assert (mode == "combos") == (gc > 1)
+            else:
+                assert (g1, g2) == parallel.block_grid(n1, n2, world), (n1, n2, inner, world)
+    assert seen == {"none", "points", "blocks", "combos", "slices"}
