@@ -137,6 +137,7 @@ SYMBOLS = [
       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     # all GPUs of the node from one process
     ("coreg_device_count", C.c_int, []),
+    ("coreg_physical_device_count", C.c_int, []),
     ("coreg_multi_create", C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(C.c_int)]),
     ("coreg_multi_destroy", None, [_P]),
     ("coreg_multi_size", C.c_int, [_P]),
@@ -567,6 +568,11 @@ MULTI_MODES = {0: "none", 1: "blocks", 2: "slices", 3: "points", 4: "combos"}
 def device_count() -> int:
     """GPUs the library sees (COREG_VIRTUAL_DEVICES overrides it); 0 when there is none.  Does not touch torch."""
     return max(0, int(load_library().coreg_device_count()))
+
+
+def physical_device_count() -> int:
+    """GPUs actually present (coreg_device_count() minus the COREG_VIRTUAL_DEVICES mapping)."""
+    return max(0, int(load_library().coreg_physical_device_count()))
 
 
 def multi_plan(n_crval1, n_crval2, n_inner, world):

@@ -607,6 +607,12 @@ int coreg_device_count(void) {
     return ndev;
 }
 
+int coreg_physical_device_count(void) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    return ndev;
+}
+
 int coreg_multi_plan(int32_t n_crval1, int32_t n_crval2, int64_t n_inner, int32_t world, int32_t* mode, int32_t* g_combo,
                      int32_t* g1, int32_t* g2) {
     if (n_crval1 < 1 || n_crval2 < 1 || n_inner < 1 || world < 1 || !mode || !g_combo || !g1 || !g2) return COREG_EINVAL;

@@ -11,9 +11,14 @@ Same arguments and same outputs as the reference.  What changes is how the work 
   * a reader thread decodes the next image(s), `pipeline_depth` (default 2) driver threads -- each with its own
     library context and stream on the GPU -- upload and sweep, and a writer thread fits / writes the previous result:
     the GPU always has the next sweep queued behind the running one;
-  * with torch.distributed initialised (one process per GPU) the images of a sublist -- independent units once their
-    reference is fixed -- are dealt round-robin to the ranks; ranks meet at a barrier between sublists because the next
-    sublist's reference is an output of this one (jitter_correction.py:106, :137-138).  No data-path collective.
+  * every GPU of the machine from the plain script, as the reference uses every core (its sweeps fan out over a
+    process pool, jitter_correction.py:214-224 -> alignment.py:692-744): the images of a sublist -- independent units
+    once their reference is fixed -- are dealt round-robin to the visible devices, each with its own `pipeline_depth`
+    driver threads and library contexts and its own resident copy of the prepared reference; all outputs of a sublist
+    are on disk before the next one starts (its reference is one of them, jitter_correction.py:106, :137-138).
+    Threads only, never a fork.  `device=` or COREG_SINGLE_DEVICE=1 keep one GPU;
+  * with torch.distributed initialised (one process per GPU) the images of a sublist are dealt round-robin to the
+    ranks instead, each rank on its own device; ranks meet at a barrier between sublists.  No data-path collective.
 `parallelism`, `cpu_count` are accepted and ignored (they size the reference's process pool).
 """
 from __future__ import annotations
@@ -26,7 +31,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-from .. import parallel
+from .. import _lib, parallel
 from ..hdrshift.alignment import Alignment
 from ..utils import fits_io
 
@@ -74,19 +79,22 @@ def jitter_correction_imagers(list_files_input, path_files_output, lonlims=None,
     os.makedirs(path_files_output, exist_ok=True)
 
     done = []
-    prefetch = max(1, int(prefetch))
     depth = max(1, int(pipeline_depth))
+    devices = session_devices(device, world)
+    prefetch = max(1, int(prefetch), len(devices))
     reader = ThreadPoolExecutor(max_workers=prefetch)
-    drivers = ThreadPoolExecutor(max_workers=depth)
-    writer = ThreadPoolExecutor(max_workers=1)
+    # one pool of `depth` driver threads per device; thread t of device d owns library context (d, slot t)
+    drivers = [ThreadPoolExecutor(max_workers=depth) for _ in devices]
+    writer = ThreadPoolExecutor(max_workers=max(1, min(4, len(devices))))
     slots = threading.local()
-    slot_ids = iter(range(depth))
+    slot_ids = [iter(range(depth)) for _ in devices]
     slot_lock = threading.Lock()
 
-    def drive(index_to_align, index_ref, path_reference, fut_image):
+    def drive(k_dev, index_to_align, index_ref, path_reference, fut_image):
         if not hasattr(slots, "id"):
             with slot_lock:
-                slots.id = next(slot_ids)
+                slots.id = next(slot_ids[k_dev])
+        dev, slot0 = devices[k_dev]
         A, corr = _align_hrieuv_with_hrieuv(
             large_fov_fits_path=path_reference, large_fov_window=window_files_input,
             small_fov_path=list_files_input[index_to_align], window_to_align=window_files_input,
@@ -94,10 +102,10 @@ def jitter_correction_imagers(list_files_input, path_files_output, lonlims=None,
             cpu_count=cpu_count, do_plot_figure=plot_all_figures,
             method_carrington_reprojection=method_carrington_reprojection, reference_date=dates[index_ref],
             parallelism=parallelism, alignement_method=alignement_method, small_fov_value_max=small_fov_value_max,
-            small_fov_value_min=small_fov_value_min, unit_lag=unit_lag, device=device,
-            _preloaded_small=fut_image.result(), _return_corr=True, _handle_slot=slots.id, **kwargs_carrington)
+            small_fov_value_min=small_fov_value_min, unit_lag=unit_lag, device=dev,
+            _preloaded_small=fut_image.result(), _return_corr=True, _handle_slot=slot0 + slots.id, **kwargs_carrington)
         out_path = os.path.join(path_files_output, os.path.basename(list_files_input[index_to_align]))
-        # sub-lag Gaussian fit + corrected FITS in the writer thread: the GPU is already on the next image
+        # sub-lag Gaussian fit + corrected FITS in a writer thread: the GPU is already on the next image
         figure_path = None
         if path_figures is not None:
             figure_path = os.path.join(path_figures, f"correlation_{_time_tag(dates[index_to_align])}_"
@@ -112,23 +120,43 @@ def jitter_correction_imagers(list_files_input, path_files_output, lonlims=None,
                 shutil.copyfile(list_files_input[index_ref], path_reference)
             _barrier(world)  # the reference of this sublist is on disk for every rank
             mine = [int(i) for k, i in enumerate(list_[1:]) if k % world == rank]
-            # bounded look-ahead: at most prefetch + depth decoded images are alive at any time
+            # bounded look-ahead: at most prefetch + depth images per device are in flight at any time
             inflight = []
-            for index_to_align in mine:
-                while len(inflight) >= prefetch + depth:
+            for k, index_to_align in enumerate(mine):
+                while len(inflight) >= prefetch + depth * len(devices):
                     i0, f0 = inflight.pop(0)
                     done.append((i0, index_ref, f0.result().result()))
                 img = reader.submit(fits_io.load_for_upload, list_files_input[index_to_align], window_files_input)
-                inflight.append((index_to_align, drivers.submit(drive, index_to_align, index_ref, path_reference, img)))
+                k_dev = k % len(devices)
+                inflight.append((index_to_align, drivers[k_dev].submit(drive, k_dev, index_to_align, index_ref,
+                                                                       path_reference, img)))
             for i0, f0 in inflight:
                 # surfaces exceptions; every output of this sublist is on disk before the next one starts
                 done.append((i0, index_ref, f0.result().result()))
             _barrier(world)
     finally:
         reader.shutdown(wait=True)
-        drivers.shutdown(wait=True)
+        for d in drivers:
+            d.shutdown(wait=True)
         writer.shutdown(wait=True)
     return done
+
+
+def session_devices(device=None, world=1):
+    """[(physical device, first context slot)] the session drives from this process: the one asked for (`device=`, a
+    rank of a torch.distributed job, COREG_SINGLE_DEVICE=1), else every visible GPU.  COREG_VIRTUAL_DEVICES=k (tests on a
+    one-GPU box) gives k logical devices: logical device L is physical device L mod n with its own block of context
+    slots."""
+    if device is not None:
+        return [(device, 0)]
+    if world > 1:
+        return [(None, 0)]  # (hdrshift.Alignment takes the rank's current device)
+    if os.environ.get("COREG_SINGLE_DEVICE", "0") == "1":
+        return [(-1, 0)]
+    n_logical, n_physical = _lib.device_count(), _lib.physical_device_count()
+    if n_logical <= 1 or n_physical < 1:
+        return [(-1, 0)]
+    return [(L % n_physical, 16 * (L // n_physical)) for L in range(n_logical)]
 
 
 def _finish(A, corr, window, out_path, figure_path=None):

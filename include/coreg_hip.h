@@ -351,6 +351,7 @@ int coreg_fit_gaussian2d(int32_t m, const double* x, const double* y, const doub
  * ones (dtype = COREG_F32 / COREG_F64 of the host pixels); sweeps return the WHOLE map, C order, in host memory. */
 typedef struct coreg_multi coreg_multi;
 int coreg_device_count(void); /* visible GPUs, or COREG_VIRTUAL_DEVICES when set */
+int coreg_physical_device_count(void); /* visible GPUs (logical device L of a virtual set is physical device L mod this) */
 int coreg_multi_create(coreg_multi** m, int n_devices, const int* device_ids);
 void coreg_multi_destroy(coreg_multi* m);
 int coreg_multi_size(const coreg_multi* m);

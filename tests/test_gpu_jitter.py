@@ -159,3 +159,40 @@ def test_two_library_contexts_sweep_concurrently(series):
             t.join()
         for k in range(1, 5):
             assert np.array_equal(seq[k], par[k], equal_nan=True), (rounds, k)
+
+
+def test_session_drives_every_device_from_one_process(series, tmp_path, monkeypatch):
+    """The plain-script session on several GPUs (here: two logical devices on the one GPU, COREG_VIRTUAL_DEVICES=2): the
+    images of a sublist are dealt to the devices, each with its own contexts and its own prepared reference; corrected
+    headers, correlation maps and files equal the one-device session's; `device=` / COREG_SINGLE_DEVICE=1 opt out."""
+    from euispice_coreg_amd import _lib
+    from euispice_coreg_amd.jitter_correction import jitter_correction_imagers
+    from euispice_coreg_amd.jitter_correction.jitter_correction import session_devices
+    from euispice_coreg_amd.utils import fits_io
+    paths = series[0]
+    lag = np.arange(-12.0, 12.5, 1.0)
+    kw = dict(lonlims=LON, latlims=LAT, shape=SHAPE, lag_crval1=lag, lag_crval2=lag, sublist_length=4, overlap=1,
+              small_fov_value_max=2800.0)
+    one = jitter_correction_imagers(paths, str(tmp_path / "one"), device=0, **kw)
+    assert session_devices(None, 1) == [(-1, 0)] and session_devices(3, 1) == [(3, 0)]
+    monkeypatch.setenv("COREG_VIRTUAL_DEVICES", "2")
+    assert session_devices(None, 1) == [(0, 0), (0, 16)]
+    monkeypatch.setenv("COREG_SINGLE_DEVICE", "1")
+    assert session_devices(None, 1) == [(-1, 0)]
+    monkeypatch.delenv("COREG_SINGLE_DEVICE")
+    used = []
+    orig = _lib.shared_handle
+
+    def spy(device=-1, slot=0):
+        used.append((int(device), int(slot)))
+        return orig(device, slot)
+    monkeypatch.setattr(_lib, "shared_handle", spy)
+    two = jitter_correction_imagers(paths, str(tmp_path / "two"), **kw)
+    assert {s // 16 for _, s in used} == {0, 1}            # both logical devices swept
+    assert [(i, r) for i, r, _ in one] == [(i, r) for i, r, _ in two]
+    for (_, _, a), (_, _, b) in zip(one, two):
+        assert np.array_equal(a.corr, b.corr, equal_nan=True) and a.shift_arcsec == b.shift_arcsec
+    for p in paths:
+        f1, f2 = (os.path.join(str(tmp_path / d), os.path.basename(p)) for d in ("one", "two"))
+        assert open(f1, "rb").read() == open(f2, "rb").read()
+        assert fits_io.read_header(f1, -1)["CRVAL1"] == fits_io.read_header(f2, -1)["CRVAL1"]
