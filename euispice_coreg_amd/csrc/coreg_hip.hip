@@ -1596,6 +1596,7 @@ static int set_small_fits(coreg_handle* h, const coreg_fits_pixels* px, int32_t 
     DevBuf& dst = fmt.swap_only() ? h->small : h->up_raw;
     HIPCHK(dst.reserve(n * eb));
     if (kind == SRC_PINNED) HIPCHK(hipMemcpyAsync(dst.p, px->data, n * eb, hipMemcpyHostToDevice, h->stream));
+    else if (kind == SRC_DEVICE) HIPCHK(hipMemcpyAsync(dst.p, px->data, n * eb, hipMemcpyDeviceToDevice, h->stream));
     else RETCHK(staged_upload(h, dst.p, px->data, n * eb));
     RETCHK(fits_decode(h, fmt, dst.p, n, h->small, &h->small_f32));
     h->sW = nx;

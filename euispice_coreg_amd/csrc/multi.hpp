@@ -248,8 +248,10 @@ struct coreg_multi {
     PinBuf stage;        // shared page-locked staging of an image: every device copies from it over its own link
     PinBuf host_gather;  // peer-copy collective: the devices' blocks, chunk doubles each
     std::vector<DevBuf> blk, gat;
+    std::vector<DevBuf> img;  // per device: the image to align as uploaded (row shares assembled by one all-gather)
     int last_mode = MULTI_NONE;
     int force_mode = -1;            // coreg_multi_set_option "force_mode": tests of one partition on any lag set
+    int opt_image_shares = 1;       // "image_shares": 1 = row shares + one all-gather when RCCL is in use, 0 = N copies
     std::string rccl_error;         // why RCCL was given up on this handle ("" = it was not)
     bool force_collective = false;  // COREG_MULTI_FORCE_RCCL=1 with ONE device: the RCCL calls run with a one-rank group
 };
@@ -515,6 +517,51 @@ int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out,
     return COREG_OK;
 }
 
+// The image to align crosses PCIe ONCE in all: device k uploads rows [k * ceil(H / N), ...) over its own link, ONE
+// all-gather over xGMI (in place: every device's share sits where the gathered image wants it) assembles the replica on
+// every GPU, and each device adopts (and, for raw FITS bytes, decodes) its copy.  The reference hands its workers the
+// image through ONE shared-memory copy (alignment.py:657-665).  Returns COREG_ENOTIMPL when RCCL is not in use or
+// fails (the caller then stages the whole image once in page-locked memory and every device copies it).
+int multi_set_small_shares(coreg_multi* m, const void* src, const PixFmt& fmt, const coreg_fits_pixels* px, int dtype,
+                           int32_t ny, int32_t nx) {
+    const int world = m->n;
+    if (!m->use_rccl || m->comms.size() != (size_t)world) return COREG_ENOTIMPL;
+    const size_t row_bytes = (size_t)nx * fmt.elem();
+    const size_t rows = ((size_t)ny + world - 1) / world, share = rows * row_bytes;
+    if (share == 0 || share > ((size_t)1 << 40)) return COREG_ENOTIMPL;
+    RETCHK(multi_run(m, [&](int k) {
+        coreg_handle* h = m->h[k];
+        RETCHK(bind_device(h));
+        HIPCHK(m->img[k].reserve(share * world));
+        const size_t lo = std::min<size_t>((size_t)k * rows, (size_t)ny), hi = std::min<size_t>(lo + rows, (size_t)ny);
+        if (hi > lo)
+            RETCHK(staged_upload(h, (char*)m->img[k].p + (size_t)k * share, (const char*)src + lo * row_bytes,
+                                 (hi - lo) * row_bytes));
+        return COREG_OK;
+    }));
+    RcclApi& api = RcclApi::get();
+    ncclResult_t e = api.GroupStart();
+    for (int k = 0; k < world && e == ncclSuccess; ++k)
+        e = api.AllGather((const char*)m->img[k].p + (size_t)k * share, m->img[k].p, share, ncclChar, m->comms[k],
+                          m->h[k]->stream);
+    const ncclResult_t e2 = api.GroupEnd();
+    if (e != ncclSuccess || e2 != ncclSuccess) {
+        multi_drop_rccl(m, "RCCL all-gather of the image failed");
+        return COREG_ENOTIMPL;
+    }
+    return multi_run(m, [&](int k) {
+        coreg_handle* h = m->h[k];
+        if (px) {
+            coreg_fits_pixels dev = *px;
+            dev.data = m->img[k].p;
+            RETCHK(set_small_fits(h, &dev, ny, nx, SRC_DEVICE));
+        } else {
+            RETCHK(set_small_direct(h, m->img[k].p, dtype, ny, nx, SRC_DEVICE));
+        }
+        return coreg_synchronize(h);  // the caller's host buffer and the share buffers are free again on return
+    });
+}
+
 // The communicators have never carried data: before any result depends on them, every device contributes (k + 1) * 1.5
 // to ONE grouped all-gather -- the very call a sweep makes -- and checks what it received.  The wait is bounded
 // (COREG_RCCL_SELFTEST_SECONDS, default 20): a group that does not come back is aborted (ncclCommAbort) and the handle
@@ -655,6 +702,7 @@ int coreg_multi_create(coreg_multi** out, int n_devices, const int* device_ids) 
     m->h.assign(m->n, nullptr);
     m->blk.resize(m->n);
     m->gat.resize(m->n);
+    m->img.resize(m->n);
     for (int k = 0; k < m->n; ++k) m->w.emplace_back(new DeviceWorker());
     std::vector<int> rc(m->n, COREG_OK);
     for (int k = 0; k < m->n; ++k) m->w[k]->post([&, k] { rc[k] = coreg_create(&m->h[k], m->devices[k]); });
@@ -695,6 +743,7 @@ void coreg_multi_destroy(coreg_multi* m) {
             if (m->h[k]->stream) (void)hipStreamSynchronize(m->h[k]->stream);
             m->blk[k].release();
             m->gat[k].release();
+            m->img[k].release();
         });
         m->w[k]->wait();
     }
@@ -731,6 +780,10 @@ int coreg_multi_set_option(coreg_multi* m, const char* name, int64_t value) {
         m->force_mode = (int)value;
         return COREG_OK;
     }
+    if (std::string(name) == "image_shares") {
+        m->opt_image_shares = value ? 1 : 0;
+        return COREG_OK;
+    }
     return multi_run(m, [&](int k) { return coreg_set_option(m->h[k], name, value); });
 }
 
@@ -738,6 +791,10 @@ int coreg_multi_set_small(coreg_multi* m, const void* img, int dtype, int32_t ny
     if (!m) return COREG_EINVAL;
     if (!img || ny < 1 || nx < 1 || (dtype != COREG_F32 && dtype != COREG_F64))
         return mfail(m, COREG_EINVAL, "multi_set_small: bad argument");
+    if (m->opt_image_shares) {
+        const int rc = multi_set_small_shares(m, img, PixFmt::native(dtype == COREG_F32), nullptr, dtype, ny, nx);
+        if (rc != COREG_ENOTIMPL) return rc;
+    }
     if (m->n == 1) {
         int rc;
         m->w[0]->post([&] {
@@ -797,6 +854,10 @@ int coreg_multi_set_small_fits(coreg_multi* m, const coreg_fits_pixels* px, int3
     PixFmt fmt;
     if (check_fits(nullptr, px, &fmt) != COREG_OK || ny < 1 || nx < 1)
         return mfail(m, COREG_EINVAL, "multi_set_small_fits: bad argument");
+    if (m->opt_image_shares) {
+        const int rc = multi_set_small_shares(m, px->data, fmt, px, 0, ny, nx);
+        if (rc != COREG_ENOTIMPL) return rc;
+    }
     if (m->n == 1) {
         int rc;
         m->w[0]->post([&] { rc = coreg_set_small_fits(m->h[0], px, ny, nx); });

@@ -347,6 +347,9 @@ int coreg_fit_gaussian2d(int32_t m, const double* x, const double* y, const doub
  * run time (dlopen; a copy already loaded in the process, e.g. PyTorch's, first).  Without it -- or when
  * COREG_VIRTUAL_DEVICES=k maps k logical devices onto the GPUs present (tests of this path on a one-GPU box; RCCL
  * refuses two ranks on one device) -- every device copies its block to the host instead.
+ * The image to align crosses PCIe once in all when RCCL is in use: device k uploads rows [k * ceil(H / N), ...) over its
+ * own link and ONE all-gather over xGMI assembles the replica on every GPU (coreg_multi_set_option "image_shares" 0, a
+ * failing collective, or no RCCL: the image is staged once in page-locked memory and every device copies all of it).
  * n_devices 0 = all visible (or COREG_VIRTUAL_DEVICES); device_ids NULL = 0 .. n-1.  The calls mirror the single-device
  * ones (dtype = COREG_F32 / COREG_F64 of the host pixels); sweeps return the WHOLE map, C order, in host memory. */
 typedef struct coreg_multi coreg_multi;

@@ -144,7 +144,7 @@ def test_multi_helioprojective_with_the_zero_lag(gpu_handle, monkeypatch):
     assert abs(full[8, 14] - oracle[1]) <= 1e-7 and abs(full[25, 5] - oracle[2]) <= 1e-7  # (0, 0) and (17, -9)
 
 
-def test_multi_rccl_calls_run_with_a_one_rank_group(gpu_handle, monkeypatch):
+def test_multi_rccl_calls_run_with_a_one_rank_group(gpu_handle, monkeypatch, tmp_path):
     """The RCCL side of the driver on the one GPU there is: dlopen, ncclCommInitAll, ncclGroupStart / ncclAllGather /
     ncclGroupEnd on the handle's stream, device-0 hand-over -- a one-rank group (the all-gather is then a copy)."""
     from euispice_coreg_amd import _lib
@@ -155,10 +155,25 @@ def test_multi_rccl_calls_run_with_a_one_rank_group(gpu_handle, monkeypatch):
     with _lib.MultiHandle(device_ids=[0]) as m:
         if m.collective != "rccl":
             pytest.skip("no RCCL runtime could be loaded in this process")
+        assert m.rccl_status == "ok"   # the communicator gathered the self-test pattern at creation
         got = _multi_carr(m, small, hs, large, hl, lags)
         assert m.last_mode == "slices" and m.collective == "rccl"
-    want = _single_carr(gpu_handle, small, hs, large, hl, lags)
-    assert np.array_equal(got, want, equal_nan=True)
+        want = _single_carr(gpu_handle, small, hs, large, hl, lags)
+        assert np.array_equal(got, want, equal_nan=True)
+        # the image to align by row shares + ONE all-gather (in place), against the whole-image hand-over: float32
+        # pixels, float64 pixels that are not float32-exact, and the raw bytes of a FITS data unit
+        from euispice_coreg_amd.utils import fits_io
+        p = str(tmp_path / "s.fits")
+        fits_io.write_images(p, [(None, {}), (small.astype(np.float32), hs)])
+        noisy = small + 1e-7 * np.arange(small.size).reshape(small.shape)
+        for img in (small.astype(np.float32), noisy, fits_io.open_raw(p, -1)):
+            maps = []
+            for shares in (1, 0):
+                m.set_option("image_shares", shares)
+                maps.append(_multi_carr(m, img, hs, large, hl, lags))
+            assert np.array_equal(maps[0], maps[1], equal_nan=True)
+            assert np.array_equal(maps[0], _single_carr(gpu_handle, np.asarray(img), hs, large, hl, lags), equal_nan=True)
+        m.set_option("image_shares", 1)
 
 
 def test_alignment_uses_every_visible_gpu_from_a_plain_script(tmp_path, monkeypatch):
@@ -247,3 +262,30 @@ def test_multi_rccl_in_a_script_that_never_imports_torch(tmp_path):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert "ok" in r.stdout
     assert "collective rccl mode slices" in r.stdout, r.stdout
+
+
+def test_multi_on_two_or_more_physical_gpus(gpu_handle, monkeypatch):
+    """The real thing, wherever more than one GPU is visible (the build's box has one: skipped there): every device from
+    one process, RCCL communicators from ncclCommInitAll, the image by row shares + one all-gather, every partition of
+    the lag set with its one collective -- against device 0 sweeping alone."""
+    from euispice_coreg_amd import _lib, parallel
+    monkeypatch.delenv("COREG_VIRTUAL_DEVICES", raising=False)
+    n = _lib.physical_device_count()
+    if n < 2:
+        pytest.skip("one GPU visible")
+    small, hs, large, hl, _ = H.scene()
+    l24, l23 = 17.0 + 1.0 * (np.arange(24) - 12), -9.0 + 1.0 * (np.arange(23) - 11)
+    cases = [(l24, l23, None, None, [0.3]), (l24, l23, None, None, [0.0, 0.3, -0.2]),
+             (17.0 + 2.0 * (np.arange(5) - 2), -9.0 + 2.0 * (np.arange(4) - 2), None, None, None)]
+    with _lib.MultiHandle() as m:
+        assert m.size == n
+        print("collective:", m.collective, "rccl:", m.rccl_status)
+        for lags in cases:
+            for force in (-1, 1, 2, 4):
+                m.set_option("force_mode", force)
+                got = _multi_carr(m, small.astype(np.float32), hs, large, hl, lags)
+                want = _single_carr(gpu_handle, small.astype(np.float32), hs, large, hl, lags)
+                assert np.array_equal(np.isnan(got), np.isnan(want)), (force, m.last_mode)
+                assert np.nanmax(np.abs(got - want)) <= 1e-12, (force, m.last_mode)
+        m.set_option("force_mode", -1)
+        assert m.collective in ("rccl", "host-copy")
