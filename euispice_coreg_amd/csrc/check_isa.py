@@ -123,10 +123,11 @@ def _branch_target(lines, k, addr_of):
 
 
 def check(text):
-    """Every group of hand-issued ds_read_b64 (4 or 9 in a row, kernels.hpp Taps<N>): on EVERY control-flow path from
+    """Every group of hand-issued ds_read_b64 (4, 9 or 16 in a row, kernels.hpp Taps<N>): on EVERY control-flow path from
     the group to the next `s_waitcnt lgkmcnt(0)` (the software-pipelined loop waits for a sample's reads after its
     back edge) no instruction may name one of the group's destination registers."""
     n_groups, bad = 0, []
+    by_size = {}
     kernel = "?"
     lines = text.splitlines()
     addr_of = _addr_index(lines)
@@ -144,8 +145,9 @@ def check(text):
                 ops = lines[j].strip().split("//")[0].split(None, 1)[1]
                 dst |= regs(ops.split(",")[0])
                 j += 1
-            if j - i in (4, 9):  # Taps<2> / Taps<3>
+            if j - i in (4, 9, 16):  # Taps<2> / Taps<3> / Taps<4>
                 n_groups += 1
+                by_size[j - i] = by_size.get(j - i, 0) + 1
                 work, seen = [j], set()
                 while work:
                     k = work.pop()
@@ -176,6 +178,7 @@ def check(text):
             i = j
             continue
         i += 1
+    check.by_size = by_size
     return n_groups, bad
 
 
@@ -261,7 +264,10 @@ def main(lib):
         for k, t in bad[:20]:
             print("check_isa: tap register touched between the reads and their wait:", k, "|", t, file=sys.stderr)
         raise SystemExit(f"check_isa: {len(bad)} violation(s)")
-    print(f"[check_isa] ok: {n} hand-issued LDS read groups, none has its registers touched before the wait")
+    sizes = ", ".join(f"{v} of {k} reads" for k, v in sorted(getattr(check, "by_size", {}).items()))
+    if not getattr(check, "by_size", {}).get(16):
+        raise SystemExit("check_isa: no 16-read group (the cubic gather, Taps<4>) found in k_sweep")
+    print(f"[check_isa] ok: {n} hand-issued LDS read groups ({sizes}), none has its registers touched before the wait")
 
 
 if __name__ == "__main__":

@@ -825,7 +825,7 @@ long long lds_window_elems(const coreg_handle* h);
 // Compile-time LDS window pitch for the Carrington order-2 sweep: the smallest instantiated pitch that holds the planned
 // window (width + slack) within the LDS.  All of them are 25 mod 32, the residue that spreads the ~2 px lag lattice best
 // over the 32 bank pairs in the conflict simulation.  0 = pitch chosen per visit.
-int pick_pitch(const coreg_handle* h, const Plan& plan, long long lds_elems) {
+int pick_pitch(const coreg_handle* h, const Plan& plan, long long lds_elems, int order = 2) {
     if (h->opt_pitch == 0 || !h->opt_use_lds) return 0;
     static const int kPitches[] = {89, 121, 153, 185, 217};
     if (h->opt_pitch > 0) {
@@ -834,7 +834,9 @@ int pick_pitch(const coreg_handle* h, const Plan& plan, long long lds_elems) {
         return 0;
     }
     for (int p : kPitches)
-        if ((double)p >= plan.win_w + 2.0 && (double)p * plan.win_h <= 0.985 * (double)lds_elems) return p;
+        if ((double)p >= plan.win_w + (order > 2 ? 4.0 : 2.0) &&
+            (double)p * (plan.win_h + (order > 2 ? 2.0 : 0.0)) <= 0.985 * (double)lds_elems)
+            return p;
     return 0;
 }
 
@@ -948,20 +950,29 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
             if (pitch_sel == 89) SWP(MODE_HOMOGRAPHY, 2, float, true, false, 89);
             else SWP(MODE_HOMOGRAPHY, 2, float, true, false, 121);
         }
+    } else if (mode == MODE_TRANSLATE && order == 3 && h->small_f32 && method != COREG_METHOD_RESIDUS &&
+               (pitch_sel == 89 || pitch_sel == 121 || pitch_sel == 153)) {
+        // the cubic Carrington sweep with a compile-time window pitch
+        if (pitch_sel == 89) SWP(MODE_TRANSLATE, 3, float, false, false, 89);
+        else if (pitch_sel == 121) SWP(MODE_TRANSLATE, 3, float, false, false, 121);
+        else SWP(MODE_TRANSLATE, 3, float, false, false, 153);
     } else if (mode == MODE_TRANSLATE) {
         if (order == 2) SW_T(MODE_TRANSLATE, 2, false);
         else if (order == 1) SW_T(MODE_TRANSLATE, 1, false);
+        else if (order == 3) SW_T(MODE_TRANSLATE, 3, false);
         else SW_T(MODE_TRANSLATE, ORDER_RT, false);
     } else if (mode == MODE_CAR) {
         if (order == 2) SW_T(MODE_CAR, 2, true);
         else if (order == 1) SW_T(MODE_CAR, 1, true);
         else SW_T(MODE_CAR, ORDER_RT, true);
-    } else if (mode == MODE_HOMOGRAPHY_SERIES && (order == 1 || order == 2)) {
+    } else if (mode == MODE_HOMOGRAPHY_SERIES && (order == 1 || order == 2 || order == 3)) {
         if (order == 2) SW_T(MODE_HOMOGRAPHY_SERIES, 2, true);
+        else if (order == 3) SW_T(MODE_HOMOGRAPHY_SERIES, 3, true);
         else SW_T(MODE_HOMOGRAPHY_SERIES, 1, true);
     } else {
         if (order == 2) SW_T(MODE_HOMOGRAPHY, 2, true);
         else if (order == 1) SW_T(MODE_HOMOGRAPHY, 1, true);
+        else if (order == 3) SW_T(MODE_HOMOGRAPHY, 3, true);
         else SW_T(MODE_HOMOGRAPHY, ORDER_RT, true);
     }
 #undef SWP
@@ -2133,7 +2144,7 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
         RETCHK(launch_sweep(h, MODE_TRANSLATE, order, method, h->lane_params.as<double>() + 2 * L.slot_off,
                             h->out_index.as<long long>() + L.slot_off, L.n_batches, n_tiles, lag_begin, out_dev, nullptr,
                             nullptr, (long long)L.slot_off,
-                            pick_pitch(h, plan, h->opt_use_lds ? lds_window_elems(h) : 0)));
+                            pick_pitch(h, plan, h->opt_use_lds ? lds_window_elems(h) : 0, order)));
     }
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }
@@ -2481,7 +2492,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles, pick_groups(h, n_batches, n_tiles), n_batches));
     RETCHK(launch_sweep(h, sweep_mode, order, method, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
                         n_tiles, lag_begin, out_dev, nullptr, &fix, 0,
-                        pick_pitch(h, plan, h->opt_use_lds ? lds_window_elems(h) : 0)));
+                        pick_pitch(h, plan, h->opt_use_lds ? lds_window_elems(h) : 0, order)));
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }
 

@@ -193,6 +193,34 @@ __device__ __forceinline__ void spline_weights_t<1>(double t, double* w) {  // t
     w[1] = t;
 }
 
+// cubic B-spline (scipy ni_splines.c, order 3), argument y in [0, 1): SIX times the weights -- 6 w0 = z^3, 6 w1 =
+// 3 y^2 (y - 2) + 4, 6 w2 = 3 z^2 (z - 2) + 4 with z = 1 - y, 6 w3 = 6 - the others (scipy: w3 = 1 - w0 - w1 - w2) -- so
+// that scipy's four divisions by 6 per axis become ONE multiplication of the sample by 1/36 (values equal to scipy's
+// to ~1 ulp; a float64 division costs ~30 instructions here)
+__device__ __forceinline__ void spline_weights6_o3(double y, double* w) {
+    const double z = 1.0 - y;
+    const double y2 = y * y, z2 = z * z;
+    w[0] = z2 * z;
+    w[1] = fma(3.0 * y2, y - 2.0, 4.0);
+    w[2] = fma(3.0 * z2, z - 2.0, 4.0);
+    w[3] = ((6.0 - w[0]) - w[1]) - w[2];
+}
+template <>
+__device__ __forceinline__ void spline_weights_t<3>(double y, double* w) {  // y in [0, 1)
+    spline_weights6_o3(y, w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] *= (1.0 / 6.0);
+}
+template <>
+struct Spline<3> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void eval(double c, int& start, double w[4]) {
+        const double f = floor(c);
+        spline_weights_t<3>(c - f, w);
+        start = (int)f - 1;
+    }
+};
+
 template <>
 struct Spline<1> {
     static constexpr int N = 2;
@@ -286,6 +314,13 @@ __device__ __forceinline__ int mirror_far(int i, int n) {  // scipy NI_EXTEND_MI
     i = i % p;
     return i > n - 1 ? p - i : i;
 }
+// taps of the compile-time orders: one reflection is enough up to order 2 (taps at most one sample outside), order 3
+// reaches two samples out
+template <int ORDER>
+__device__ __forceinline__ int mirror_tap(int i, int n) {
+    if constexpr (ORDER > 2) return mirror_far(i, n);
+    else return mirror_idx(i, n);
+}
 // Source images may be CROPS of the image the header describes (the once-only reference preparation uploads only the
 // rectangle the target grid can touch): `img` then holds columns x0 .. and rows y0 .. of the W x H image with row pitch
 // `pitch`; bounds rule and mirroring use the full W x H, the crop is guaranteed to hold every tap of an in-bounds sample.
@@ -370,8 +405,8 @@ __device__ __forceinline__ double spline_global(const TS* __restrict__ img, int 
     int ix[N], iy[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        ix[k] = mirror_idx(sx + k, W) - cr.x0;
-        iy[k] = (mirror_idx(sy + k, H) - cr.y0) * pitch;
+        ix[k] = mirror_tap<ORDER>(sx + k, W) - cr.x0;
+        iy[k] = (mirror_tap<ORDER>(sy + k, H) - cr.y0) * pitch;
     }
     double acc = 0.0;
 #pragma unroll
@@ -975,6 +1010,89 @@ struct Taps<2> {
     }
 };
 
+template <>
+struct Taps<4> {
+    double t[16];
+    // the sixteen reads of a cubic sample; (fx, fy) pinned to the issue point so that the weight arithmetic that starts
+    // from them is scheduled after the reads and overlaps their latency
+    __device__ __forceinline__ void issue_before(unsigned a0, unsigned a1, unsigned a2, unsigned a3, double& fx,
+                                                 double& fy) {
+        asm volatile(
+            "ds_read_b64 %0, %18\n\tds_read_b64 %1, %18 offset:8\n\tds_read_b64 %2, %18 offset:16\n\t"
+            "ds_read_b64 %3, %18 offset:24\n\t"
+            "ds_read_b64 %4, %19\n\tds_read_b64 %5, %19 offset:8\n\tds_read_b64 %6, %19 offset:16\n\t"
+            "ds_read_b64 %7, %19 offset:24\n\t"
+            "ds_read_b64 %8, %20\n\tds_read_b64 %9, %20 offset:8\n\tds_read_b64 %10, %20 offset:16\n\t"
+            "ds_read_b64 %11, %20 offset:24\n\t"
+            "ds_read_b64 %12, %21\n\tds_read_b64 %13, %21 offset:8\n\tds_read_b64 %14, %21 offset:16\n\t"
+            "ds_read_b64 %15, %21 offset:24"
+            : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+              "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]), "=&v"(t[12]), "=&v"(t[13]), "=&v"(t[14]),
+              "=&v"(t[15]), "+v"(fx), "+v"(fy)
+            : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+    }
+    // compile-time window pitch P: the four rows are immediate offsets of one address register
+    template <int P>
+    __device__ __forceinline__ void issue_before_imm(unsigned a0, double& fx, double& fy) {
+        static_assert(P > 0 && (3 * P + 3) * 8 < 65536, "LDS immediate offsets are 16 bits");
+        asm volatile(
+            "ds_read_b64 %0, %18\n\tds_read_b64 %1, %18 offset:8\n\tds_read_b64 %2, %18 offset:16\n\t"
+            "ds_read_b64 %3, %18 offset:24\n\t"
+            "ds_read_b64 %4, %18 offset:%19\n\tds_read_b64 %5, %18 offset:%20\n\tds_read_b64 %6, %18 offset:%21\n\t"
+            "ds_read_b64 %7, %18 offset:%22\n\t"
+            "ds_read_b64 %8, %18 offset:%23\n\tds_read_b64 %9, %18 offset:%24\n\tds_read_b64 %10, %18 offset:%25\n\t"
+            "ds_read_b64 %11, %18 offset:%26\n\t"
+            "ds_read_b64 %12, %18 offset:%27\n\tds_read_b64 %13, %18 offset:%28\n\tds_read_b64 %14, %18 offset:%29\n\t"
+            "ds_read_b64 %15, %18 offset:%30"
+            : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+              "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]), "=&v"(t[12]), "=&v"(t[13]), "=&v"(t[14]),
+              "=&v"(t[15]), "+v"(fx), "+v"(fy)
+            : "v"(a0), "n"(P * 8), "n"(P * 8 + 8), "n"(P * 8 + 16), "n"(P * 8 + 24), "n"(2 * P * 8), "n"(2 * P * 8 + 8),
+              "n"(2 * P * 8 + 16), "n"(2 * P * 8 + 24), "n"(3 * P * 8), "n"(3 * P * 8 + 8), "n"(3 * P * 8 + 16),
+              "n"(3 * P * 8 + 24));
+    }
+    __device__ __forceinline__ void wait_after(double* wx, double* wy) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
+                       "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]),
+                       "+v"(t[15]), "+v"(wx[0]), "+v"(wx[1]), "+v"(wx[2]), "+v"(wx[3]), "+v"(wy[0]), "+v"(wy[1]),
+                       "+v"(wy[2]), "+v"(wy[3]));
+    }
+};
+
+// Cubic B-spline sample (reprojection_order = 3, alignment.py:54) from the LDS window at the window-relative coordinate
+// (ux, uy) = coordinate - 1 - window origin: trunc(u) is the window index of the first of the four taps per axis,
+// fract(u) the spline argument.  Sixteen hand-issued reads, the weights (six-fold, see spline_weights6_o3) computed under
+// their latency, one multiplication by 1/36 at the end.
+template <int PITCH>
+__device__ __forceinline__ double gather_o3(unsigned win, int pitch, double ux, double uy) {
+    const int c0 = (int)ux, r0 = (int)uy;
+    const unsigned a0 = win + 8u * (unsigned)(__mul24(r0, PITCH > 0 ? PITCH : pitch) + c0);
+    Taps<4> tp;
+    double fx = __builtin_amdgcn_fract(ux), fy = __builtin_amdgcn_fract(uy);
+    if constexpr (PITCH > 0) {
+        tp.template issue_before_imm<PITCH>(a0, fx, fy);
+    } else {
+        const unsigned a1 = a0 + 8u * (unsigned)pitch;
+        const unsigned a2 = a1 + 8u * (unsigned)pitch;
+        const unsigned a3 = a2 + 8u * (unsigned)pitch;
+        tp.issue_before(a0, a1, a2, a3, fx, fy);
+    }
+    double wx[4], wy[4];
+    spline_weights6_o3(fx, wx);
+    spline_weights6_o3(fy, wy);
+    tp.wait_after(wx, wy);
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double row = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) row = fma(tp.t[r * 4 + c], wx[c], row);
+        v = fma(row, wy[r], v);
+    }
+    return v * (1.0 / 36.0);
+}
+
 // Quadratic B-spline sample from the LDS window at the window-relative coordinate (ux, uy) = coordinate + 1/2 - 1 -
 // window origin: trunc(u) is the window index of the first tap, f = fract(u) = t + 1/2 the spline argument.  The weights
 // of scipy's quadratic B-spline, w0 = (1/2 - t)^2 / 2, w1 = 3/4 - t^2, w2 = (1/2 + t)^2 / 2, are g^2 / 2, 1/2 + f g,
@@ -1055,6 +1173,8 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
         double v = 0.0;
         if constexpr (ORDER == 2) {
             v = gather_o2<PITCH>(win, pitch, ux, uy);
+        } else if constexpr (ORDER == 3) {
+            v = gather_o3<PITCH>(win, pitch, ux, uy);
         } else {
             const int c0 = (int)ux, r0 = (int)uy;
             const unsigned a0 = win + 8u * (unsigned)(__mul24(r0, pitch) + c0);
@@ -1126,6 +1246,8 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
             // the arithmetic of the interior path under this lane's bounds predicate: (pxw, pyw) = 1/2 - 1 - window
             // origin turn the coordinate into the window-relative one
             v = gather_o2<PITCH>(win, pitch, nx + pxw, ny + pyw);
+        } else if constexpr (LDS && ORDER == 3) {
+            v = gather_o3<PITCH>(win, pitch, nx + pxw, ny + pyw);  // (pxw, pyw) = -1 - window origin
         } else if constexpr (LDS) {
             // tap addresses first, so that the reads are in flight while the weights are computed
             const double fx = floor(nx + (ORDER == 2 ? 0.5 : 0.0)), fy = floor(ny + (ORDER == 2 ? 0.5 : 0.0));
@@ -1153,8 +1275,8 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
             int ix[N], iy[N];
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-                ix[k] = mirror_idx(sx + k, W);
-                iy[k] = mirror_idx(sy + k, H) * W;
+                ix[k] = mirror_tap<ORDER>(sx + k, W);
+                iy[k] = mirror_tap<ORDER>(sy + k, H) * W;
             }
 #pragma unroll
             for (int r = 0; r < N; ++r) {
@@ -1457,12 +1579,15 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
         const bool interior = (mnx >= 0.0) & (mxx <= (double)(W - 1)) & (mny >= 0.0) & (mxy <= (double)(H - 1));
         // integer window with the mirrored apron: taps of in-bounds samples lie in [floor(c)-1, floor(c)+2] (orders 1, 2);
         // run-time orders: [floor(c) - order/2 - 1, floor(c) + order - order/2 + 1]
-        const int ap_lo = ORDER == ORDER_RT ? a.car_inv.order_rt / 2 + 1 : 1;
-        const int ap_hi = ORDER == ORDER_RT ? a.car_inv.order_rt - a.car_inv.order_rt / 2 + 1 : 2;
-        const int ox = max((int)floor(fmax(mnx, 0.0)) - ap_lo, ORDER == ORDER_RT ? -ap_lo : -1);
-        const int oy = max((int)floor(fmax(mny, 0.0)) - ap_lo, ORDER == ORDER_RT ? -ap_lo : -1);
-        const int ex = min((int)floor(fmin(mxx, (double)(W - 1))) + ap_hi, ORDER == ORDER_RT ? W - 1 + ap_hi : W);
-        const int ey = min((int)floor(fmin(mxy, (double)(H - 1))) + ap_hi, ORDER == ORDER_RT ? H - 1 + ap_hi : H);
+        // (kWide: the apron can reach several samples past the image edge -- run-time orders and the cubic kernel)
+        constexpr bool kWide = ORDER == ORDER_RT || ORDER > 2;
+        const int ord = ORDER == ORDER_RT ? a.car_inv.order_rt : ORDER;
+        const int ap_lo = kWide ? ord / 2 + 1 : 1;
+        const int ap_hi = kWide ? ord - ord / 2 + 1 : 2;
+        const int ox = max((int)floor(fmax(mnx, 0.0)) - ap_lo, kWide ? -ap_lo : -1);
+        const int oy = max((int)floor(fmax(mny, 0.0)) - ap_lo, kWide ? -ap_lo : -1);
+        const int ex = min((int)floor(fmin(mxx, (double)(W - 1))) + ap_hi, kWide ? W - 1 + ap_hi : W);
+        const int ey = min((int)floor(fmin(mxy, (double)(H - 1))) + ap_hi, kWide ? H - 1 + ap_hi : H);
         const int ww = ex - ox + 1, wh = ey - oy + 1;
         // Odd pitch, and not any odd pitch: with lags ~2 px apart, rows r and r + 2 of the window hold neighbouring lag
         // rows, so 2 * pitch must not be close to a multiple of 32 bank pairs.  Measured on the headline sweep with
@@ -1510,13 +1635,13 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
                     for (int j = 0; j < kCols; ++j) {
                         const int c = c0 + 64 * j + lane;
                         // (the apron of the run-time orders can reach several samples past the edge: general reflection)
-                        gx[j] = ORDER == ORDER_RT ? mirror_far(ox + min(c, ww - 1), W) : mirror_idx(ox + min(c, ww - 1), W);
+                        gx[j] = kWide ? mirror_far(ox + min(c, ww - 1), W) : mirror_idx(ox + min(c, ww - 1), W);
                     }
                     TS v[kStage][kCols];
 #pragma unroll
                     for (int k = 0; k < kStage; ++k) {
                         const int r = min(r0 + k * kWaves, wh - 1);
-                        const int gy = ORDER == ORDER_RT ? mirror_far(oy + r, H) : mirror_idx(oy + r, H);
+                        const int gy = kWide ? mirror_far(oy + r, H) : mirror_idx(oy + r, H);
                         const TS* __restrict__ row = img + (size_t)gy * W;
 #pragma unroll
                         for (int j = 0; j < kCols; ++j) v[k][j] = row[gx[j]];
@@ -1553,8 +1678,9 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
                     n_vis_clean += clean ? 1 : 0;
                     if (!pad_lane) {
                         // window-relative lane constants (exact: a small integer is subtracted)
-                        const double offx = (ORDER == 2 ? 0.5 : 0.0) - (double)((ORDER == 2 ? 1 : 0) + ox);
-                        const double offy = (ORDER == 2 ? 0.5 : 0.0) - (double)((ORDER == 2 ? 1 : 0) + oy);
+                        // (first tap = floor(c [+ 1/2 for the even order]) - ORDER / 2)
+                        const double offx = (ORDER == 2 ? 0.5 : 0.0) - (double)(ORDER / 2 + ox);
+                        const double offy = (ORDER == 2 ? 0.5 : 0.0) - (double)(ORDER / 2 + oy);
                         const double pxw = MODE == MODE_TRANSLATE ? px0 + offx : offx;
                         const double pyw = MODE == MODE_TRANSLATE ? py0 + offy : offy;
                         if (kCleanPath && clean) {
@@ -1570,9 +1696,9 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
                 }
             }
             if (!done) {
-                // (order 2: window-relative offsets for gather_o2, exact small numbers)
-                const double offx = ORDER == 2 ? 0.5 - (double)(1 + ox) : 0.0;
-                const double offy = ORDER == 2 ? 0.5 - (double)(1 + oy) : 0.0;
+                // (orders 2, 3: window-relative offsets for gather_o2 / gather_o3, exact small numbers)
+                const double offx = ORDER == 2 ? 0.5 - (double)(1 + ox) : (ORDER == 3 ? -(double)(1 + ox) : 0.0);
+                const double offy = ORDER == 2 ? 0.5 - (double)(1 + oy) : (ORDER == 3 ? -(double)(1 + oy) : 0.0);
                 tile_points<MODE, ORDER, TS, true, ROUND, RESID, false, PITCH>(acc, win, img, pitch, ox, oy, W, H, px0, py0,
                                                                                offx, offy, hm, a.car_inv, pts, p_begin,
                                                                                p_end, pivot_b, pg);

@@ -77,9 +77,9 @@ def test_multi_every_partition_equals_single_device(gpu_handle, monkeypatch, n_v
             assert np.nanmax(np.abs(got - want)) <= 1e-10
         # a sweep that fails inside the grid-share branch must not leave the contexts sharded: the next
         # lag-sharded sweep on the same handle gives the whole map
-        m.set_reference_on_grid(np.full((SHAPE[1], SHAPE[0]), np.nan))  # all-NaN reference: the pivot is not finite
-        with pytest.raises(_lib.CoregError):
-            m.sweep_carrington(hs, grid, 1.004, _lib.LagSet(*few))
+        with pytest.raises(_lib.CoregError):  # (refused by every device's sweep call, inside the grid-share branch)
+            m.sweep_carrington(hs, grid, 1.004, _lib.LagSet(*few), order=9)
+        assert m.last_mode == "points"
         got = _multi_carr(m, small, hs, large, hl, cases[0][1])
         want = _single_carr(gpu_handle, small, hs, large, hl, cases[0][1])
         assert m.last_mode == "blocks" and np.nanmax(np.abs(got - want)) <= 1e-12

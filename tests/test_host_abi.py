@@ -197,7 +197,7 @@ def test_hand_issued_lds_reads_are_not_touched_before_their_wait():
     chk = os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc", "check_isa.py")
     p = subprocess.run([sys.executable, chk, _lib.LIB_PATH], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
-    assert "hand-issued LDS read groups" in p.stdout
+    assert "hand-issued LDS read groups" in p.stdout and "of 16 reads" in p.stdout  # (the cubic gather too)
     assert "s_load_dwordx8 in k_sweep" in p.stdout
 
 
