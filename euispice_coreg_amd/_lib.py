@@ -545,9 +545,10 @@ class CoregHandle:
 
     def last_visit_counts(self) -> dict:
         """(tile, lag batch) visits of the sweep kernel's last launch by kind (diagnostics; waits for the stream)."""
-        c = (C.c_int64 * 5)()
+        c = (C.c_int64 * 6)()
         self._chk(self._lib.coreg_last_visit_counts(self._h, c))
-        return {"visits": c[0], "lds": c[1], "interior": c[2], "all_finite": c[3], "refined_lag_points": c[4]}
+        return {"visits": c[0], "lds": c[1], "interior": c[2], "all_finite": c[3], "refined_lag_points": c[4],
+                "flagged_not_refined": c[5]}
 
 
 class _HandleView(CoregHandle):

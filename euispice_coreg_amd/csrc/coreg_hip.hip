@@ -171,7 +171,7 @@ struct coreg_handle {
     // options
     int64_t opt_crop_reference = 1;
     int64_t opt_taper_min = 128, opt_taper_frac = -1, opt_taper_rounds = 6;  // tapered group shares (pick_taper)
-    int64_t opt_use_lds = 1, opt_clean_path = 1, opt_refine = 1, opt_refine_cond_log10 = 5, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
+    int64_t opt_use_lds = 1, opt_clean_path = 1, opt_refine = 1, opt_refine_cond_log10 = 5, opt_refine_max = 4, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
 
     coreg_stats stats;
     bool stats_pending = false;   // a device-output sweep is in flight: timings are collected on demand
@@ -185,6 +185,7 @@ struct coreg_handle {
     hipEvent_t ev_end[2] = {nullptr, nullptr};
     PinBuf pin_plan[2];
     int plan_slot = 0;
+    bool plan_open = false;  // upload_plan has staged a plan that no end_sweep has closed yet (a sweep that failed midway)
 };
 
 namespace {
@@ -793,7 +794,10 @@ int launch_precompute(coreg_handle* h, const PrecomputeArgs& a, int n_tiles, int
 }
 
 int reserve_tiles(coreg_handle* h, int n_tiles) {
-    const size_t pts = (size_t)n_tiles * kTilePts;
+    // + an explicit tail: the rolling scalar prefetch of tile_points reads up to kPointGroups chunks past a tile's last
+    // chunk (never used), which for the last tile is past the requested size whatever capacity an earlier, larger
+    // reservation left
+    const size_t pts = (size_t)n_tiles * kTilePts + (size_t)(kPointGroups + 1) * kChunk;
     HIPCHK(h->pts.reserve(pts * sizeof(Pt)));
     HIPCHK(h->tile_count.reserve(n_tiles * sizeof(int)));
     HIPCHK(h->tile_list.reserve(n_tiles * sizeof(int)));
@@ -1064,6 +1068,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     f.refine.pivots = h->pivots.as<double>();
     f.refine.car_inv = a.car_inv;
     f.refine_count = h->counters.as<long long>();  // (null before the first plan: no sweep without one)
+    f.refine_max = (int)h->opt_refine_max;
     f.partials = h->partials.as<double>();
     f.n_groups = g_per + (fixing ? 1 : 0);
     f.part_stride = n_slots;
@@ -1257,6 +1262,15 @@ int begin_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_d
     h->pending_fin.clear();
     h->sums_slots = 0;
     h->pending_n_out = 0;
+    // A sweep that failed between upload_plan and end_sweep leaves its prologue armed and may have enqueued kernels that
+    // still read its pinned plan slot: forget the prologue, and let everything it enqueued finish before that slot (it
+    // was never handed on) is written again.
+    std::memset(&h->pending_prologue, 0, sizeof(h->pending_prologue));
+    if (h->plan_open) {
+        h->plan_open = false;
+        RETCHK(bind_device(h));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     if (!h->small.p) return fail(h, COREG_ESTATE, "coreg_set_small has not been called");
     if (!h->ref.p) return fail(h, COREG_ESTATE, "no reference image on the target grid");
     if (!corr_out && n_out > 0) return fail(h, COREG_EINVAL, "corr_out is null");
@@ -1320,6 +1334,7 @@ int end_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_dev
     h->ev_t1 = h->ev_end[h->plan_slot];  // this sweep's end: statistics, and the guard of its plan staging slot
     HIPCHK(hipEventRecord(h->ev_t1, h->stream));
     h->plan_slot ^= 1;
+    h->plan_open = false;
     if (!out_on_device && n_out > 0)
         HIPCHK(hipMemcpyAsync(corr_out, out_dev, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     h->stats_pending = true;  // (timings and the kept-point count are gathered when coreg_last_stats asks: collect_stats)
@@ -1343,6 +1358,7 @@ int upload_plan(coreg_handle* h, const std::vector<double>& params, const std::v
     HIPCHK(h->out_index.reserve(outidx.size() * sizeof(long long)));
     PinBuf& pin = h->pin_plan[h->plan_slot];
     HIPCHK(hipEventSynchronize(h->ev_end[h->plan_slot]));  // the sweep before last (same slot) has ended
+    h->plan_open = true;  // (closed by end_sweep; begin_sweep cleans up after a sweep that never got there)
     HIPCHK(pin.reserve(bytes));
     std::memcpy(pin.p, params.data(), params.size() * sizeof(double));
     std::memcpy((char*)pin.p + params.size() * sizeof(double), outidx.data(), outidx.size() * sizeof(long long));
@@ -1488,6 +1504,9 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
     } else if (n == "refine_cond_log10") {
         if (value < -3 || value > 15) return fail(h, COREG_EINVAL, "refine_cond_log10 must be in [-3, 15]");
         h->opt_refine_cond_log10 = value;
+    } else if (n == "refine_max") {
+        if (value < 0 || value > 16) return fail(h, COREG_EINVAL, "refine_max must be in [0, 16]");
+        h->opt_refine_max = value;
     } else if (n == "tile_w") {
         if (value != 0 && (value < 1 || value > kTilePts || (value & (value - 1)) != 0))
             return fail(h, COREG_EINVAL, "tile_w must be 0 or a power of two <= 1024");
@@ -2603,16 +2622,18 @@ int coreg_car_map(const coreg_wcs2d* from, const coreg_wcs2d* to, int64_t n, con
     return COREG_OK;
 }
 
-int coreg_last_visit_counts(coreg_handle* h, int64_t* counts5) {
+int coreg_last_visit_counts(coreg_handle* h, int64_t* counts6) {
+    int64_t* counts5 = counts6;
     if (!h || !counts5) return COREG_EINVAL;
     RETCHK(bind_device(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     long long info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (h->tile_info.p) HIPCHK(hipMemcpy(info, h->tile_info.p, 7 * sizeof(long long), hipMemcpyDeviceToHost));
     for (int k = 0; k < 4; ++k) counts5[k] = info[3 + k];
-    long long refined = 0;
-    if (h->counters.p) HIPCHK(hipMemcpy(&refined, h->counters.p, sizeof(refined), hipMemcpyDeviceToHost));
-    counts5[4] = refined;
+    long long refined[2] = {0, 0};
+    if (h->counters.p) HIPCHK(hipMemcpy(refined, h->counters.p, sizeof(refined), hipMemcpyDeviceToHost));
+    counts5[4] = refined[0];
+    counts6[5] = refined[1];
     return COREG_OK;
 }
 

@@ -638,7 +638,7 @@ struct PrologueArgs {
 };
 __device__ __forceinline__ void run_prologue(const PrologueArgs& p) {
     if (!p.src) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && p.refine_count) *p.refine_count = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.refine_count) p.refine_count[0] = p.refine_count[1] = 0;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     for (long long i = i0; i < p.n_params; i += stride) p.dst_params[i] = p.src[i];
@@ -1953,7 +1953,10 @@ struct FinalizeArgs {
     long long sums_stride, sums_off;
     long long part_stride;  // distance between the six sums of a slab (n_slots, or sums_stride when reading reduced sums)
     RefineArgs refine;
-    long long* refine_count;  // device counter of re-evaluated lag-points (diagnostics), or null
+    long long* refine_count;  // device counters (diagnostics), or null: [0] re-evaluated lag-points, [1] lag-points that
+                              // were flagged but left with their one-pass value (refine_max)
+    int refine_max;           // at most this many re-evaluations per block of kFinSlots lag slots (0 = no limit): bounds
+                              // the run time of a sweep whose overlaps are degenerate everywhere
 };
 constexpr int kFinLanes = 16;  // threads per lag slot in k_finalize
 constexpr int kFinSlots = 16;  // lag slots per block: 256-thread blocks, 16 of them per 256-lag batch -- a sweep of two
@@ -2101,8 +2104,16 @@ __global__ void __launch_bounds__(kFinThreads) k_finalize(const FinalizeArgs a) 
     if (!a.refine.enabled) return;  // (uniform)
     if (j == 0) s_flag[ls] = flag;
     __syncthreads();
+    int n_done = 0;  // (uniform)
     for (int q = 0; q < kFinSlots; ++q) {
         if (!s_flag[q]) continue;  // (uniform: shared)
+        if (a.refine_max > 0 && n_done >= a.refine_max) {
+            // the first refine_max flagged slots of a block are re-evaluated, in slot order (deterministic); the others
+            // keep the one-pass coefficient
+            if (threadIdx.x == 0 && a.refine_count) atomicAdd((unsigned long long*)a.refine_count + 1, 1ull);
+            continue;
+        }
+        ++n_done;
         const long long sq = (long long)blockIdx.x * kFinSlots + q;
         const double r2 = a.refine.small_f32 ? refine_mode<float>(a, sq, s_ref) : refine_mode<double>(a, sq, s_ref);
         if (threadIdx.x == 0) {

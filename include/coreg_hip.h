@@ -243,12 +243,13 @@ int coreg_set_pivots(coreg_handle* h, const double* pivots2);
 /* Waits for an in-flight device-output sweep (those return without synchronising the stream). */
 int coreg_last_stats(coreg_handle* h, coreg_stats* out);
 
-/* Diagnostics.  counts5[0..3]: (tile, lag batch) visits of the sweep kernel's workgroups in the LAST launch of the last
+/* Diagnostics.  counts6[0..3]: (tile, lag batch) visits of the sweep kernel's workgroups in the LAST launch of the last
  * sweep -- all; gathered from an LDS window; of those, "interior" (every sample inside the image: no bounds rule); of
- * those, all-finite windows (no sample mask either).  counts5[4]: lag-points of the WHOLE last sweep whose six sums
- * were too ill-conditioned for the one-pass Pearson formula and were re-evaluated with centred sums ("refine").
- * Waits for the stream. */
-int coreg_last_visit_counts(coreg_handle* h, int64_t* counts5);
+ * those, all-finite windows (no sample mask either).  counts6[4]: lag-points of the WHOLE last sweep whose six sums
+ * were too ill-conditioned for the one-pass Pearson formula and were re-evaluated with centred sums ("refine");
+ * counts6[5]: lag-points that were flagged likewise but kept their one-pass value because their block of 16 lag slots
+ * had used up its "refine_max" re-evaluations.  Waits for the stream. */
+int coreg_last_visit_counts(coreg_handle* h, int64_t* counts6);
 
 /* Tuning / test knobs (name -> integer value). Known names:
  *   "use_lds"      1 (default) stage the gather window in LDS, 0 gather from global memory
@@ -258,6 +259,11 @@ int coreg_last_visit_counts(coreg_handle* h, int64_t* counts5);
  *                  overlap inside a flat region) are re-evaluated with means first and centred sums second, as
  *                  c_correlate.py:39-72 does; 0: the one-pass formula everywhere
  *   "refine_cond_log10"  5 (default): log10 of that threshold; -1 re-evaluates every lag-point (tests)
+ *   "refine_max"   4 (default): re-evaluations per block of 16 consecutive lag slots (a re-evaluation walks every active
+ *                  grid point twice with ONE workgroup, ~1.5 ms at headline size: the cap bounds a sweep whose overlaps
+ *                  are degenerate everywhere -- flat images, a handful of samples per lag-point -- to a few tens of ms;
+ *                  the flagged lag-points beyond it keep the one-pass value and are counted, coreg_last_visit_counts);
+ *                  0 = no limit
  *   "tile_w"       0 (default, auto) or a power of two in [4, 256]: grid-tile width in points (tile = 1024 pts)
  *   "n_groups"     0 (default, auto): tile groups (partial-sum slabs) per lag batch
  *   "lds_bytes"    dynamic LDS per workgroup for the float64 gather window (default and max 159 KiB)

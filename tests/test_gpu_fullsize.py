@@ -128,6 +128,84 @@ def test_headline_size_oracle_spot_check(gpu_handle, big_scene, carr_ready):
         assert abs(got - want) <= 1e-10, (d1, d2, dr, got, want)
 
 
+@pytest.mark.parametrize("small_f64", [False, True])
+def test_headline_60x60_map_against_the_oracle(gpu_handle, big_scene, small_f64):
+    """THE headline plan -- 60 x 60 lags arange(-30, 30, 1), 15 patches of 256 lanes, compile-time pitch 121, tapered
+    group shares -- compared with the oracle where it is indexed INTO that map: the peak, two corners, the zero lag and
+    an arbitrary interior point.  Second variant: image to align with full float64 pixels (`bench.py --small-f64`, the
+    k_sweep<..., double, ...> kernels)."""
+    from euispice_coreg_amd import _lib, synthetic
+    from oracle import coreg_oracle as O
+    if small_f64:
+        small, hs, large, hl, truth = synthetic.make_scene(float32_exact=False)
+    else:
+        small, hs, large, hl, truth = big_scene
+    grid = _lib.Grid(LON, LAT, SHAPE)
+    gpu_handle.set_small(small)
+    gpu_handle.prepare_reference_carrington(large, hl, grid, 1.004, 2)
+    lag = np.arange(-30.0, 30.0, 1.0)
+    full = _sweep(gpu_handle, hs, grid, (lag, lag, None, None, None))[:, :, 0, 0, 0]
+    stats = gpu_handle.last_stats()
+    assert stats["small_is_f32"] == (0 if small_f64 else 1) and stats["n_sweep_launches"] == 1 and stats["used_lds"] == 1
+    assert np.isfinite(full).all()
+    am = np.unravel_index(np.argmax(full), full.shape)
+    assert (lag[am[0]], lag[am[1]]) == (truth["lag_crval1"], truth["lag_crval2"]) == (17.0, -9.0)
+    st = H.oracle_state(small, hs, large, hl, ([0.0], [0.0], None, None, None), shape=list(SHAPE), lonlims=list(LON),
+                        latlims=list(LAT), solar_r=(1.004,))
+    O.set_initial_header_values(st)
+    ref = O.prepare_reference(st, "carrington", 1.004)
+    for d1, d2 in [(17.0, -9.0), (-30.0, -30.0), (29.0, 29.0), (0.0, 0.0), (-12.0, 23.0)]:
+        want = O.step(st, "carrington", st.data_small, ref, d1, d2, 0.0, 0.0, 0.0, 1.004)
+        got = full[int(d1 + 30), int(d2 + 30)]
+        assert abs(got - want) <= 1e-10, (small_f64, d1, d2, got, want)
+
+
+def test_degenerate_overlaps_everywhere_stay_bounded_at_full_size(gpu_handle, big_scene):
+    """a sweep whose every lag-point is ill-conditioned (a near-constant reference inside the overlap, a pivot
+    far away) sends every lag-point to k_finalize's two-pass re-evaluation -- one workgroup walking all active points
+    twice per lag-point.  `refine_max` (default 4 per block of 16 lag slots) bounds that: 900 of the 3600 lag-points
+    are re-evaluated, the rest keep their one-pass value and are counted; the launch stays in the tens of ms.  The
+    re-evaluated lag-points agree with the two-pass oracle."""
+    from euispice_coreg_amd import _lib
+    from oracle import coreg_oracle as O
+    small, hs, large, hl, truth = big_scene
+    grid = _lib.Grid(LON, LAT, SHAPE)
+    rng = np.random.default_rng(99)
+    ref = 1000.0 + 1e-3 * rng.standard_normal((SHAPE[1], SHAPE[0]))
+    ref[:160, :160] = -1.0e7        # a corner far outside the small FOV's footprint: moves the pivot, never overlaps
+    gpu_handle.set_small(small)
+    gpu_handle.set_reference_on_grid(ref)
+    lag = np.arange(-30.0, 30.0, 1.0)
+    ls = _lib.LagSet(lag, lag, None, None, None)
+    try:
+        got = gpu_handle.sweep_carrington(hs, grid, 1.004, ls).reshape(60, 60)
+        st = gpu_handle.last_stats()
+        counts = gpu_handle.last_visit_counts()
+        print("degenerate sweep: total_gpu_ms", st["total_gpu_ms"], "sweep_kernel_ms", st["sweep_kernel_ms"], counts)
+        assert counts["refined_lag_points"] == 900 and counts["flagged_not_refined"] == 2700
+        assert st["total_gpu_ms"] < 60.0
+        assert np.isfinite(got).all()
+        # slot order inside a 12 x 20 (or whatever) patch decides WHICH lag-points are re-evaluated; deterministic
+        again = gpu_handle.sweep_carrington(hs, grid, 1.004, ls).reshape(60, 60)
+        assert np.array_equal(got, again)
+        # no cap: every lag-point re-evaluated (what rounds 1-3 did: seconds of one-block work are avoided by the cap)
+        gpu_handle.set_option("refine", 0)
+        one_pass = gpu_handle.sweep_carrington(hs, grid, 1.004, ls).reshape(60, 60)
+        refined = got != one_pass
+        assert 0 < refined.sum() <= 900
+        stt = H.oracle_state(small, hs, large, hl, ([0.0], [0.0], None, None, None), shape=list(SHAPE), lonlims=list(LON),
+                             latlims=list(LAT), solar_r=(1.004,))
+        O.set_initial_header_values(stt)
+        idx = np.argwhere(refined)
+        for i1, i2 in (idx[0], idx[len(idx) // 2], idx[-1]):
+            want = O.step(stt, "carrington", stt.data_small, ref, lag[i1], lag[i2], 0.0, 0.0, 0.0, 1.004)
+            # (|r| ~ 1e-3 here: a noise field against an image; the two-pass value is good to ~1e-9 of it, the one-pass
+            # value is garbage at the 1e-2 level)
+            assert abs(got[i1, i2] - want) <= 1e-9, (i1, i2, got[i1, i2], want, one_pass[i1, i2])
+    finally:
+        gpu_handle.set_option("refine", 1)
+
+
 def test_helioprojective_full_size(gpu_handle, big_scene):
     """Config 2 size (2048^2 vs 3072^2, sub-map semantics): oracle spot check + self-correlation property."""
     from euispice_coreg_amd import _lib

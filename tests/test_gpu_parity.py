@@ -594,7 +594,11 @@ def test_ill_conditioned_lag_points_are_re_evaluated_with_centred_sums(gpu_handl
     grid = dict(shape=(23, 25), lonlims=(200.0, 234.0), latlims=(-72.0, 22.0), order=2)
     want = H.oracle_carrington(small, hs, large, hl, lags, grid["shape"], grid["lonlims"], grid["latlims"], order=2,
                                solar_r=(1.004,))
-    got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, **grid)
+    gpu_handle.set_option("refine_max", 0)  # (6 active points: nearly every lag-point is degenerate; no cap here)
+    try:
+        got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, **grid)
+    finally:
+        gpu_handle.set_option("refine_max", 4)
     counts = gpu_handle.last_visit_counts()
     assert gpu_handle.last_stats()["n_active_points"] == 6
     assert counts["refined_lag_points"] > 0, counts
@@ -640,10 +644,12 @@ def test_re_evaluating_every_lag_point_gives_the_oracle_map(gpu_handle, order, f
 
     one_pass, n0 = run_all()
     gpu_handle.set_option("refine_cond_log10", -1)
+    gpu_handle.set_option("refine_max", 0)  # (no cap: every lag-point is re-evaluated)
     try:
         two_pass, n1 = run_all()
     finally:
         gpu_handle.set_option("refine_cond_log10", 5)
+        gpu_handle.set_option("refine_max", 4)
     assert n0 == [0, 0, 0]
     for k, (a, b) in enumerate(zip(one_pass, two_pass)):
         assert n1[k] == int(np.isfinite(b).sum()) or n1[k] >= int(np.isfinite(b).sum()), (k, n1)
