@@ -163,8 +163,8 @@ SYMBOLS = [
     ("coreg_multi_sweep_helioprojective", C.c_int, [_P, _WP, _WP, C.POINTER(Lags), C.c_int, C.c_int, C.c_int, _P]),
     ("coreg_multi_last_stats", C.c_int, [_P, C.c_int, C.POINTER(Stats)]),
     ("coreg_multi_plan", C.c_int,
-     [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-      C.POINTER(C.c_int32)]),
+     [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 ]
 
 _lib = None
@@ -576,12 +576,12 @@ def physical_device_count() -> int:
     return max(0, int(load_library().coreg_physical_device_count()))
 
 
-def multi_plan(n_crval1, n_crval2, n_inner, world):
+def multi_plan(n_crval1, n_crval2, n_inner, world, per_combo_launch=True):
     """(mode, g_combo, g1, g2) the in-library multi-GPU driver gives a lag set (host-only helper; mirrors
     parallel.lag_plan)."""
     mode, gc, g1, g2 = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
-    rc = load_library().coreg_multi_plan(int(n_crval1), int(n_crval2), int(n_inner), int(world), C.byref(mode),
-                                         C.byref(gc), C.byref(g1), C.byref(g2))
+    rc = load_library().coreg_multi_plan(int(n_crval1), int(n_crval2), int(n_inner), int(world), int(per_combo_launch),
+                                         C.byref(mode), C.byref(gc), C.byref(g1), C.byref(g2))
     if rc != COREG_OK:
         raise CoregError(rc, "coreg_multi_plan: bad arguments")
     return MULTI_MODES[mode.value], gc.value, g1.value, g2.value

@@ -189,7 +189,7 @@ void multi_combo_bounds(long long inner, int g_combo, int k, long long* lo, long
 struct MultiPlan {
     int mode = MULTI_NONE, g_combo = 1, g1 = 1, g2 = 1;
 };
-MultiPlan multi_lag_plan(int n1, int n2, long long inner, int world) {
+MultiPlan multi_lag_plan(int n1, int n2, long long inner, int world, bool per_combo_launch = true) {
     MultiPlan p;
     const long long n = (long long)n1 * n2 * inner;
     if (world <= 1) return p;
@@ -210,8 +210,10 @@ MultiPlan multi_lag_plan(int n1, int n2, long long inner, int world) {
         if (!full) continue;
         int g1, g2;
         multi_block_grid(n1, n2, gb, &g1, &g2);
-        const double cost = (double)((inner + gc - 1) / gc) *
-                            (kLaunchOverheadBatches + (double)multi_lag_batches((n1 + g1 - 1) / g1, (n2 + g2 - 1) / g2));
+        const double n_c = (double)((inner + gc - 1) / gc);
+        const double n_b = (double)multi_lag_batches((n1 + g1 - 1) / g1, (n2 + g2 - 1) / g2);
+        // (one launch per combination, or -- helioprojective -- one launch in all: parallel.lag_plan)
+        const double cost = per_combo_launch ? n_c * (kLaunchOverheadBatches + n_b) : kLaunchOverheadBatches + n_c * n_b;
         if (best < 0 || cost < best - 1e-9 || (std::fabs(cost - best) <= 1e-9 && gc > p.g_combo)) {
             best = cost;
             p.g_combo = gc;
@@ -305,7 +307,7 @@ void multi_drop_rccl(coreg_multi* m, const char* why) {
 }
 
 // one sweep on every device + the collective; `launch(k, lags_k, begin, end, out_dev)` = the per-device sweep call
-int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out,
+int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out, bool per_combo_launch,
                 const std::function<int(int, const coreg_lags*, int64_t, int64_t, double*)>& launch) {
     if (!m) return COREG_EINVAL;
     if (!lags || !lags->crval1 || !lags->crval2 || !lags->cdelt1 || !lags->cdelt2 || !lags->crota || lags->n_crval1 < 1 ||
@@ -315,7 +317,7 @@ int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out,
     const long long inner = (long long)lags->n_cdelt1 * lags->n_cdelt2 * lags->n_crota;
     const long long n_lags = (long long)n1 * n2 * inner;
     if (!corr_out && n_lags > 0) return mfail(m, COREG_EINVAL, "corr_out is null");
-    MultiPlan plan = multi_lag_plan(n1, n2, inner, world);
+    MultiPlan plan = multi_lag_plan(n1, n2, inner, world, per_combo_launch);
     if (m->force_mode >= 0 && world > 1) {  // tests: "force_mode" 1 = blocks, 2 = slices, 4 = combos over the whole plane
         if (m->force_mode == MULTI_SLICES) plan.mode = MULTI_SLICES;
         if (m->force_mode == MULTI_BLOCKS || m->force_mode == MULTI_COMBOS) {
@@ -660,10 +662,10 @@ int coreg_physical_device_count(void) {
     return ndev;
 }
 
-int coreg_multi_plan(int32_t n_crval1, int32_t n_crval2, int64_t n_inner, int32_t world, int32_t* mode, int32_t* g_combo,
-                     int32_t* g1, int32_t* g2) {
+int coreg_multi_plan(int32_t n_crval1, int32_t n_crval2, int64_t n_inner, int32_t world, int32_t per_combo_launch,
+                     int32_t* mode, int32_t* g_combo, int32_t* g1, int32_t* g2) {
     if (n_crval1 < 1 || n_crval2 < 1 || n_inner < 1 || world < 1 || !mode || !g_combo || !g1 || !g2) return COREG_EINVAL;
-    const MultiPlan p = multi_lag_plan(n_crval1, n_crval2, n_inner, world);
+    const MultiPlan p = multi_lag_plan(n_crval1, n_crval2, n_inner, world, per_combo_launch != 0);
     *mode = p.mode;
     *g_combo = p.g_combo;
     *g1 = p.g1;
@@ -893,7 +895,7 @@ int coreg_multi_prepare_reference_helioprojective_fits(coreg_multi* m, const cor
 
 int coreg_multi_sweep_carrington(coreg_multi* m, const coreg_wcs2d* hdr_small, const coreg_carr_grid* grid, double solar_r,
                                  const coreg_lags* lags, int order, int method, int cdelt_semantics, double* corr_out) {
-    return multi_sweep(m, lags, corr_out, [&](int k, const coreg_lags* l, int64_t lo, int64_t hi, double* out_dev) {
+    return multi_sweep(m, lags, corr_out, true, [&](int k, const coreg_lags* l, int64_t lo, int64_t hi, double* out_dev) {
         return out_dev ? coreg_sweep_carrington(m->h[k], hdr_small, grid, solar_r, l, order, method, cdelt_semantics, lo,
                                                 hi, out_dev, 1)
                        : coreg_sweep_carrington(m->h[k], hdr_small, grid, solar_r, l, order, method, cdelt_semantics, lo,
@@ -903,7 +905,9 @@ int coreg_multi_sweep_carrington(coreg_multi* m, const coreg_wcs2d* hdr_small, c
 
 int coreg_multi_sweep_helioprojective(coreg_multi* m, const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_small,
                                       const coreg_lags* lags, int order, int method, int cdelt_semantics, double* corr_out) {
-    return multi_sweep(m, lags, corr_out, [&](int k, const coreg_lags* l, int64_t lo, int64_t hi, double* out_dev) {
+    // (TAN headers: one launch whatever the lag set; plate-carree maps: one launch per (cdelt, crota) combination)
+    const bool per_combo = hdr_target && hdr_target->proj == COREG_PROJ_CAR;
+    return multi_sweep(m, lags, corr_out, per_combo, [&](int k, const coreg_lags* l, int64_t lo, int64_t hi, double* out_dev) {
         return out_dev ? coreg_sweep_helioprojective(m->h[k], hdr_target, hdr_small, l, order, method, cdelt_semantics, lo,
                                                      hi, out_dev, 1)
                        : coreg_sweep_helioprojective(m->h[k], hdr_target, hdr_small, l, order, method, cdelt_semantics, lo,

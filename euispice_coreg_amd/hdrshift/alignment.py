@@ -354,12 +354,14 @@ class Alignment:
         # all-gather -- the partition bench.py measures; contiguous slices of the raveled index (the reference's literal
         # np.array_split, alignment.py:677-687) when the plane is smaller than the number of GPUs; shares of the GRID +
         # one all-reduce of the six sums per lag when there are few lag-points per GPU.
-        mode = parallel.lag_sharding(lags.shape, world)
+        # (the helioprojective sweep runs ONE launch whatever the lag set; the others one per (cdelt, crota) combination)
+        per_combo = self.coordinate_frame != "final_helioprojective"
+        mode = parallel.lag_sharding(lags.shape, world, per_combo)
         self.last_sharding = mode
         my_lags, lo, hi = lags, 0, lags.size
         combos = None  # (c_lo, c_hi): this rank's run of (cdelt1, cdelt2, crota) combinations, None = all of them
         if mode in ("blocks", "combos"):
-            lo1, hi1, lo2, hi2, c_lo, c_hi = parallel.grid_share(lags.shape, world, rank)
+            lo1, hi1, lo2, hi2, c_lo, c_hi = parallel.grid_share(lags.shape, world, rank, per_combo)
             a = lags.arrays
             my_lags = _lib.LagSet(a[0][lo1:hi1], a[1][lo2:hi2], a[2], a[3], a[4])
             inner = lags.shape[2] * lags.shape[3] * lags.shape[4]
@@ -416,7 +418,7 @@ class Alignment:
             if mode == "points":
                 part = parallel.point_sharded_sweep(h, run, lags.size)
             elif mode in ("blocks", "combos"):
-                part = parallel.allgather_lag_blocks(run(), lags.shape)
+                part = parallel.allgather_lag_blocks(run(), lags.shape, per_combo_launch=per_combo)
             elif mode == "slices":
                 part = parallel.allgather_lag_slices(run(), lags.size).cpu().numpy()
             else:

@@ -108,7 +108,7 @@ def combo_bounds(inner: int, g_combo: int, k: int):
     return lo, lo + q + (1 if k < r else 0)
 
 
-def lag_plan(shape5, world: int):
+def lag_plan(shape5, world: int, per_combo_launch: bool = True):
     """How a sweep over the lag set `shape5` = (n_crval1, n_crval2, n_cdelt1, n_cdelt2, n_crota) is spread over `world`
     GPUs: (mode, g_combo, g1, g2).  The GPUs form a g_combo x (g1 x g2) grid: rank r = kc * (g1 * g2) + kb sweeps the
     inner (cdelt1, cdelt2, crota) combinations `combo_bounds(inner, g_combo, kc)` over block kb of the (CRVAL1, CRVAL2)
@@ -122,7 +122,9 @@ def lag_plan(shape5, world: int):
       'slices'  contiguous slices of the raveled C-order index, the literal np.array_split fan-out of the reference
                 (alignment.py:677-687), when no grid gives every rank work (e.g. 3 x 3 CRVAL lags on 8 GPUs).
     Among the grids that give every rank a non-empty share the planner takes the cheapest by the model above (cost of
-    the busiest rank: launches x (fixed cost + lag batches)); ties go to the larger g_combo."""
+    the busiest rank: launches x fixed cost + lag batches); ties go to the larger g_combo.  `per_combo_launch`: the
+    Carrington and plate-carree sweeps run one precompute + one launch per combination; the helioprojective sweep
+    carries the combination in each lane's homography and runs ONE launch whatever the lag set (False)."""
     n1, n2 = int(shape5[0]), int(shape5[1])
     inner = int(shape5[2]) * int(shape5[3]) * int(shape5[4])
     n = n1 * n2 * inner
@@ -138,7 +140,8 @@ def lag_plan(shape5, world: int):
         if not all(b[1] > b[0] and b[3] > b[2] for b in (block_bounds(n1, n2, gb, r) for r in range(gb))):
             continue
         g1, g2 = block_grid(n1, n2, gb)
-        cost = (-(-inner // gc)) * (LAUNCH_OVERHEAD_BATCHES + lag_batches(-(-n1 // g1), -(-n2 // g2)))
+        n_c, n_b = -(-inner // gc), lag_batches(-(-n1 // g1), -(-n2 // g2))
+        cost = n_c * (LAUNCH_OVERHEAD_BATCHES + n_b) if per_combo_launch else LAUNCH_OVERHEAD_BATCHES + n_c * n_b
         if best is None or cost < best[0] - 1e-9 or (abs(cost - best[0]) <= 1e-9 and gc > best[1]):
             best = (cost, gc, g1, g2)
     if best is None:
@@ -146,14 +149,14 @@ def lag_plan(shape5, world: int):
     return ("combos" if best[1] > 1 else "blocks"), best[1], best[2], best[3]
 
 
-def lag_sharding(shape5, world: int) -> str:
+def lag_sharding(shape5, world: int, per_combo_launch: bool = True) -> str:
     """The mode of `lag_plan` alone ('none', 'points', 'blocks', 'combos', 'slices')."""
-    return lag_plan(shape5, world)[0]
+    return lag_plan(shape5, world, per_combo_launch)[0]
 
 
-def grid_share(shape5, world: int, rank: int):
+def grid_share(shape5, world: int, rank: int, per_combo_launch: bool = True):
     """This rank's share under a 'blocks' / 'combos' plan: (lo1, hi1, lo2, hi2, c_lo, c_hi)."""
-    _, gc, g1, g2 = lag_plan(shape5, world)
+    _, gc, g1, g2 = lag_plan(shape5, world, per_combo_launch)
     gb = g1 * g2
     kc, kb = rank // gb, rank % gb
     inner = int(shape5[2]) * int(shape5[3]) * int(shape5[4])
@@ -161,17 +164,17 @@ def grid_share(shape5, world: int, rank: int):
     return block_bounds(int(shape5[0]), int(shape5[1]), gb, kb) + (c_lo, c_hi)
 
 
-def grid_gather_index(shape5, world: int):
+def grid_gather_index(shape5, world: int, per_combo_launch: bool = True):
     """Index array `perm` (int64, prod(shape5) long) with full.ravel() = gathered[perm], where `gathered` is the
     concatenation over ranks of each rank's C-order share [hi1-lo1, hi2-lo2, c_hi-c_lo] padded to `chunk` values.
     Returns (perm, chunk).  With g_combo = 1 this is `block_gather_index`."""
     n1, n2, n3, n4, n5 = (int(v) for v in shape5)
     inner = n3 * n4 * n5
-    _, gc, g1, g2 = lag_plan(shape5, world)
+    _, gc, g1, g2 = lag_plan(shape5, world, per_combo_launch)
     chunk = (-(-n1 // g1)) * (-(-n2 // g2)) * (-(-inner // gc))
     perm = np.empty((n1, n2, inner), dtype=np.int64)
     for r in range(world):
-        lo1, hi1, lo2, hi2, c_lo, c_hi = grid_share(shape5, world, r)
+        lo1, hi1, lo2, hi2, c_lo, c_hi = grid_share(shape5, world, r, per_combo_launch)
         if hi1 <= lo1 or hi2 <= lo2 or c_hi <= c_lo:
             continue
         w2, nc = hi2 - lo2, c_hi - c_lo
@@ -182,14 +185,14 @@ def grid_gather_index(shape5, world: int):
     return perm.reshape(-1), chunk
 
 
-def allgather_lag_blocks(local, shape5, group=None):
+def allgather_lag_blocks(local, shape5, group=None, per_combo_launch: bool = True):
     """Every rank holds the coefficients of its share of the lag set -- a block of the (CRVAL1, CRVAL2) plane times a run
     of inner combinations (`grid_share`; C order [hi1-lo1, hi2-lo2, c_hi-c_lo], numpy): ONE all-gather of ceil-sized chunks
     + one index permutation give the full raveled C-order map (numpy) on every rank."""
     import torch
     import torch.distributed as dist
     rank, world = world_info(group)
-    perm, chunk = grid_gather_index(tuple(int(v) for v in shape5), world)
+    perm, chunk = grid_gather_index(tuple(int(v) for v in shape5), world, per_combo_launch)
     backend = dist.get_backend(group) if world > 1 else None
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     buf = torch.full((chunk,), float("nan"), dtype=torch.float64, device=dev)

@@ -397,9 +397,11 @@ int coreg_multi_last_stats(coreg_multi* m, int k, coreg_stats* out);
 /* The partition a sweep over (n_crval1, n_crval2, n_inner = n_cdelt1 n_cdelt2 n_crota) lag-points gets on `world` GPUs
  * (host-only; checked against euispice_coreg_amd/parallel.py): mode as coreg_multi_last_mode; the GPUs form a
  * g_combo x (g1 x g2) grid: the inner combinations are dealt in g_combo contiguous runs, the (CRVAL1, CRVAL2) plane is
- * cut in g1 x g2 blocks (mode 1 "blocks": g_combo = 1; mode 4 "combos": g_combo > 1). */
-int coreg_multi_plan(int32_t n_crval1, int32_t n_crval2, int64_t n_inner, int32_t world, int32_t* mode, int32_t* g_combo,
-                     int32_t* g1, int32_t* g2);
+ * cut in g1 x g2 blocks (mode 1 "blocks": g_combo = 1; mode 4 "combos": g_combo > 1).  per_combo_launch: 1 for the
+ * Carrington / plate-carree sweeps (one precompute + launch per combination), 0 for helioprojective (TAN) sweeps (one
+ * launch whatever the lag set): it enters the planner's cost model. */
+int coreg_multi_plan(int32_t n_crval1, int32_t n_crval2, int64_t n_inner, int32_t world, int32_t per_combo_launch,
+                     int32_t* mode, int32_t* g_combo, int32_t* g1, int32_t* g2);
 
 #ifdef __cplusplus
 }

@@ -76,24 +76,29 @@ def main():
             sweep = lambda sub, n: h.sweep_helioprojective(hs4, hs4, sub, lag_end=n)  # noqa: E731
             reps = 2
         inner = lags.shape[2] * lags.shape[3] * lags.shape[4]
+        per_combo = name != "cfg4"  # (the helioprojective sweep runs one launch whatever the lag set)
         t1 = None
         for world in (1, 2, 4, 8):
-            plan = parallel.lag_plan(lags.shape, world)
-            shares = {"planner": parallel.grid_share(lags.shape, world, 0) if plan[0] in ("blocks", "combos") else None,
-                      "blocks": parallel.block_bounds(lags.shape[0], lags.shape[1], world, 0) + (0, inner)}
+            plan = parallel.lag_plan(lags.shape, world, per_combo)
+            shares = {"planner": parallel.grid_share(lags.shape, world, 0, per_combo) if plan[0] in ("blocks", "combos") else None,
+                      "blocks": parallel.block_bounds(lags.shape[0], lags.shape[1], world, 0) + (0, inner),
+                      # (what the planner would pick if every combination were a launch of its own)
+                      "combos": parallel.grid_share(lags.shape, world, 0, True)
+                      if parallel.lag_plan(lags.shape, world, True)[0] == "combos" else None}
             if world == 1:
                 shares = {"planner": (0, lags.shape[0], 0, lags.shape[1], 0, inner)}
             for part, share in shares.items():
-                if share is None or (part == "blocks" and plan[0] == "blocks" and world > 1):
-                    continue  # (the planner's choice IS the block partition: timed once)
+                if share is None or (part != "planner" and world > 1 and share == shares["planner"]):
+                    continue  # (the planner's choice IS this partition: timed once)
                 call, n = share_call(h, sweep, lags, share)
                 dt = timed(call, reps)
                 st = h.last_stats()
                 if world == 1:
                     t1 = dt
                 print(json.dumps({"config": name, "n_gpus": world, "partition": part,
-                                  "plan": list(plan) if part == "planner" else ["blocks", 1] + list(
-                                      parallel.block_grid(lags.shape[0], lags.shape[1], world)),
+                                  "plan": list(plan) if part == "planner" else (
+                                      list(parallel.lag_plan(lags.shape, world, True)) if part == "combos" else
+                                      ["blocks", 1] + list(parallel.block_grid(lags.shape[0], lags.shape[1], world))),
                                   "rank0_lag_points": n, "rank0_ms": round(dt * 1e3, 3),
                                   "rank0_sweep_launches": st["n_sweep_launches"],
                                   "rank0_kernel_ms": round(st["sweep_kernel_ms"], 3),

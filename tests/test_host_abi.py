@@ -284,13 +284,17 @@ def test_multi_plan_matches_the_python_partition(lib):
     seen = set()
     for n1, n2, inner in shapes:
         for world in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16):
-            mode, gc, g1, g2 = lib.multi_plan(n1, n2, inner, world)
-            want = parallel.lag_plan((n1, n2, inner, 1, 1), world)
-            seen.add(mode)
-            assert mode == want[0], (n1, n2, inner, world, mode, want)
-            if mode in ("blocks", "combos"):
-                assert (gc, g1, g2) == want[1:] and gc * g1 * g2 == world, (n1, n2, inner, world, (gc, g1, g2), want)
-                assert (mode == "combos") == (gc > 1)
-            else:
-                assert (g1, g2) == parallel.block_grid(n1, n2, world), (n1, n2, inner, world)
+            for per_combo in (True, False):
+                mode, gc, g1, g2 = lib.multi_plan(n1, n2, inner, world, per_combo)
+                want = parallel.lag_plan((n1, n2, inner, 1, 1), world, per_combo)
+                seen.add(mode)
+                assert mode == want[0], (n1, n2, inner, world, per_combo, mode, want)
+                if mode in ("blocks", "combos"):
+                    assert (gc, g1, g2) == want[1:] and gc * g1 * g2 == world, (n1, n2, inner, world, (gc, g1, g2), want)
+                    assert (mode == "combos") == (gc > 1)
+                else:
+                    assert (g1, g2) == parallel.block_grid(n1, n2, world), (n1, n2, inner, world)
     assert seen == {"none", "points", "blocks", "combos", "slices"}
+    # cfg4 is a helioprojective sweep (one launch for all 21 CROTA values): blocks of the plane; as a Carrington sweep it
+    # would be dealt by combination
+    assert lib.multi_plan(61, 61, 21, 8, False)[0] == "blocks" and lib.multi_plan(61, 61, 21, 8, True)[0] == "combos"
