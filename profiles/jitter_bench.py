@@ -42,9 +42,10 @@ def main():
 
     # stage costs, one image, serial
     t = {}
-    t0 = time.perf_counter(); img, hdr = fits_io.read_image(paths[1], -1); t["fits_decode_ms"] = 1e3 * (time.perf_counter() - t0)
+    t0 = time.perf_counter(); img, hdr = fits_io.read_image(paths[1], -1); t["fits_decode_host_ms"] = 1e3 * (time.perf_counter() - t0)
+    t0 = time.perf_counter(); raw, hdr = fits_io.load_for_upload(paths[1], -1); t["fits_open_raw_ms"] = 1e3 * (time.perf_counter() - t0)
     h = _lib.shared_handle(-1)
-    t0 = time.perf_counter(); h.set_small(img); h.threshold_small(None, 2800.0); t["upload_threshold_ms"] = 1e3 * (time.perf_counter() - t0)
+    t0 = time.perf_counter(); h.set_small(raw); h.threshold_small(None, 2800.0); t["upload_decode_threshold_ms"] = 1e3 * (time.perf_counter() - t0)
     grid = _lib.Grid(lon, lat, shape)
     lags = _lib.LagSet(np.arange(-5, 5, 0.1), np.arange(-5, 5, 0.1), None, None, None)
     t0 = time.perf_counter(); h.sweep_carrington(hdr, grid, 1.004, lags); t["sweep_call_ms"] = 1e3 * (time.perf_counter() - t0)
@@ -56,7 +57,9 @@ def main():
     t0 = time.perf_counter(); AlignmentResults(done[0][2].corr, lags.arrays[0], lags.arrays[1], None, None, None, "arcsec"); t["gauss_fit_ms"] = 1e3 * (time.perf_counter() - t0)
     print(json.dumps({"images": len(done), "n": n, "lags_per_image": 10000, "wall_s": dt, "images_per_s": len(done) / dt,
                       "lag_points_per_s": 10000 * len(done) / dt, "active_points": st["n_active_points"],
-                      "max_abs_shift_error_arcsec": err.max(axis=0).tolist(), "stages": t}))
+                      "max_abs_shift_error_arcsec": err.max(axis=0).tolist(), "stages": t,
+                      "devices": [list(d) for d in __import__("euispice_coreg_amd.jitter_correction.jitter_correction",
+                                                              fromlist=["session_devices"]).session_devices(None, 1)]}))
 
 
 if __name__ == "__main__":

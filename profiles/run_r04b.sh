@@ -12,6 +12,7 @@ timeout -k 10 300 python3 profiles/jitter_bench.py > $O/jitter_bench.json 2> $O/
 cat $O/jitter_bench.json; echo
 COREG_VIRTUAL_DEVICES=2 timeout -k 10 300 python3 profiles/jitter_bench.py > $O/jitter_bench_virtual2.json 2> $O/jitter2.err || { tail $O/jitter2.err; exit 1; }
 cat $O/jitter_bench_virtual2.json; echo
+timeout -k 10 100 python3 profiles/copy_bench.py > $O/copy_bench.json 2>&1; cat $O/copy_bench.json
 timeout -k 10 400 python3 profiles/partition_timing.py > $O/partition_timing.jsonl 2> $O/partition.err || { tail $O/partition.err; exit 1; }
 cat $O/partition_timing.jsonl
 timeout -k 10 400 python3 profiles/slice_timing.py > $O/slice_timing.log 2> $O/slice_timing.err || { tail $O/slice_timing.err; exit 1; }
