@@ -2393,7 +2393,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     int n_batches = 0;
     double fx0 = 1e300, fx1 = -1e300, fy0 = 1e300, fy1 = -1e300;  // cull box in target pixels
     HomographyFamily fam;
-    fam.init(*hdr_target, *hdr_small, lags->crval1, d.n1, lags->crval2, d.n2);
+    fam.init(*hdr_target, *hdr_small, lags->crval1, d.n1, lags->crval2, d.n2, d.nc > 1);
     BorderFix fix;
     std::vector<std::vector<unsigned char>> flags_host;  // per noise-decided lag-point (odd spline orders only)
     const int i1_lo = (int)(lag_begin / row), i1_hi = (int)((lag_end - 1) / row);

@@ -154,9 +154,13 @@ inline Mat3d mul3(const Mat3d& a, const Mat3d& b) {
 struct HomographyFamily {
     std::vector<Mat3d> Q;  // [n1]
     std::vector<Mat3d> P;  // [n2]
+    // P[i2] * Q[i1], filled on first use: a sweep over several (cdelt, crota) combinations asks for every (i1, i2) once per
+    // combination (same product, same bits)
+    mutable std::vector<Mat3d> PQ;
+    mutable std::vector<unsigned char> have_pq;
     // from: header whose pixel grid is mapped (target grid); ref: unshifted header being lagged
     void init(const coreg_wcs2d& from, const coreg_wcs2d& ref, const double* lag1, int n1, const double* lag2,
-              int n2) {
+              int n2, bool cache_products = false) {
         const Mat3 N = {{{0, -1, 0}, {1, 0, 0}, {0, 0, 1}}};
         const Mat3 m1 = mat_mul(native_to_celestial(from), mat_mul(N, pix_to_iwc(from)));
         const ld d2r = (ld)kPi / 180.0L;
@@ -174,6 +178,12 @@ struct HomographyFamily {
             const Mat3 t = {{{-sinl(dp), 0, cosl(dp)}, {0, -1, 0}, {cosl(dp), 0, sinl(dp)}}};
             P[j] = to_double(mat_mul(rzp, t));
         }
+        PQ.clear();
+        have_pq.clear();
+        if (cache_products && (size_t)n1 * n2 <= ((size_t)1 << 20)) {  // (72 B per lag of the plane)
+            PQ.assign((size_t)n1 * n2, Mat3d());
+            have_pq.assign((size_t)n1 * n2, 0);
+        }
     }
     // per (cdelt, crota) combination: B = iwc_to_pix(shifted header) * Ninv
     static Mat3d combo(const coreg_wcs2d& shifted) {
@@ -181,7 +191,18 @@ struct HomographyFamily {
         return to_double(mat_mul(iwc_to_pix(shifted), Ninv));
     }
     void get(const Mat3d& B, int i1, int i2, double h[9]) const {
-        const Mat3d m = mul3(B, mul3(P[i2], Q[i1]));
+        Mat3d pq;
+        if (!PQ.empty()) {
+            const size_t k = (size_t)i2 * Q.size() + i1;
+            if (!have_pq[k]) {
+                PQ[k] = mul3(P[i2], Q[i1]);
+                have_pq[k] = 1;
+            }
+            pq = PQ[k];
+        } else {
+            pq = mul3(P[i2], Q[i1]);
+        }
+        const Mat3d m = mul3(B, pq);
         const double s = 1.0 / m.m[2][2];
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) h[3 * i + j] = m.m[i][j] * s;

@@ -97,14 +97,16 @@ class AlignmentSpice(Alignment):
     # ------------------------------------------------------------------------------------------------------------
     def _extract_imager_data_header(self):
         """alignment_spice.py:182-187."""
-        dl, hl = fits_io.read_image(self.large_fov_known_pointing, self.large_fov_window)
-        self.data_large = np.array(dl, dtype=np.float64)
-        self.hdr_large = fits_io.Header(hl)
+        # (the pixels are read when the reference is prepared -- `Alignment._large_pixels`: as stored, cropped to what the
+        # target grid can touch, decoded on the GPU; not at all when the prepared reference is still resident)
+        self.data_large = None
+        self.hdr_large = fits_io.Header(fits_io.read_header(self.large_fov_known_pointing, self.large_fov_window))
         hdrutil.check_and_create_pcij_matrix(self.hdr_large, self.force_crota_0, warn=False)
 
     def _extract_spice_data_header(self, level, coeff=None):
         """alignment_spice.py:189-221."""
-        cube, hdr = fits_io.read_image(self.small_fov_to_correct, self.small_fov_window)
+        # a big-endian view of the memory-mapped window: only the wavelength planes the sum needs are ever touched
+        cube, hdr = fits_io.open_cube(self.small_fov_to_correct, self.small_fov_window)
         hdr = fits_io.Header(hdr)
         dt = hdr["PC4_1"]
         if level == 2:

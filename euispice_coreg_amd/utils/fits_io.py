@@ -215,6 +215,29 @@ def open_raw(path, window=-1):
     return RawImage(os.fspath(path), pos, nbytes, shape, hdr)
 
 
+def open_cube(path, window=-1):
+    """(array, header) of an image HDU of any dimension WITHOUT reading or decoding it: a read-only big-endian view of
+    the memory-mapped data unit (NumPy converts what is actually touched, plane by plane, when it is used).  For the
+    4-D SPICE windows of which a sweep needs a few wavelength planes.  Falls back to `read_image` (everything decoded)
+    for anything that is not a plain, unscaled image HDU of a local file."""
+    if isinstance(path, (str, os.PathLike)) and os.path.isfile(path):
+        try:
+            hdus, spans = _scan(path)
+            i = _select([(h, None) for h in hdus], window)
+            hdr = hdus[i]
+            is_image = hdr.get("SIMPLE") is not None or str(hdr.get("XTENSION", "")).strip() == "IMAGE"
+            plain = (spans[i] is not None and is_image and int(hdr["BITPIX"]) in _BITPIX_DTYPE
+                     and hdr.get("BSCALE", 1) == 1 and hdr.get("BZERO", 0) == 0
+                     and int(hdr.get("GCOUNT", 1)) == 1 and int(hdr.get("PCOUNT", 0)) == 0)
+        except (IOError, KeyError, IndexError, ValueError):
+            plain = False
+        if plain:
+            pos, nbytes, shape = spans[i]
+            arr = np.memmap(path, dtype=_BITPIX_DTYPE[int(hdr["BITPIX"])], mode="r", offset=pos, shape=tuple(shape))
+            return arr, hdr
+    return read_image(path, window)
+
+
 def load_for_upload(path, window=-1):
     """(pixels, header) of one HDU for the library: a RawImage (nothing decoded, nothing read yet beyond the header)
     when the HDU is a plain image of a local file, else what `read_image` returns."""

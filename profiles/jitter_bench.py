@@ -44,7 +44,8 @@ def main():
     t = {}
     t0 = time.perf_counter(); img, hdr = fits_io.read_image(paths[1], -1); t["fits_decode_host_ms"] = 1e3 * (time.perf_counter() - t0)
     t0 = time.perf_counter(); raw, hdr = fits_io.load_for_upload(paths[1], -1); t["fits_open_raw_ms"] = 1e3 * (time.perf_counter() - t0)
-    h = _lib.shared_handle(-1)
+    from euispice_coreg_amd.jitter_correction.jitter_correction import session_devices
+    h = _lib.shared_handle(*session_devices(None, 1)[0])  # (a context the session has left its prepared reference in)
     t0 = time.perf_counter(); h.set_small(raw); h.threshold_small(None, 2800.0); t["upload_decode_threshold_ms"] = 1e3 * (time.perf_counter() - t0)
     grid = _lib.Grid(lon, lat, shape)
     lags = _lib.LagSet(np.arange(-5, 5, 0.1), np.arange(-5, 5, 0.1), None, None, None)
