@@ -132,6 +132,7 @@ SYMBOLS = [
     ("coreg_car_map", C.c_int, [_WP, _WP, C.c_int64, _P, _P, _P, _P]),
     ("coreg_wcslib_pixel_to_pixel", C.c_int, [_WP, _WP, C.c_int64, _P, _P, _P, _P, _P, _P]),
     ("coreg_car_tile_margin", C.c_int, [_WP, _WP, C.c_int32, C.c_double, C.POINTER(C.c_double)]),
+    ("coreg_nansum_planes_be", C.c_int, [_P, C.c_int32, C.c_int64, _P, C.c_int32, _P]),
     ("coreg_fit_gaussian2d", C.c_int,
      [C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, _P,
       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -875,6 +876,24 @@ def wcslib_pixel_to_pixel(hdr_from, hdr_to, px, py):
     if rc != COREG_OK:
         raise CoregError(rc, "coreg_wcslib_pixel_to_pixel")
     return tuple(out)
+
+
+def nansum_planes_be(cube_be, plane_index):
+    """np.nansum(float64(cube_be)[plane_index], axis=0) of a big-endian float32 / float64 array [n_planes, ...] (a view
+    of a FITS data unit) by the library's threaded host routine; None when the array is not of that kind."""
+    a = cube_be
+    if a.dtype.kind != "f" or a.dtype.byteorder != ">" or a.dtype.itemsize not in (4, 8) or not a.flags.c_contiguous:
+        return None
+    idx = np.ascontiguousarray(plane_index, dtype=np.int64)
+    if idx.size and (idx.min() < 0 or idx.max() >= a.shape[0]):
+        raise IndexError("plane index out of range")
+    n_pix = int(np.prod(a.shape[1:]))
+    out = np.empty(a.shape[1:], dtype=np.float64)
+    rc = load_library().coreg_nansum_planes_be(a.ctypes.data, -8 * a.dtype.itemsize, n_pix, idx.ctypes.data, idx.size,
+                                               out.ctypes.data)
+    if rc != COREG_OK:
+        raise CoregError(rc, "coreg_nansum_planes_be: bad arguments")
+    return out
 
 
 def fit_gaussian2d(x, y, z, p0, lb, ub, jac="2-point", ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=0):

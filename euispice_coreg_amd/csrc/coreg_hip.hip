@@ -2694,6 +2694,49 @@ int coreg_carrington_origin(const coreg_wcs2d* hdr, double* x0, double* y0) {
     return COREG_OK;
 }
 
+int coreg_nansum_planes_be(const void* cube, int32_t bitpix, int64_t n_pixels, const int64_t* plane_index, int32_t n_sel,
+                           double* out) {
+    if (!cube || !out || n_pixels < 0 || n_sel < 0 || (n_sel > 0 && !plane_index) || (bitpix != -32 && bitpix != -64))
+        return COREG_EINVAL;
+    for (int k = 0; k < n_sel; ++k)
+        if (plane_index[k] < 0) return COREG_EINVAL;
+    auto work = [&](int64_t lo, int64_t hi) {
+        for (int64_t p = lo; p < hi; ++p) out[p] = 0.0;
+        for (int k = 0; k < n_sel; ++k) {
+            if (bitpix == -32) {
+                const uint32_t* src = (const uint32_t*)cube + (size_t)plane_index[k] * (size_t)n_pixels;
+                for (int64_t p = lo; p < hi; ++p) {
+                    const uint32_t u = __builtin_bswap32(src[p]);
+                    float f;
+                    std::memcpy(&f, &u, sizeof(f));
+                    const double v = (double)f;
+                    out[p] += (v != v) ? 0.0 : v;
+                }
+            } else {
+                const uint64_t* src = (const uint64_t*)cube + (size_t)plane_index[k] * (size_t)n_pixels;
+                for (int64_t p = lo; p < hi; ++p) {
+                    const uint64_t u = __builtin_bswap64(src[p]);
+                    double v;
+                    std::memcpy(&v, &u, sizeof(v));
+                    out[p] += (v != v) ? 0.0 : v;
+                }
+            }
+        }
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int nt = (int)std::min<int64_t>(std::min<unsigned>(hw, 12u), std::max<int64_t>(1, n_pixels * std::max(n_sel, 1) / (1 << 18)));
+    if (nt <= 1) {
+        work(0, n_pixels);
+        return COREG_OK;
+    }
+    std::vector<std::thread> th;
+    const int64_t per = ((n_pixels + nt - 1) / nt + 7) & ~(int64_t)7;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work, std::min<int64_t>(n_pixels, t * per), std::min<int64_t>(n_pixels, (t + 1) * per));
+    work(0, std::min<int64_t>(n_pixels, per));
+    for (auto& t : th) t.join();
+    return COREG_OK;
+}
+
 int coreg_fit_gaussian2d(int32_t m, const double* x, const double* y, const double* z, const double* p0,
                          const double* lb, const double* ub, int32_t jac, double ftol, double xtol, double gtol,
                          int32_t max_nfev, double* popt, int32_t* nfev, int32_t* status) {

@@ -321,6 +321,15 @@ int coreg_car_tile_margin(const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_
                           double tile_abs_lat_rad, double* margin_px);
 
 
+/* SPICE preparation (host only, no GPU): np.nansum(float64(cube)[0, selected], axis=0) of
+ * AlignmentSpice._prepare_spice_from_l2 (hdrshift/alignment_spice.py:250-323) straight from the FITS data unit: `cube`
+ * points at big-endian elements (BITPIX -32 or -64), plane k of `n_sel` selected planes starts at element
+ * plane_index[k] * n_pixels.  Every pixel is accumulated in float64 over the planes IN THE ORDER GIVEN, NaN counted as
+ * +0.0 -- the sequential reduction NumPy performs over an outer axis, hence the same sums to the bit -- by a few
+ * threads that split the pixels.  out: n_pixels doubles (all +0.0 when n_sel is 0). */
+int coreg_nansum_planes_be(const void* cube, int32_t bitpix, int64_t n_pixels, const int64_t* plane_index, int32_t n_sel,
+                           double* out);
+
 /* Sub-lag refinement of the correlation peak (host only, no GPU): the bounded least-squares fit of
  *     g(x, y) = offset + amplitude * exp(-((x - xo)^2 / (2 sigma_x^2) + (y - yo)^2 / (2 sigma_y^2)))
  * that AlignmentResults._compute_shift (hdrshift/AlignmentResults.py:12-21, :218-341) hands to

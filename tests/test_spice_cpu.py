@@ -142,3 +142,33 @@ def test_correct_solar_rotation_shrinks_cdelt1():
     want = 4.0 - (-25.2) * rate * np.cos(phi)
     assert abs(A.hdr_small["CDELT1"] * 3600 - want) < 1e-9
     assert want > 4.0  # PC4_1 < 0: the raster runs against the rotation
+
+
+def test_library_plane_sum_equals_numpy_nansum_to_the_bit():
+    """coreg_nansum_planes_be (threaded host routine on the big-endian data unit) == np.nansum(float64(cube)[sel], axis=0):
+    NaN counted as +0.0, infinities and signed zeros kept, the order of the additions that of the selection."""
+    from euispice_coreg_amd import _lib
+    rng = np.random.default_rng(4)
+    for dt in (">f4", ">f8"):
+        cube = (rng.standard_normal((9, 130, 70)) * 10.0 ** rng.integers(-6, 7, (9, 130, 70))).astype(dt)
+        cube[rng.random(cube.shape) < 0.05] = np.nan
+        cube[2, 5, 5], cube[3, 5, 5], cube[4, 6, 6] = np.inf, -np.inf, np.inf
+        cube[:, 7, 7] = -0.0
+        cube[:, 8, 8] = np.nan
+        for sel in (np.arange(9), np.array([1, 4, 5]), np.array([7, 2, 2, 0]), np.array([], dtype=np.int64), np.array([3])):
+            got = _lib.nansum_planes_be(cube, sel)
+            want = np.zeros(cube.shape[1:])
+            for k in sel:  # np.nansum over the outer axis: sequential, NaN -> 0
+                q = cube[k].astype(np.float64)
+                q[np.isnan(q)] = 0.0
+                want = want + q
+            with np.errstate(invalid="ignore"):
+                ref = np.nansum(cube[sel].astype(np.float64), axis=0) if len(sel) else want
+            assert np.array_equal(got, want, equal_nan=True) and np.array_equal(np.signbit(got), np.signbit(want))
+            assert np.array_equal(got, ref, equal_nan=True)
+        assert _lib.nansum_planes_be(cube.astype(cube.dtype.newbyteorder("=")), [0]) is None   # native order: NumPy's job
+        assert _lib.nansum_planes_be(cube[:, ::2], [0]) is None                               # not contiguous
+        with pytest.raises(IndexError):
+            _lib.nansum_planes_be(cube, [9])
+    big = rng.standard_normal((32, 832, 192)).astype(">f4")          # a SPICE window: several threads
+    assert np.array_equal(_lib.nansum_planes_be(big, np.arange(32)), big.astype(np.float64).sum(axis=0))
