@@ -289,3 +289,38 @@ def test_multi_on_two_or_more_physical_gpus(gpu_handle, monkeypatch):
                 assert np.nanmax(np.abs(got - want)) <= 1e-12, (force, m.last_mode)
         m.set_option("force_mode", -1)
         assert m.collective in ("rccl", "host-copy")
+
+
+def test_multi_helioprojective_and_plate_carree_3d_lag_sets(gpu_handle, monkeypatch):
+    """3-D lag sets (CROTA values) in the other two frames over three logical devices.  A helioprojective sweep is ONE
+    launch whatever the lag set, so the planner keeps lag-plane blocks (forced runs of combinations give the same map);
+    a plate-carree sweep is one launch per combination and is dealt by combination."""
+    from euispice_coreg_amd import _lib, parallel, synthetic
+    monkeypatch.setenv("COREG_VIRTUAL_DEVICES", "3")
+    small, hs, large, hl, _ = H.scene()
+    lags = (np.arange(-8.0, 20.0, 1.0), np.arange(-14.0, 3.0, 1.0), None, None, [0.0, 0.3, -0.2])
+    ls = _lib.LagSet(*lags)
+    want = H.gpu_helio(gpu_handle, small, hs, large, hl, lags).ravel()
+    assert parallel.lag_sharding(ls.shape, 3, per_combo_launch=False) == "blocks"
+    assert parallel.lag_sharding(ls.shape, 3, per_combo_launch=True) == "combos"
+    with _lib.MultiHandle() as m:
+        m.set_small(small)
+        m.prepare_reference_helioprojective(large, hl, hs, 2)
+        for force, mode in ((-1, "blocks"), (4, "combos"), (2, "slices")):
+            m.set_option("force_mode", force)
+            got = m.sweep_helioprojective(hs, hs, ls)
+            assert m.last_mode == mode
+            assert np.array_equal(np.isnan(got), np.isnan(want)) and np.nanmax(np.abs(got - want)) <= 1e-12, mode
+        m.set_option("force_mode", -1)
+        # plate-carree maps (align_using_initial_carrington): 40 x 40 lags x 3 CROTA values
+        cs, chs, cl, chl, _ = synthetic.make_car_scene(small_shape=(60, 70), large_shape=(90, 100))
+        clags = (np.linspace(-0.02, 0.02, 40), np.linspace(-0.015, 0.015, 40), None, None, [0.0, 0.2, -0.1])
+        cls = _lib.LagSet(*clags)
+        gpu_handle.set_small(cs)
+        gpu_handle.set_reference_on_grid(np.asarray(cl, dtype=np.float32))
+        wantc = gpu_handle.sweep_helioprojective(chl, chs, cls)
+        m.set_small(cs)
+        m.set_reference_on_grid(np.asarray(cl, dtype=np.float32))
+        gotc = m.sweep_helioprojective(chl, chs, cls)
+        assert m.last_mode == "combos"
+        assert np.array_equal(np.isnan(gotc), np.isnan(wantc)) and np.nanmax(np.abs(gotc - wantc)) <= 1e-12
