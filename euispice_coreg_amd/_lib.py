@@ -65,6 +65,51 @@ class FitsPixels(C.Structure):
                 ("bzero", C.c_double)]
 
 
+class FitsTiled(C.Structure):
+    _fields_ = [("heap", C.c_void_p), ("heap_bytes", C.c_int64), ("tile_offset", C.c_void_p), ("tile_nbytes", C.c_void_p),
+                ("n_tiles", C.c_int32), ("zbitpix", C.c_int32), ("naxis1", C.c_int32), ("naxis2", C.c_int32),
+                ("ztile1", C.c_int32), ("ztile2", C.c_int32), ("blocksize", C.c_int32), ("bytepix", C.c_int32),
+                ("quantize", C.c_int32), ("dither0", C.c_int32), ("has_blank", C.c_int32), ("blank", C.c_int32),
+                ("zscale", C.c_void_p), ("zzero", C.c_void_p), ("zscale0", C.c_double), ("zzero0", C.c_double),
+                ("bscale", C.c_double), ("bzero", C.c_double)]
+
+
+def _is_tiled(img):
+    """utils.fits_io.CompressedImage that the GPU can decode as it is (duck-typed)."""
+    return hasattr(img, "tile_nbytes") and hasattr(img, "ztile") and getattr(img, "on_gpu", False)
+
+
+def _fits_tiled(ci):
+    """(struct, arrays that must stay alive during the call) of a CompressedImage."""
+    off = np.ascontiguousarray(ci.tile_offset, dtype=np.int64)
+    nb = np.ascontiguousarray(ci.tile_nbytes, dtype=np.int32)
+    keep = [off, nb, ci._heap]
+    zs = zz = None
+    if ci.zscale is not None and ci.zzero is not None:
+        zs = np.ascontiguousarray(ci.zscale, dtype=np.float64)
+        zz = np.ascontiguousarray(ci.zzero, dtype=np.float64)
+        keep += [zs, zz]
+    t = FitsTiled(ci._heap.ctypes.data, int(ci._heap.size), off.ctypes.data, nb.ctypes.data, int(ci.n_tiles), int(ci.zbitpix),
+                  int(ci.shape[1]), int(ci.shape[0]), int(ci.ztile[0]), int(ci.ztile[1]), int(ci.blocksize), int(ci.bytepix),
+                  int(ci.quantize), int(ci.dither0), int(bool(ci.has_blank)), int(ci.blank),
+                  zs.ctypes.data if zs is not None else None, zz.ctypes.data if zz is not None else None,
+                  float(ci.zscale0), float(ci.zzero0), float(ci.bscale), float(ci.bzero))
+    return t, keep
+
+
+def decode_tiled_host(ci, out):
+    """Rice-decode a CompressedImage into `out` ([ny, nx] float32 for ZBITPIX = -32, else float64) on the host (the code
+    the GPU runs, a few threads over the tiles).  Returns the per-tile status (0 ok, 1 corrupt, 2 not Rice-coded)."""
+    t, keep = _fits_tiled(ci)
+    status = np.zeros(ci.n_tiles, dtype=np.int32)
+    rc = load_library().coreg_decode_tiled_host(C.byref(t), out.ctypes.data, COREG_F32 if out.dtype == np.float32 else COREG_F64,
+                                                status.ctypes.data)
+    if rc != COREG_OK:
+        raise CoregError(rc, "coreg_decode_tiled_host: bad arguments (unsupported tiling / codec parameters)")
+    del keep
+    return status
+
+
 def _is_raw(img):
     """utils.fits_io.RawImage (duck-typed: the binding does not import the FITS reader)."""
     return hasattr(img, "bitpix") and hasattr(img, "ptr")
@@ -93,6 +138,11 @@ SYMBOLS = [
      [_P, C.POINTER(FitsPixels), C.c_int32, C.c_int32, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
     ("coreg_prepare_reference_helioprojective_fits", C.c_int,
      [_P, C.POINTER(FitsPixels), C.c_int32, C.c_int32, _WP, _WP, C.c_int]),
+    ("coreg_set_small_tiled", C.c_int, [_P, C.POINTER(FitsTiled)]),
+    ("coreg_prepare_reference_carrington_tiled", C.c_int,
+     [_P, C.POINTER(FitsTiled), _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
+    ("coreg_prepare_reference_helioprojective_tiled", C.c_int, [_P, C.POINTER(FitsTiled), _WP, _WP, C.c_int]),
+    ("coreg_decode_tiled_host", C.c_int, [C.POINTER(FitsTiled), _P, C.c_int, _P]),
     ("coreg_threshold_small", C.c_int, [_P, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_longlong)]),
     ("coreg_set_reference_on_grid", C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32]),
     ("coreg_prepare_reference_carrington", C.c_int,
@@ -154,6 +204,10 @@ SYMBOLS = [
      [_P, C.POINTER(FitsPixels), C.c_int32, C.c_int32, _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
     ("coreg_multi_prepare_reference_helioprojective_fits", C.c_int,
      [_P, C.POINTER(FitsPixels), C.c_int32, C.c_int32, _WP, _WP, C.c_int]),
+    ("coreg_multi_set_small_tiled", C.c_int, [_P, C.POINTER(FitsTiled)]),
+    ("coreg_multi_prepare_reference_carrington_tiled", C.c_int,
+     [_P, C.POINTER(FitsTiled), _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
+    ("coreg_multi_prepare_reference_helioprojective_tiled", C.c_int, [_P, C.POINTER(FitsTiled), _WP, _WP, C.c_int]),
     ("coreg_multi_threshold_small", C.c_int, [_P, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_longlong)]),
     ("coreg_multi_set_reference_on_grid", C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32]),
     ("coreg_multi_prepare_reference_carrington", C.c_int,
@@ -349,6 +403,10 @@ class CoregHandle:
     def set_small(self, img):
         """Image to align.  A RawImage (utils/fits_io.py) goes up as the file stores it and is decoded on the GPU;
         float32 arrays (FITS BITPIX=-32 pixels) go up as they are; anything else as float64."""
+        if _is_tiled(img):  # a tile-compressed image: the compressed bytes go up, the GPU decodes them
+            t, keep = _fits_tiled(img)
+            self._chk(self._lib.coreg_set_small_tiled(self._h, C.byref(t)))
+            return
         if _is_raw(img):
             px = _fits_pixels(img)
             self._chk(self._lib.coreg_set_small_fits(self._h, C.byref(px), img.shape[0], img.shape[1]))
@@ -392,6 +450,11 @@ class CoregHandle:
     def prepare_reference_carrington(self, large, hdr_large, grid: Grid, solar_r, order=2):
         w = wcs_from_header(hdr_large, carrington=True)
         self.reference_tag = None
+        if _is_tiled(large):
+            t, keep = _fits_tiled(large)
+            self._chk(self._lib.coreg_prepare_reference_carrington_tiled(self._h, C.byref(t), C.byref(w), C.byref(grid.c),
+                                                                         float(solar_r), int(order)))
+            return
         if _is_raw(large):
             px = _fits_pixels(large)
             self._chk(self._lib.coreg_prepare_reference_carrington_fits(
@@ -406,6 +469,11 @@ class CoregHandle:
     def prepare_reference_helioprojective(self, large, hdr_large, hdr_small, order=2):
         wl, ws = wcs_from_header(hdr_large), wcs_from_header(hdr_small)
         self.reference_tag = None
+        if _is_tiled(large):
+            t, keep = _fits_tiled(large)
+            self._chk(self._lib.coreg_prepare_reference_helioprojective_tiled(self._h, C.byref(t), C.byref(wl), C.byref(ws),
+                                                                              int(order)))
+            return
         if _is_raw(large):
             px = _fits_pixels(large)
             self._chk(self._lib.coreg_prepare_reference_helioprojective_fits(
@@ -666,6 +734,10 @@ class MultiHandle:
         return np.ascontiguousarray(img, dtype=np.float64), COREG_F64
 
     def set_small(self, img):
+        if _is_tiled(img):
+            t, keep = _fits_tiled(img)
+            self._chk(self._lib.coreg_multi_set_small_tiled(self._m, C.byref(t)))
+            return
         if _is_raw(img):
             px = _fits_pixels(img)
             self._chk(self._lib.coreg_multi_set_small_fits(self._m, C.byref(px), img.shape[0], img.shape[1]))
@@ -690,6 +762,11 @@ class MultiHandle:
     def prepare_reference_carrington(self, large, hdr_large, grid: Grid, solar_r, order=2):
         w = wcs_from_header(hdr_large, carrington=True)
         self.reference_tag = None
+        if _is_tiled(large):
+            t, keep = _fits_tiled(large)
+            self._chk(self._lib.coreg_multi_prepare_reference_carrington_tiled(self._m, C.byref(t), C.byref(w),
+                                                                               C.byref(grid.c), float(solar_r), int(order)))
+            return
         if _is_raw(large):
             px = _fits_pixels(large)
             self._chk(self._lib.coreg_multi_prepare_reference_carrington_fits(
@@ -704,6 +781,11 @@ class MultiHandle:
     def prepare_reference_helioprojective(self, large, hdr_large, hdr_small, order=2):
         wl, ws = wcs_from_header(hdr_large), wcs_from_header(hdr_small)
         self.reference_tag = None
+        if _is_tiled(large):
+            t, keep = _fits_tiled(large)
+            self._chk(self._lib.coreg_multi_prepare_reference_helioprojective_tiled(self._m, C.byref(t), C.byref(wl),
+                                                                                    C.byref(ws), int(order)))
+            return
         if _is_raw(large):
             px = _fits_pixels(large)
             self._chk(self._lib.coreg_multi_prepare_reference_helioprojective_fits(

@@ -19,6 +19,7 @@
 #include "fit.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "ricecomp.hpp"
 
 using namespace coreg;
 
@@ -139,6 +140,8 @@ struct coreg_handle {
     DevBuf lane_params, out_index, partials, out_dev, tmp_img;
     DevBuf up_f64, up_flag;  // upload staging on the device (float64 copy, exactness flag)
     DevBuf up_raw;           // raw FITS elements awaiting their decode (BITPIX other than an unscaled -32)
+    DevBuf rice_blob, rice_rand, dec_img;  // tile-compressed images: heap + tile tables, cfitsio's random sequence, a
+                                           // decoded reference image (the image to align is decoded in place)
     PrologueArgs pending_prologue = {};  // set by upload_plan, consumed by the sweep's first k_precompute launch
     DevBuf bbox_buf;         // reference_crop: partial bounding boxes
     hipStream_t aux_stream = nullptr;  // side stream of reference_crop (created on first use)
@@ -450,6 +453,128 @@ int check_fits(coreg_handle* h, const coreg_fits_pixels* px, PixFmt* fmt) {
     fmt->bscale = px->bscale;
     fmt->bzero = px->bzero;
     return COREG_OK;
+}
+
+// ---- tile-compressed FITS images (csrc/ricecomp.hpp) -----------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_rice_tiles(const coregrice::TileImage t, int* status) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= t.n_tiles) return;
+    const int e = coregrice::decode_tile(t, n);  // one thread per tile: a tile's bit stream is sequential
+    if (e) atomicOr(status, e);
+}
+
+const char* check_tiled(const coreg_fits_tiled* t) {
+    if (!t || !t->heap || !t->tile_offset || !t->tile_nbytes) return "tiled image: null pointer";
+    if (t->heap_bytes < 1 || t->n_tiles < 1) return "tiled image: empty heap or no tiles";
+    if (t->naxis1 < 1 || t->naxis2 < 1 || t->ztile1 < 1 || t->ztile2 < 1) return "tiled image: bad image / tile shape";
+    const long long ntx = (t->naxis1 + t->ztile1 - 1) / t->ztile1, nty = (t->naxis2 + t->ztile2 - 1) / t->ztile2;
+    if (ntx * nty != t->n_tiles) return "tiled image: n_tiles does not match the tiling";
+    if (t->bytepix != 1 && t->bytepix != 2 && t->bytepix != 4) return "tiled image: BYTEPIX must be 1, 2 or 4";
+    if (t->blocksize < 1 || t->blocksize > 1024) return "tiled image: bad BLOCKSIZE";
+    const int b = t->zbitpix;
+    if (b != 8 && b != 16 && b != 32 && b != -32 && b != -64) return "tiled image: ZBITPIX must be 8, 16, 32, -32 or -64";
+    if (t->quantize < 0 || t->quantize > 3) return "tiled image: bad quantize method";
+    if ((b < 0) != (t->quantize != 0)) return "tiled image: quantize method and ZBITPIX disagree";
+    if (b < 0 && t->bytepix != 4) return "tiled image: quantized floats are 4-byte integers";
+    if (b > 0 && t->bytepix * 8 != b) return "tiled image: BYTEPIX and ZBITPIX disagree";
+    if ((t->zscale == nullptr) != (t->zzero == nullptr)) return "tiled image: ZSCALE / ZZERO must come together";
+    return nullptr;
+}
+
+void fill_tile_image(const coreg_fits_tiled& t, coregrice::TileImage* im) {
+    std::memset(im, 0, sizeof(*im));
+    im->naxis1 = t.naxis1;
+    im->naxis2 = t.naxis2;
+    im->ztile1 = t.ztile1;
+    im->ztile2 = t.ztile2;
+    im->bytepix = t.bytepix;
+    im->blocksize = t.blocksize;
+    im->zbitpix = t.zbitpix;
+    im->quantize = t.quantize;
+    im->dither0 = t.dither0;
+    im->has_blank = t.has_blank || t.zbitpix < 0;
+    im->blank = t.has_blank ? t.blank : coregrice::kNullValue;
+    im->scaled = (t.bscale != 1.0 || t.bzero != 0.0) ? 1 : 0;
+    im->bscale = t.bscale;
+    im->bzero = t.bzero;
+    im->zscale0 = t.zscale0;
+    im->zzero0 = t.zzero0;
+    im->heap_bytes = t.heap_bytes;
+    im->n_tiles = t.n_tiles;
+}
+
+// compressed bytes + tile tables up, one thread per tile decodes into `pix` (float32 for ZBITPIX = -32, else the float64
+// pixels go through the float32-exactness test of every float64 upload)
+int decode_tiled_device(coreg_handle* h, const coreg_fits_tiled* t, DevBuf& pix, bool* is_f32) {
+    if (const char* why = check_tiled(t)) return fail(h, COREG_EINVAL, why);
+    if (!std::isfinite(t->bscale) || !std::isfinite(t->bzero)) return fail(h, COREG_EINVAL, "tiled image: BSCALE / BZERO");
+    const size_t n = (size_t)t->naxis1 * t->naxis2, nt = (size_t)t->n_tiles;
+    for (size_t k = 0; k < nt; ++k)
+        if (t->tile_nbytes[k] <= 0)
+            return fail(h, COREG_ENOTIMPL, "tiled image: a tile is not Rice-coded (decode it on the host: "
+                                           "coreg_decode_tiled_host + the GZIP_COMPRESSED_DATA column)");
+    // blob layout: [heap][pad][tile_offset: int64 x nt][zscale: f64 x nt][zzero: f64 x nt][tile_nbytes: int32 x nt]
+    const size_t heap_pad = ((size_t)t->heap_bytes + 15) & ~(size_t)15;
+    const bool per_tile = t->zscale != nullptr;
+    const size_t tbl_bytes = nt * 8 + (per_tile ? nt * 16 : 0) + nt * 4;
+    HIPCHK(h->rice_blob.reserve(heap_pad + tbl_bytes));
+    char* blob = h->rice_blob.as<char>();
+    RETCHK(staged_upload(h, blob, t->heap, (size_t)t->heap_bytes));
+    std::vector<char> tbl(tbl_bytes);
+    size_t at = 0;
+    std::memcpy(tbl.data() + at, t->tile_offset, nt * 8);
+    at += nt * 8;
+    if (per_tile) {
+        std::memcpy(tbl.data() + at, t->zscale, nt * 8);
+        at += nt * 8;
+        std::memcpy(tbl.data() + at, t->zzero, nt * 8);
+        at += nt * 8;
+    }
+    std::memcpy(tbl.data() + at, t->tile_nbytes, nt * 4);
+    RETCHK(staged_upload(h, blob + heap_pad, tbl.data(), tbl_bytes));  // (copied into pinned staging before returning)
+    if (!h->rice_rand.p) {
+        std::vector<float> r(coregrice::kNRandom);
+        coregrice::init_randoms(r.data());
+        HIPCHK(h->rice_rand.reserve(r.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(h->rice_rand.p, r.data(), r.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    coregrice::TileImage im;
+    fill_tile_image(*t, &im);
+    im.heap = (const unsigned char*)blob;
+    at = heap_pad;
+    im.tile_offset = (const int64_t*)(blob + at);
+    at += nt * 8;
+    if (per_tile) {
+        im.zscale = (const double*)(blob + at);
+        at += nt * 8;
+        im.zzero = (const double*)(blob + at);
+        at += nt * 8;
+    }
+    im.tile_nbytes = (const int32_t*)(blob + at);
+    im.randoms = h->rice_rand.as<float>();
+    const bool direct_f32 = t->zbitpix == -32;
+    if (direct_f32) {
+        HIPCHK(pix.reserve(n * sizeof(float)));
+        im.out = pix.p;
+        im.out_dtype = coregrice::OUT_F32;
+    } else {
+        HIPCHK(h->up_f64.reserve(n * sizeof(double)));
+        im.out = h->up_f64.p;
+        im.out_dtype = coregrice::OUT_F64;
+    }
+    HIPCHK(h->up_flag.reserve(sizeof(int)));
+    HIPCHK(hipMemsetAsync(h->up_flag.p, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_rice_tiles, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, im, h->up_flag.as<int>());
+    HIPCHK(hipGetLastError());
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, h->up_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (flag) return fail(h, COREG_EINVAL, "tiled image: a Rice stream is truncated or corrupt");
+    if (direct_f32) {
+        *is_f32 = true;
+        return COREG_OK;
+    }
+    return upload_image(h, h->up_f64.as<double>(), n, pix, is_f32, SRC_DEVICE);
 }
 
 int upload_carr_tables(coreg_handle* h, const coreg_carr_grid& g, const coreg_wcs2d& hdr, CarrDev* dev) {
@@ -1446,7 +1571,7 @@ void coreg_destroy(coreg_handle* h) {
     DevBuf* bufs[] = {&h->small, &h->ref, &h->pivots, &h->red_sum, &h->red_cnt, &h->t_sin_lon, &h->t_cos_lon,
                       &h->t_cos_lat, &h->t_sin_lat, &h->pts, &h->tile_count, &h->tile_list, &h->tile_cum, &h->group_first,
                       &h->tile_info, &h->tile_bbox, &h->counters, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
-                      &h->tmp_img, &h->up_f64, &h->up_flag, &h->up_raw, &h->border_dev, &h->sums, &h->fin_outidx, &h->border_flags, &h->fix_partial};
+                      &h->tmp_img, &h->up_f64, &h->up_flag, &h->up_raw, &h->rice_blob, &h->rice_rand, &h->dec_img, &h->border_dev, &h->sums, &h->fin_outidx, &h->border_flags, &h->fix_partial};
     for (DevBuf* b : bufs) b->release();
     for (int k = 0; k < 2; ++k) {
         h->pin_img[k].release();
@@ -1637,6 +1762,57 @@ static int set_small_fits(coreg_handle* h, const coreg_fits_pixels* px, int32_t 
 
 int coreg_set_small_fits(coreg_handle* h, const coreg_fits_pixels* px, int32_t ny, int32_t nx) {
     return set_small_fits(h, px, ny, nx, SRC_HOST);
+}
+
+int coreg_set_small_tiled(coreg_handle* h, const coreg_fits_tiled* t) {
+    if (!h) return COREG_EINVAL;
+    RETCHK(bind_device(h));
+    RETCHK(decode_tiled_device(h, t, h->small, &h->small_f32));
+    h->sW = t->naxis1;
+    h->sH = t->naxis2;
+    const long long n = (long long)h->sW * h->sH;
+    if (h->small_f32) return device_mean<float>(h, h->small.as<float>(), n, h->pivots.as<double>() + 1);
+    return device_mean<double>(h, h->small.as<double>(), n, h->pivots.as<double>() + 1);
+}
+
+int coreg_decode_tiled_host(const coreg_fits_tiled* t, void* out, int dtype, int32_t* tile_status) {
+    if (check_tiled(t) || !out || (dtype != COREG_F32 && dtype != COREG_F64)) return COREG_EINVAL;
+    if (dtype == COREG_F32 && t->zbitpix != -32) return COREG_EINVAL;
+    static const std::vector<float> randoms = [] {
+        std::vector<float> r(coregrice::kNRandom);
+        coregrice::init_randoms(r.data());
+        return r;
+    }();
+    coregrice::TileImage im;
+    fill_tile_image(*t, &im);
+    im.heap = (const unsigned char*)t->heap;
+    im.tile_offset = t->tile_offset;
+    im.tile_nbytes = t->tile_nbytes;
+    im.zscale = t->zscale;
+    im.zzero = t->zzero;
+    im.randoms = randoms.data();
+    im.out = out;
+    im.out_dtype = dtype == COREG_F32 ? coregrice::OUT_F32 : coregrice::OUT_F64;
+    const int nt = t->n_tiles;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int n_thr = (int)std::min<long long>(std::min<unsigned>(hw, 12u),
+                                               std::max<long long>(1, (long long)t->naxis1 * t->naxis2 / (1 << 16)));
+    auto work = [&](int lo, int hi) {
+        for (int k = lo; k < hi; ++k) {
+            const int e = coregrice::decode_tile(im, k);
+            if (tile_status) tile_status[k] = e;
+        }
+    };
+    if (n_thr <= 1) {
+        work(0, nt);
+        return COREG_OK;
+    }
+    std::vector<std::thread> th;
+    const int per = (nt + n_thr - 1) / n_thr;
+    for (int k = 1; k < n_thr; ++k) th.emplace_back(work, std::min(nt, k * per), std::min(nt, (k + 1) * per));
+    work(0, std::min(nt, per));
+    for (auto& x : th) x.join();
+    return COREG_OK;
 }
 
 int coreg_threshold_small(coreg_handle* h, int has_min, double vmin, int has_max, double vmax, long long* n_finite) {
@@ -1936,6 +2112,26 @@ int coreg_prepare_reference_helioprojective_fits(coreg_handle* h, const coreg_fi
     PixFmt fmt;
     RETCHK(check_fits(h, px, &fmt));
     return prepare_helioprojective(h, px->data, fmt, ny, nx, hdr_large, hdr_small, order);
+}
+
+int coreg_prepare_reference_carrington_tiled(coreg_handle* h, const coreg_fits_tiled* t, const coreg_wcs2d* hdr_large,
+                                             const coreg_carr_grid* grid, double solar_r, int order) {
+    if (!h) return COREG_EINVAL;
+    RETCHK(bind_device(h));
+    bool f32;
+    RETCHK(decode_tiled_device(h, t, h->dec_img, &f32));  // the compressed bytes cross PCIe, the pixels never do
+    return prepare_carrington(h, h->dec_img.p, PixFmt::native(f32), t->naxis2, t->naxis1, hdr_large, grid, solar_r, order,
+                              SRC_DEVICE);
+}
+
+int coreg_prepare_reference_helioprojective_tiled(coreg_handle* h, const coreg_fits_tiled* t, const coreg_wcs2d* hdr_large,
+                                                  const coreg_wcs2d* hdr_small, int order) {
+    if (!h) return COREG_EINVAL;
+    RETCHK(bind_device(h));
+    bool f32;
+    RETCHK(decode_tiled_device(h, t, h->dec_img, &f32));
+    return prepare_helioprojective(h, h->dec_img.p, PixFmt::native(f32), t->naxis2, t->naxis1, hdr_large, hdr_small, order,
+                                   SRC_DEVICE);
 }
 
 int coreg_get_reference_on_grid(coreg_handle* h, void* out, int dtype) {

@@ -893,6 +893,30 @@ int coreg_multi_prepare_reference_helioprojective_fits(coreg_multi* m, const cor
     });
 }
 
+// ... and as a tile-compressed image (every device uploads the compressed bytes itself -- a quarter of the pixels -- and
+// decodes them)
+int coreg_multi_set_small_tiled(coreg_multi* m, const coreg_fits_tiled* t) {
+    if (!m) return COREG_EINVAL;
+    return multi_run(m, [&](int k) { return coreg_set_small_tiled(m->h[k], t); });
+}
+
+int coreg_multi_prepare_reference_carrington_tiled(coreg_multi* m, const coreg_fits_tiled* t, const coreg_wcs2d* hdr_large,
+                                                   const coreg_carr_grid* grid, double solar_r, int order) {
+    if (!m) return COREG_EINVAL;
+    return multi_run(m, [&](int k) {
+        return coreg_prepare_reference_carrington_tiled(m->h[k], t, hdr_large, grid, solar_r, order);
+    });
+}
+
+int coreg_multi_prepare_reference_helioprojective_tiled(coreg_multi* m, const coreg_fits_tiled* t,
+                                                        const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small,
+                                                        int order) {
+    if (!m) return COREG_EINVAL;
+    return multi_run(m, [&](int k) {
+        return coreg_prepare_reference_helioprojective_tiled(m->h[k], t, hdr_large, hdr_small, order);
+    });
+}
+
 int coreg_multi_sweep_carrington(coreg_multi* m, const coreg_wcs2d* hdr_small, const coreg_carr_grid* grid, double solar_r,
                                  const coreg_lags* lags, int order, int method, int cdelt_semantics, double* corr_out) {
     return multi_sweep(m, lags, corr_out, true, [&](int k, const coreg_lags* l, int64_t lo, int64_t hi, double* out_dev) {

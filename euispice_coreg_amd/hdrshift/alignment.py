@@ -95,9 +95,10 @@ class Alignment:
             # to the GPU as the file stores them (fits_io.RawImage; byte swap, BSCALE / BZERO and the float conversion
             # of alignment.py:198 / :314 run there).  Anything else (in-memory pairs, compressed images, URLs with
             # astropy) is read and decoded as before.
-            raw = fits_io.open_raw(self.small_fov_to_correct, self.small_fov_window) if self.raw_fits_upload else None
-            ds, hs = (raw, raw.header) if raw is not None else fits_io.read_image(self.small_fov_to_correct,
-                                                                                  self.small_fov_window)
+            # A tile-compressed image (EUI level-1 / level-2 files) likewise: its COMPRESSED bytes go up and the GPU
+            # decodes them (fits_io.CompressedImage; cfitsio's RICE_1 codec restated, csrc/ricecomp.hpp).
+            ds, hs = (fits_io.load_for_upload if self.raw_fits_upload else fits_io.read_image)(
+                self.small_fov_to_correct, self.small_fov_window)
         # float32 (BITPIX=-32) pixels stay float32: the float64 cast of alignment.py:198 / :314 is exact
         self.data_small = fits_io.native_pixels(ds)
         self.hdr_small = fits_io.Header(hs)
@@ -106,8 +107,8 @@ class Alignment:
 
     def _large_pixels(self):
         if self.data_large is None:
-            raw = fits_io.open_raw(self.large_fov_known_pointing, self.large_fov_window) if self.raw_fits_upload else None
-            dl = raw if raw is not None else fits_io.read_image(self.large_fov_known_pointing, self.large_fov_window)[0]
+            dl = (fits_io.load_for_upload if self.raw_fits_upload else fits_io.read_image)(
+                self.large_fov_known_pointing, self.large_fov_window)[0]
             # alignment.py:191 / :301 cast to float64; float32 pixels (BITPIX=-32) are kept as they are -- the cast is
             # exact and the library does it on the GPU, half the bytes cross PCIe; a memory-mapped data unit (RawImage)
             # goes up as stored, and only the rectangle the target grid can touch
@@ -315,7 +316,7 @@ class Alignment:
         spread = world > 1
 
         def upload_small(data):
-            if spread and isinstance(data, fits_io.RawImage):
+            if spread and isinstance(data, (fits_io.RawImage, fits_io.CompressedImage)):
                 data = fits_io.native_pixels(data.decode())  # row shares + all-gather work on decoded pixels
             t = parallel.replicate_image(data) if spread and np.asarray(data).dtype in (np.float32, np.float64) else None
             if t is None:

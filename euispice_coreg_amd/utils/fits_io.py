@@ -215,6 +215,236 @@ def open_raw(path, window=-1):
     return RawImage(os.fspath(path), pos, nbytes, shape, hdr)
 
 
+# ---- tile-compressed images (the image lives in a binary table: what EUI level-1 / level-2 files hold) ----------------
+_TFORM_BYTES = {"L": 1, "X": 1, "B": 1, "I": 2, "J": 4, "K": 8, "A": 1, "E": 4, "D": 8, "C": 8, "M": 16, "P": 8, "Q": 16}
+# keywords of the table / of the compression convention that do not belong to the image header astropy presents
+_TABLE_ONLY = ("XTENSION", "BITPIX", "NAXIS", "NAXIS1", "NAXIS2", "PCOUNT", "GCOUNT", "TFIELDS", "THEAP", "ZIMAGE",
+               "ZTENSION", "ZBITPIX", "ZNAXIS", "ZPCOUNT", "ZGCOUNT", "ZCMPTYPE", "ZQUANTIZ", "ZDITHER0", "ZBLANK", "ZSCALE",
+               "ZZERO", "ZSIMPLE", "ZEXTEND", "ZBLOCKED", "ZHECKSUM", "ZDATASUM", "CHECKSUM", "DATASUM")
+_QUANTIZE = {"NO_DITHER": 1, "SUBTRACTIVE_DITHER_1": 2, "SUBTRACTIVE_DITHER_2": 3}
+
+
+def _image_header_of_table(th):
+    """The header of the IMAGE a compressed-image table stands for (as astropy's CompImageHDU.header presents it): the
+    Z-keywords give BITPIX / NAXISn back, table and compression keywords go."""
+    h = Header()
+    h["BITPIX"] = int(th["ZBITPIX"])
+    naxis = int(th["ZNAXIS"])
+    h["NAXIS"] = naxis
+    for i in range(naxis):
+        h["NAXIS%d" % (i + 1)] = int(th["ZNAXIS%d" % (i + 1)])
+    for k, v in th.items():
+        if k in _TABLE_ONLY or k in h:
+            continue
+        if any(k.startswith(p) and k[len(p):].isdigit() for p in ("TTYPE", "TFORM", "TUNIT", "TDIM", "TNULL", "TSCAL",
+                                                                  "TZERO", "TDISP", "ZNAXIS", "ZTILE", "ZNAME", "ZVAL")):
+            continue
+        h[k] = v
+    return h
+
+
+class CompressedImage:
+    """One tile-compressed image HDU, NOT decompressed: the table's heap memory-mapped, the per-tile descriptors and
+    scale / zero columns parsed, the compression parameters read.  The library uploads the COMPRESSED bytes and decodes
+    them on the GPU (`coreg_set_small_tiled`, `coreg_prepare_reference_*_tiled`: cfitsio's RICE_1 codec and float
+    dequantization restated, csrc/ricecomp.hpp).  `np.asarray(ci)` / `ci.decode()` decode on the host through the same
+    code (plus zlib for tiles cfitsio stored gzipped, and for GZIP_1 / GZIP_2 images) -- no astropy involved."""
+
+    ndim = 2
+
+    def __init__(self, path, data_pos, table_hdr):
+        th = table_hdr
+        self.path, self.table_header = path, th
+        self.header = _image_header_of_table(th)
+        if int(th["ZNAXIS"]) != 2:
+            raise NotImplementedError("tile-compressed images of dimension other than 2")
+        self.zbitpix = int(th["ZBITPIX"])
+        self.shape = (int(th["ZNAXIS2"]), int(th["ZNAXIS1"]))
+        self.ztile = (int(th.get("ZTILE1", self.shape[1])), int(th.get("ZTILE2", 1)))
+        self.cmptype = str(th["ZCMPTYPE"]).strip()
+        params = {str(th["ZNAME%d" % i]).strip(): th["ZVAL%d" % i] for i in range(1, 20) if "ZNAME%d" % i in th}
+        self.blocksize = int(params.get("BLOCKSIZE", 32))
+        self.bytepix = int(params.get("BYTEPIX", 4))
+        q = str(th.get("ZQUANTIZ", "NO_DITHER")).strip()
+        if self.zbitpix < 0 and q == "NONE":
+            self.quantize = 0  # lossless floats (GZIP only)
+        elif self.zbitpix < 0:
+            if q not in _QUANTIZE:
+                raise NotImplementedError(f"ZQUANTIZ = {q!r}")
+            self.quantize = _QUANTIZE[q]
+        else:
+            self.quantize = 0
+        self.dither0 = int(th.get("ZDITHER0", 1))
+        self.bscale, self.bzero = th.get("BSCALE", 1), th.get("BZERO", 0)
+        # ---- the table: rows of fixed-size fields, variable-length arrays in the heap
+        row_bytes, n_rows = int(th["NAXIS1"]), int(th["NAXIS2"])
+        ntx = -(-self.shape[1] // self.ztile[0])
+        nty = -(-self.shape[0] // self.ztile[1])
+        if n_rows != ntx * nty:
+            raise ValueError("compressed image: the table does not hold one row per tile")
+        cols, off = {}, 0
+        for i in range(1, int(th["TFIELDS"]) + 1):
+            form = str(th["TFORM%d" % i]).strip()
+            j = 0
+            while j < len(form) and form[j].isdigit():
+                j += 1
+            rep, code = (int(form[:j]) if j else 1), form[j]
+            if code not in _TFORM_BYTES:
+                raise NotImplementedError(f"TFORM{i} = {form!r}")
+            size = rep * _TFORM_BYTES[code] if code != "X" else (rep + 7) // 8
+            cols[str(th["TTYPE%d" % i]).strip()] = (off, code, rep)
+            off += size
+        if off != row_bytes:
+            raise ValueError("compressed image: TFORMn do not add up to NAXIS1")
+        heap_off = int(th.get("THEAP", row_bytes * n_rows))
+        heap_bytes = int(th.get("PCOUNT", 0)) - (heap_off - row_bytes * n_rows)
+        total = heap_off + max(heap_bytes, 0)
+        gran = mmap.ALLOCATIONGRANULARITY
+        start = (data_pos // gran) * gran
+        with open(path, "rb") as f:
+            self._mm = mmap.mmap(f.fileno(), total + (data_pos - start), flags=mmap.MAP_SHARED | getattr(mmap, "MAP_POPULATE", 0),
+                                 prot=mmap.PROT_READ, offset=start)
+        base = data_pos - start
+        rows = np.frombuffer(self._mm, dtype=np.uint8, count=row_bytes * n_rows, offset=base).reshape(n_rows, row_bytes)
+        self._heap = np.frombuffer(self._mm, dtype=np.uint8, count=max(heap_bytes, 0), offset=base + heap_off)
+        self.n_tiles = n_rows
+
+        def descriptors(name):
+            if name not in cols:
+                return None, None
+            o, code, _ = cols[name]
+            if code == "P":
+                d = np.ascontiguousarray(rows[:, o:o + 8]).view(">i4").reshape(n_rows, 2)
+            elif code == "Q":
+                d = np.ascontiguousarray(rows[:, o:o + 16]).view(">i8").reshape(n_rows, 2)
+            else:
+                raise ValueError(f"column {name}: not a variable-length array")
+            return d[:, 0].astype(np.int32), d[:, 1].astype(np.int64)
+
+        def scalars(name, kw_default):
+            if name in cols:
+                o, code, _ = cols[name]
+                dt = {"D": ">f8", "E": ">f4", "J": ">i4", "I": ">i2", "K": ">i8", "B": "u1"}[code]
+                w = np.dtype(dt).itemsize
+                return np.ascontiguousarray(rows[:, o:o + w]).view(dt).reshape(n_rows).astype(np.float64 if code in "DE" else np.int64)
+            return kw_default
+
+        self.tile_nbytes, self.tile_offset = descriptors("COMPRESSED_DATA")
+        if self.tile_nbytes is None:
+            raise ValueError("compressed image: no COMPRESSED_DATA column")
+        self.gzip_nbytes, self.gzip_offset = descriptors("GZIP_COMPRESSED_DATA")
+        if "UNCOMPRESSED_DATA" in cols and descriptors("UNCOMPRESSED_DATA")[0].any():
+            raise NotImplementedError("compressed image with tiles in UNCOMPRESSED_DATA")
+        self.zscale = scalars("ZSCALE", None)
+        self.zzero = scalars("ZZERO", None)
+        self.zscale0, self.zzero0 = float(th.get("ZSCALE", 1.0)), float(th.get("ZZERO", 0.0))
+        if self.zbitpix < 0 and self.zscale is None and "ZSCALE" not in th:
+            self.quantize = 0  # no scale anywhere: the tiles hold the floating-point values themselves (lossless GZIP)
+        blank = scalars("ZBLANK", None)
+        if blank is not None:
+            if len(np.unique(blank)) > 1:
+                raise NotImplementedError("compressed image with a per-tile ZBLANK column")
+            self.has_blank, self.blank = True, int(blank[0])
+        elif "ZBLANK" in th:
+            self.has_blank, self.blank = True, int(th["ZBLANK"])
+        elif "BLANK" in th and self.zbitpix > 0:
+            self.has_blank, self.blank = True, int(th["BLANK"])
+        else:
+            self.has_blank, self.blank = False, 0
+
+    # ---- what the library needs
+    @property
+    def on_gpu(self):
+        """Decodable on the GPU as it is: RICE_1, every tile Rice-coded, float images quantized."""
+        return (self.cmptype == "RICE_1" and bool((self.tile_nbytes > 0).all()) and self.bytepix in (1, 2, 4)
+                and (self.zbitpix > 0 or self.quantize > 0) and self.zbitpix in (8, 16, 32, -32, -64))
+
+    @property
+    def dtype(self):
+        if self.zbitpix == -32:
+            return np.dtype(np.float32)
+        if self.zbitpix == -64 or self.bscale != 1 or self.bzero != 0:
+            return np.dtype(np.float64)
+        return np.dtype({8: np.uint8, 16: np.int16, 32: np.int32}[self.zbitpix])
+
+    def decode(self):
+        """The pixels, as `read_image` returns them for a plain image of the same BITPIX (integers with BSCALE / BZERO:
+        float64(stored) * BSCALE + BZERO)."""
+        from .. import _lib
+        ny, nx = self.shape
+        if self.cmptype == "RICE_1":
+            out = np.empty(self.shape, dtype=np.float32 if self.zbitpix == -32 else np.float64)
+            status = _lib.decode_tiled_host(self, out)
+            if (status == 1).any():
+                raise IOError(f"{self.path}: corrupt Rice stream in tile(s) {np.flatnonzero(status == 1)[:5].tolist()}")
+            for n in np.flatnonzero(status == 2):  # tiles cfitsio could not quantize: gzipped floats in the other column
+                self._place(out, n, self._gunzip_tile(n, self.gzip_offset, self.gzip_nbytes, shuffled=False))
+        elif self.cmptype in ("GZIP_1", "GZIP_2"):
+            out = np.empty(self.shape, dtype=np.float32 if self.zbitpix == -32 else np.float64)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(12, os.cpu_count() or 1)) as pool:  # (zlib releases the GIL)
+                tiles = list(pool.map(lambda n: self._gunzip_tile(n, self.tile_offset, self.tile_nbytes,
+                                                                  shuffled=self.cmptype == "GZIP_2"), range(self.n_tiles)))
+            for n, t in enumerate(tiles):
+                self._place(out, n, t)
+        else:
+            raise NotImplementedError(f"ZCMPTYPE = {self.cmptype!r} (RICE_1, GZIP_1 and GZIP_2 are read)")
+        if self.zbitpix > 0 and self.bscale == 1 and self.bzero == 0:
+            return out.astype(self.dtype)
+        return out
+
+    def _tile_box(self, n):
+        ntx = -(-self.shape[1] // self.ztile[0])
+        ty, tx = divmod(n, ntx)
+        x0, y0 = tx * self.ztile[0], ty * self.ztile[1]
+        return x0, y0, min(self.ztile[0], self.shape[1] - x0), min(self.ztile[1], self.shape[0] - y0)
+
+    def _gunzip_tile(self, n, offsets, lengths, shuffled):
+        import zlib
+        x0, y0, tw, th = self._tile_box(n)
+        raw = zlib.decompress(bytes(self._heap[int(offsets[n]):int(offsets[n]) + int(lengths[n])]), 31)
+        if self.zbitpix < 0 and self.quantize > 0 and lengths is self.tile_nbytes:
+            # (a QUANTIZED float image whose integers are gzipped instead of Rice-coded)
+            raise NotImplementedError("GZIP-compressed quantized float images")
+        dt = np.dtype(_BITPIX_DTYPE[self.zbitpix])
+        if shuffled:
+            raw = np.frombuffer(raw, dtype=np.uint8).reshape(dt.itemsize, tw * th).T.tobytes()
+        a = np.frombuffer(raw, dtype=dt, count=tw * th).reshape(th, tw)
+        if self.zbitpix > 0 and (self.bscale != 1 or self.bzero != 0):
+            return a.astype(np.float64) * self.bscale + self.bzero
+        return a
+
+    def _place(self, out, n, tile):
+        x0, y0, tw, th = self._tile_box(n)
+        out[y0:y0 + th, x0:x0 + tw] = tile
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.decode()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def close(self):
+        self._heap = None
+        try:
+            self._mm.close()
+        except (BufferError, ValueError):
+            pass
+
+
+def open_compressed(path, window=-1):
+    """CompressedImage of a tile-compressed image HDU of a local file, or None when `path` / `window` do not name one."""
+    if not isinstance(path, (str, os.PathLike)) or not os.path.isfile(path):
+        return None
+    try:
+        hdus, spans = _scan(path)
+        i = _select([(h, None) for h in hdus], window)
+    except (IOError, KeyError, IndexError, ValueError):
+        return None
+    hdr = hdus[i]
+    if not (str(hdr.get("XTENSION", "")).strip() == "BINTABLE" and hdr.get("ZIMAGE") is True and spans[i] is not None):
+        return None
+    return CompressedImage(os.fspath(path), spans[i][0], hdr)
+
+
 def open_cube(path, window=-1):
     """(array, header) of an image HDU of any dimension WITHOUT reading or decoding it: a read-only big-endian view of
     the memory-mapped data unit (NumPy converts what is actually touched, plane by plane, when it is used).  For the
@@ -252,6 +482,9 @@ def load_for_upload(path, window=-1):
     raw = open_raw(path, window)
     if raw is not None:
         return raw, raw.header
+    comp = open_compressed(path, window)
+    if comp is not None:
+        return comp, comp.header
     return read_image(path, window)
 
 
@@ -273,7 +506,7 @@ def _scan(path):
 def native_pixels(a):
     """Pixels as the sweep takes them: float32 data (BITPIX=-32, either byte order) as native float32, everything else as
     float64 (the reference's own cast, alignment.py:191 / :198 / :301 / :314; exact for float32)."""
-    if isinstance(a, RawImage):
+    if isinstance(a, (RawImage, CompressedImage)):
         return a  # uploaded as stored, decoded on the GPU
     a = np.asarray(a)
     if a.dtype.kind == "f" and a.dtype.itemsize == 4:
@@ -281,45 +514,62 @@ def native_pixels(a):
     return np.array(a, dtype=np.float64)
 
 
+def _astropy_fits():
+    try:
+        import astropy.io.fits as afits  # optional: remote URLs, codecs this module does not read
+        return afits
+    except ImportError:
+        return None
+
+
 def read_image(path, window=-1):
-    """(data, header) of one HDU.  `path` may also be a (data, header) pair already in memory."""
+    """(data, header) of one HDU.  `path` may also be a (data, header) pair already in memory.  Local files are read by
+    this module -- plain images and tile-compressed ones (RICE_1, GZIP_1, GZIP_2: `CompressedImage`, pinned bit for bit
+    against astropy / cfitsio) -- astropy, when installed, serves what is left (URLs, other codecs)."""
     if isinstance(path, (tuple, list)) and len(path) == 2:
         return np.asarray(path[0]), Header(path[1])
-    try:
-        import astropy.io.fits as afits  # optional: compressed images, remote URLs
-    except ImportError:
-        afits = None
-    if afits is not None:
-        with afits.open(path) as hl:
-            hdu = hl[window]
-            return np.array(hdu.data), Header({k: hdu.header[k] for k in hdu.header.keys() if k})
-    if not os.path.exists(str(path)):
+    afits = _astropy_fits()
+    if os.path.exists(str(path)):
+        try:
+            comp = open_compressed(path, window)
+            if comp is not None:
+                return comp.decode(), comp.header
+            hdus = _read_all(path, only=window)
+            hdr, data = hdus[_select(hdus, window)]
+            if data is not None:
+                return data, hdr
+        except NotImplementedError:
+            if afits is None:
+                raise
+            hdr, data = None, None
+        if afits is None:
+            if "ZIMAGE" in hdr or str(hdr.get("XTENSION", "")).strip() == "BINTABLE":
+                raise NotImplementedError("this table HDU is not an image this reader knows (astropy.io.fits is not installed)")
+            raise ValueError(f"HDU {window!r} of {path} holds no image")
+    elif afits is None:
         raise FileNotFoundError(path)
-    hdus = _read_all(path, only=window)
-    hdr, data = hdus[_select(hdus, window)]
-    if data is None:
-        if "ZIMAGE" in hdr or str(hdr.get("XTENSION", "")).strip() == "BINTABLE":
-            raise NotImplementedError("tile-compressed FITS images need astropy.io.fits (not installed)")
-        raise ValueError(f"HDU {window!r} of {path} holds no image")
-    return data, hdr
+    with afits.open(path) as hl:
+        hdu = hl[window]
+        return np.array(hdu.data), Header({k: hdu.header[k] for k in hdu.header.keys() if k})
 
 
 def read_header(path, window=-1):
-    """Header of one HDU without decoding any pixel data."""
+    """Header of one HDU without decoding any pixel data (a tile-compressed image: the header of the image, as astropy
+    presents it, not of the table that holds it)."""
     if isinstance(path, (tuple, list)) and len(path) == 2:
         return Header(path[1])
-    try:
-        import astropy.io.fits as afits
-    except ImportError:
-        afits = None
-    if afits is not None:
-        with afits.open(path) as hl:
-            hdu = hl[window]
-            return Header({k: hdu.header[k] for k in hdu.header.keys() if k})
-    if not os.path.exists(str(path)):
+    if os.path.exists(str(path)):
+        hdus = _read_all(path, with_data=False)
+        hdr = hdus[_select(hdus, window)][0]
+        if str(hdr.get("XTENSION", "")).strip() == "BINTABLE" and hdr.get("ZIMAGE") is True:
+            return _image_header_of_table(hdr)
+        return hdr
+    afits = _astropy_fits()
+    if afits is None:
         raise FileNotFoundError(path)
-    hdus = _read_all(path, with_data=False)
-    return hdus[_select(hdus, window)][0]
+    with afits.open(path) as hl:
+        hdu = hl[window]
+        return Header({k: hdu.header[k] for k in hdu.header.keys() if k})
 
 
 def file_identity(path, window=-1):
@@ -414,6 +664,22 @@ def _copy_range(fi, fo, pos, n):
             left -= len(chunk)
 
 
+def _patch_header(raw, updates):
+    """The header blocks `raw` (bytes, END card included) with the cards of `updates` (key -> value) replaced in place,
+    new keys inserted before END; every other card -- comments, table structure, compression keywords -- untouched."""
+    cards = [raw[i:i + 80] for i in range(0, len(raw), 80)]
+    end = next(i for i, c in enumerate(cards) if c[:8].rstrip() == b"END")
+    cards = cards[:end]
+    left = dict(updates)
+    for i, c in enumerate(cards):
+        key = c[:8].decode("ascii", "replace").strip()
+        if key in left and c[8:10] == b"= ":
+            cards[i] = _card(key, left.pop(key)).encode("ascii")
+    cards += [_card(k, v).encode("ascii") for k, v in left.items()]
+    blob = b"".join(cards) + b"END".ljust(80)
+    return blob + b" " * ((-len(blob)) % BLOCK)
+
+
 def rewrite_with_corrected_headers(path_in, path_out, is_selected, correct):
     """`write_corrected_fits` without touching pixels (utils/Util.py:106-159: every HDU is copied, the selected windows
     get corrected pointing keywords and float32 data).  HDUs that are not selected are copied byte for byte, header
@@ -429,26 +695,39 @@ def rewrite_with_corrected_headers(path_in, path_out, is_selected, correct):
         spans = []
         while True:
             start = fi.tell()
-            hdr, _ = _read_header(fi)
+            hdr, raw_hdr = _read_header(fi)
             if hdr is None:
                 break
             nbytes, shape = _data_size(hdr)
             data_pos = fi.tell()
             padded = ((nbytes + BLOCK - 1) // BLOCK) * BLOCK
             fi.seek(padded, os.SEEK_CUR)
-            spans.append((hdr, start, data_pos, nbytes, padded, shape))
+            spans.append((hdr, start, data_pos, nbytes, padded, shape, raw_hdr))
         size = os.fstat(fi.fileno()).st_size
         with open(path_out, "wb") as fo:
-            for i, (hdr, start, data_pos, nbytes, padded, shape) in enumerate(spans):
+            for i, (hdr, start, data_pos, nbytes, padded, shape, raw_hdr) in enumerate(spans):
                 if not is_selected(i, len(spans), hdr):
                     _copy_range(fi, fo, start, min(data_pos + padded, size) - start)
                     continue
                 n_corrected += 1
+                before = hdr
                 hdr = hdr.copy()
                 correct(hdr)
                 is_image = hdr.get("SIMPLE") is not None or str(hdr.get("XTENSION", "")).strip() == "IMAGE"
-                if "ZIMAGE" in hdr or not is_image:
-                    raise NotImplementedError("tile-compressed FITS images need astropy.io.fits (not installed)")
+                if str(hdr.get("XTENSION", "")).strip() == "BINTABLE" and hdr.get("ZIMAGE") is True:
+                    # a tile-compressed image (EUI files): the corrected keywords are patched into the table's header,
+                    # the table and its heap -- the compressed pixels -- are copied as they are.  (The reference
+                    # decompresses, casts to float32 and compresses again, utils/Util.py:137-138; keeping the original
+                    # compressed stream keeps the original pixels.)
+                    changed = {k: v for k, v in hdr.items() if k not in before or before[k] != v or
+                               type(before[k]) is not type(v)}
+                    fo.write(_patch_header(raw_hdr, changed))
+                    _copy_range(fi, fo, data_pos, min(padded, size - data_pos))
+                    if data_pos + padded > size:
+                        fo.write(b"\0" * (data_pos + padded - size))
+                    continue
+                if not is_image:
+                    raise NotImplementedError("only image HDUs (plain or tile-compressed) can be corrected")
                 f32 = int(hdr["BITPIX"]) == -32 and hdr.get("BSCALE", 1) == 1 and hdr.get("BZERO", 0) == 0
                 if nbytes == 0:
                     fo.write(_header_blob(i, 8, (), hdr))

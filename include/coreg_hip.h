@@ -141,6 +141,51 @@ int coreg_prepare_reference_carrington_fits(coreg_handle* h, const coreg_fits_pi
 int coreg_prepare_reference_helioprojective_fits(coreg_handle* h, const coreg_fits_pixels* px, int32_t ny, int32_t nx,
                                                  const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order);
 
+/* Tile-compressed FITS images (the image lives in a binary table, one row per tile, the compressed bytes in the
+ * table's heap): what EUI level-1 / level-2 files hold and the reference reads through astropy's CompImageHDU
+ * (alignment.py:191-208, :299-314).  The COMPRESSED bytes cross PCIe and are decoded on the GPU, one thread per tile
+ * (csrc/ricecomp.hpp: cfitsio's RICE_1 codec and float dequantization restated; pinned bit for bit against astropy /
+ * cfitsio output, tests/golden/compressed_golden.npz).  The caller parses the table (utils/fits_io.py: open_compressed)
+ * and hands over:
+ *   heap / heap_bytes            the table's heap (host; may be a read-only mmap)
+ *   tile_offset / tile_nbytes    [n_tiles] where each tile's Rice stream lies in the heap (COMPRESSED_DATA descriptors);
+ *                                every tile must be Rice-coded (tiles cfitsio stored in GZIP_COMPRESSED_DATA: decode on
+ *                                the host, coreg_decode_tiled_host + zlib, and upload the pixels instead)
+ *   zbitpix, naxis1/2, ztile1/2  the image and its tiling (tiles in row-major order, edge tiles clipped)
+ *   blocksize, bytepix           ZVALn of BLOCKSIZE / BYTEPIX
+ *   quantize                     0 integer image; 1 NO_DITHER, 2 SUBTRACTIVE_DITHER_1, 3 SUBTRACTIVE_DITHER_2 (ZQUANTIZ)
+ *   dither0                      ZDITHER0
+ *   has_blank / blank            ZBLANK (quantized floats: -2147483647 when the file names none)
+ *   zscale / zzero               [n_tiles] columns, or NULL with the scalars zscale0 / zzero0 (keywords)
+ *   bscale / bzero               integer images: physical = float64(stored) * bscale + bzero when either differs from 1 / 0
+ * Resident pixels: float32 for ZBITPIX = -32, else float64 tested for float32-exactness, exactly as the other uploads. */
+typedef struct coreg_fits_tiled {
+    const void* heap;
+    int64_t heap_bytes;
+    const int64_t* tile_offset;
+    const int32_t* tile_nbytes;
+    int32_t n_tiles;
+    int32_t zbitpix;
+    int32_t naxis1, naxis2, ztile1, ztile2;
+    int32_t blocksize, bytepix;
+    int32_t quantize;
+    int32_t dither0;
+    int32_t has_blank, blank;
+    const double* zscale;
+    const double* zzero;
+    double zscale0, zzero0;
+    double bscale, bzero;
+} coreg_fits_tiled;
+int coreg_set_small_tiled(coreg_handle* h, const coreg_fits_tiled* t);
+int coreg_prepare_reference_carrington_tiled(coreg_handle* h, const coreg_fits_tiled* t, const coreg_wcs2d* hdr_large,
+                                             const coreg_carr_grid* grid, double solar_r, int order);
+int coreg_prepare_reference_helioprojective_tiled(coreg_handle* h, const coreg_fits_tiled* t, const coreg_wcs2d* hdr_large,
+                                                  const coreg_wcs2d* hdr_small, int order);
+/* The same decode on the host (no GPU; a few threads over the tiles): out = [naxis2][naxis1] float32 (dtype COREG_F32,
+ * ZBITPIX = -32 only) or float64.  tile_status (optional, [n_tiles]): 0 decoded, 1 corrupt stream, 2 not Rice-coded
+ * (left untouched in `out`).  Returns COREG_OK unless an argument is bad. */
+int coreg_decode_tiled_host(const coreg_fits_tiled* t, void* out, int dtype, int32_t* tile_status);
+
 /* Alignment._set_threshold_minmax_to_nan (alignment.py:876-887) on the resident image to align:
  * |v| < vmin -> NaN when has_min, |v| > vmax -> NaN when has_max.  *n_finite (optional) receives the number of finite
  * pixels left: 0 is the reference's "minimum or maximum value have set all small FOV to nan" error (alignment.py:655). */
@@ -391,6 +436,12 @@ int coreg_multi_prepare_reference_carrington_fits(coreg_multi* m, const coreg_fi
 int coreg_multi_prepare_reference_helioprojective_fits(coreg_multi* m, const coreg_fits_pixels* px, int32_t ny,
                                                        int32_t nx, const coreg_wcs2d* hdr_large,
                                                        const coreg_wcs2d* hdr_small, int order);
+int coreg_multi_set_small_tiled(coreg_multi* m, const coreg_fits_tiled* t);
+int coreg_multi_prepare_reference_carrington_tiled(coreg_multi* m, const coreg_fits_tiled* t, const coreg_wcs2d* hdr_large,
+                                                   const coreg_carr_grid* grid, double solar_r, int order);
+int coreg_multi_prepare_reference_helioprojective_tiled(coreg_multi* m, const coreg_fits_tiled* t,
+                                                        const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small,
+                                                        int order);
 int coreg_multi_threshold_small(coreg_multi* m, int has_min, double vmin, int has_max, double vmax, long long* n_finite);
 int coreg_multi_set_reference_on_grid(coreg_multi* m, const void* ref, int dtype, int32_t gy, int32_t gx);
 int coreg_multi_prepare_reference_carrington(coreg_multi* m, const void* large, int dtype, int32_t ny, int32_t nx,

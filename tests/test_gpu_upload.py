@@ -196,3 +196,82 @@ def test_alignment_raw_fits_path_equals_host_decode(tmp_path, monkeypatch):
     assert np.array_equal(out["1"][0], out["0"][0], equal_nan=True)
     assert np.array_equal(out["1"][1], out["0"][1], equal_nan=True)
     assert np.isfinite(out["1"][0]).all()
+
+
+def _compressed_files():
+    import glob
+    import os
+    from tests.conftest import GOLDEN
+    return sorted(glob.glob(os.path.join(GOLDEN, "compressed", "rice_*.fits")))
+
+
+@pytest.mark.parametrize("path", _compressed_files(), ids=lambda p: p.split("/")[-1][:-5])
+def test_tile_compressed_images_decoded_on_the_gpu_equal_the_host_decode(gpu_handle, path):
+    """coreg_set_small_tiled / coreg_prepare_reference_*_tiled: the COMPRESSED bytes of a tile-compressed image (EUI files)
+    go up, one GPU thread per tile runs cfitsio's RICE_1 codec + dequantization (csrc/ricecomp.hpp) -- against the same
+    image decoded on the host (which tests/test_fits_compressed_cpu.py pins bit for bit to astropy's output): identical
+    resident pixels, identical prepared references, identical sweeps."""
+    from euispice_coreg_amd import _lib
+    from euispice_coreg_amd.utils import fits_io
+    ci = fits_io.open_compressed(path, -1)
+    dec = fits_io.native_pixels(np.asarray(ci))
+    hdr = dict(ci.header)
+    hdr.update(PC1_1=1.0, PC1_2=0.0, PC2_1=0.0, PC2_2=1.0, CROTA=0.0, CTYPE1="HPLN-TAN", CTYPE2="HPLT-TAN")
+    small, hs, large, hl, _ = H.scene()
+    lags = _lib.LagSet([-3.0, 0.5, 4.0], [-2.0, 1.25], None, None, [0.0, 0.4])
+    res = {}
+    for name, img in (("host", dec), ("gpu", ci)):
+        if name == "gpu" and not ci.on_gpu:   # (a tile stored gzipped: the binding decodes on the host, same numbers)
+            assert not _lib._is_tiled(ci)
+        out = []
+        # as the image to align: the resident pixels read back through an order-1 resample on their own grid
+        gpu_handle.set_small(img)
+        out.append(None)
+        out.append(gpu_handle.resample_helioprojective(hdr, hdr, order=1, dtype=np.float64))
+        gpu_handle.prepare_reference_helioprojective(large, hl, hdr, 2)
+        out.append(gpu_handle.sweep_helioprojective(hdr, hdr, lags))
+        # as the reference image: sub-map on the scene's small grid, and on a Carrington grid
+        gpu_handle.set_small(small)
+        href = dict(hdr, CDELT1=4.44, CDELT2=4.44, CRVAL1=hs["CRVAL1"], CRVAL2=hs["CRVAL2"],
+                    DSUN_OBS=hl["DSUN_OBS"], CRLN_OBS=hl["CRLN_OBS"], CRLT_OBS=hl["CRLT_OBS"])
+        gpu_handle.prepare_reference_helioprojective(img, href, hs, 2)
+        out.append(gpu_handle.get_reference_on_grid((hs["NAXIS2"], hs["NAXIS1"]), np.float32))
+        grid = _lib.Grid(H.CARR_LON, H.CARR_LAT, SHAPE)
+        gpu_handle.prepare_reference_carrington(img, href, grid, 1.004, 2)
+        out.append(gpu_handle.get_reference_on_grid((grid.n_lat, grid.n_lon), np.float64))
+        res[name] = out[1:]
+    for a, b in zip(res["host"], res["gpu"]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.isfinite(res["gpu"][0]).any() and np.isfinite(res["gpu"][2]).any()
+    # interior pixels of the order-1 read-back ARE the decoded pixels (weights 1, 0)
+    rb, d64 = res["gpu"][0], np.asarray(dec, dtype=np.float64)
+    m = np.isfinite(rb)
+    assert m.sum() > 0.5 * rb.size and np.array_equal(rb[m], d64[m])
+
+
+def test_alignment_on_a_tile_compressed_file_equals_the_decoded_image(tmp_path, monkeypatch):
+    """`Alignment` with a tile-compressed FITS file as the image to align (the EUI case): compressed upload + GPU decode
+    (default) and host decode (COREG_RAW_FITS=0) give the same correlation array; `write_corrected_fits` then keeps the
+    compressed stream."""
+    import os
+    from tests.conftest import GOLDEN
+    from euispice_coreg_amd.hdrshift import Alignment
+    from euispice_coreg_amd.utils import fits_io
+    src = os.path.join(GOLDEN, "compressed", "rice_f32_big.fits")
+    _, _, large, hl, _ = H.scene()
+    hl = dict(hl, CRVAL1=-310.0, CRVAL2=420.0)   # the reference looks where the compressed image's header points
+    lag = np.arange(-4.0, 4.5, 2.0)
+    out = {}
+    for raw in ("1", "0"):
+        monkeypatch.setenv("COREG_RAW_FITS", raw)
+        A = Alignment((large, hl), src, lag, lag, [0], [0], [0], parallelism=True, force_crota_0=False)
+        out[raw] = A.align_using_helioprojective(return_type="corr")
+        assert isinstance(A.data_small, fits_io.CompressedImage) == (raw == "1")
+    assert np.array_equal(out["1"], out["0"], equal_nan=True) and np.isfinite(out["1"]).any()
+    monkeypatch.setenv("COREG_RAW_FITS", "1")
+    res = Alignment((large, hl), src, lag, lag, [0], [0], [0], parallelism=True).align_using_helioprojective()
+    dst = str(tmp_path / "corrected.fits")
+    res.write_corrected_fits([-1], dst)
+    d, h = fits_io.read_image(dst, -1)
+    assert np.array_equal(d, np.asarray(fits_io.open_compressed(src, -1)), equal_nan=True)
+    assert h["CRVAL1"] == pytest.approx(-310.0 + res.shift_arcsec[0])
