@@ -456,11 +456,25 @@ int check_fits(coreg_handle* h, const coreg_fits_pixels* px, PixFmt* fmt) {
 }
 
 // ---- tile-compressed FITS images (csrc/ricecomp.hpp) -----------------------------------------------------------------
+// One WORKGROUP (one wave) per tile: a tile's bit stream is sequential, so one lane decodes it -- alone in its wave, i.e.
+// without the divergence 64 independent streams per wave would serialise -- after all 64 lanes have staged the tile's
+// compressed bytes in LDS with coalesced loads (the decoder then reads LDS, not one global byte per dependent load).
+constexpr int kRiceLds = 24 * 1024;  // staged when the tile's stream fits (a 4096-pixel row of 4-byte verbatim values: 16 KB)
 __global__ void __launch_bounds__(64) k_rice_tiles(const coregrice::TileImage t, int* status) {
-    const int n = blockIdx.x * 64 + threadIdx.x;
-    if (n >= t.n_tiles) return;
-    const int e = coregrice::decode_tile(t, n);  // one thread per tile: a tile's bit stream is sequential
-    if (e) atomicOr(status, e);
+    __shared__ unsigned char stream[kRiceLds];
+    const int n = blockIdx.x;
+    const long long off = t.tile_offset[n];
+    const int len = t.tile_nbytes[n];
+    const bool staged = len > 0 && len <= kRiceLds && off >= 0 && off + len <= t.heap_bytes;
+    if (staged) {
+        const unsigned char* src = t.heap + off;
+        for (int i = threadIdx.x; i < len; i += 64) stream[i] = src[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int e = coregrice::decode_tile(t, n, staged ? stream : nullptr);
+        if (e) atomicOr(status, e);
+    }
 }
 
 const char* check_tiled(const coreg_fits_tiled* t) {
@@ -564,7 +578,7 @@ int decode_tiled_device(coreg_handle* h, const coreg_fits_tiled* t, DevBuf& pix,
     }
     HIPCHK(h->up_flag.reserve(sizeof(int)));
     HIPCHK(hipMemsetAsync(h->up_flag.p, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL(k_rice_tiles, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, h->stream, im, h->up_flag.as<int>());
+    hipLaunchKernelGGL(k_rice_tiles, dim3((unsigned)nt), dim3(64), 0, h->stream, im, h->up_flag.as<int>());
     HIPCHK(hipGetLastError());
     int flag = 0;
     HIPCHK(hipMemcpyAsync(&flag, h->up_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));

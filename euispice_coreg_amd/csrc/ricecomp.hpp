@@ -230,7 +230,8 @@ COREG_HD inline int rice_decode_tile(const unsigned char* c, int64_t clen, int n
 
 // Tile `n` of the image: geometry, per-tile scale / zero, dither start, then the Rice stream.  Returns 0 ok, 1 corrupt
 // stream, 2 the tile is not Rice-coded (nothing written).
-COREG_HD inline int decode_tile(const TileImage& t, int n) {
+// `stream`: the tile's compressed bytes somewhere faster than the heap (the GPU kernel stages them in LDS), or null
+COREG_HD inline int decode_tile(const TileImage& t, int n, const unsigned char* stream = nullptr) {
     const int ntx = (t.naxis1 + t.ztile1 - 1) / t.ztile1;
     const int tyi = n / ntx, txi = n - tyi * ntx;
     PixelSink s;
@@ -255,7 +256,7 @@ COREG_HD inline int decode_tile(const TileImage& t, int n) {
     if (off < 0 || off + len > t.heap_bytes) {
         return 1;
     }
-    return rice_decode_tile(t.heap + off, len, s.tw * s.th, t.blocksize, t.bytepix, s);
+    return rice_decode_tile(stream ? stream : t.heap + off, len, s.tw * s.th, t.blocksize, t.bytepix, s);
 }
 
 }  // namespace coregrice

@@ -60,7 +60,9 @@ def main():
     from euispice_coreg_amd.hdrshift import Alignment
     from euispice_coreg_amd.utils import fits_io
     d = tempfile.mkdtemp(prefix="coreg_comp_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    small, hs, large, hl, truth = synthetic.make_scene()
+    # (no NaN pixels: the OLD astropy that writes the file here mis-encodes NaNs of large quantized images -- its own
+    # decode of its own file then holds -1.7e9 where the NaNs were; the decoders agree on that garbage bit for bit)
+    small, hs, large, hl, truth = synthetic.make_scene(nan_frac=0.0)
     small32 = small.astype(np.float32)
     p_npy, p_hdr, p_comp, p_dec, p_plain, p_large = (os.path.join(d, n) for n in (
         "small.npy", "hdr.json", "hri_rice.fits", "astropy_decoded.npy", "hri_plain.fits", "fsi.fits"))
@@ -88,11 +90,12 @@ def main():
     raw = fits_io.open_raw(p_plain, -1)
     out["raw_plain_file_upload_ms"], _ = best(lambda: up(raw))
     # the resident pixels are the decoded ones
-    hdr1 = dict(ci.header)
+    hdr1 = dict(ci.header, PC1_1=1.0, PC1_2=0.0, PC2_1=0.0, PC2_2=1.0, CROTA=0.0)  # (an exactly diagonal map)
     h.set_small(ci)
     rb = h.resample_helioprojective(hdr1, hdr1, order=1, dtype=np.float64)
     m = np.isfinite(rb)
     out["gpu_pixels_equal_astropy"] = bool(m.sum() > 0.9 * m.size and np.array_equal(rb[m], want.astype(np.float64)[m]))
+    out["quantization_rms_error"] = float(np.sqrt(np.nanmean((want.astype(np.float64) - small32) ** 2)))
     lag = np.arange(-30, 30, 1.0)
 
     def call(path):
