@@ -456,24 +456,50 @@ int check_fits(coreg_handle* h, const coreg_fits_pixels* px, PixFmt* fmt) {
 }
 
 // ---- tile-compressed FITS images (csrc/ricecomp.hpp) -----------------------------------------------------------------
-// One WORKGROUP (one wave) per tile: a tile's bit stream is sequential, so one lane decodes it -- alone in its wave, i.e.
-// without the divergence 64 independent streams per wave would serialise -- after all 64 lanes have staged the tile's
-// compressed bytes in LDS with coalesced loads (the decoder then reads LDS, not one global byte per dependent load).
-constexpr int kRiceLds = 24 * 1024;  // staged when the tile's stream fits (a 4096-pixel row of 4-byte verbatim values: 16 KB)
+// One WORKGROUP (one wave) per tile.  A tile's bit stream is sequential, so ONE lane decodes it -- alone in its wave,
+// i.e. without the divergence 64 independent streams per wave would serialise -- between two parallel phases: all 64
+// lanes stage the tile's compressed bytes in LDS (coalesced loads; the decoder then reads LDS, not one global byte per
+// dependent load), lane 0 leaves the decoded integers in LDS, and all 64 lanes turn them into pixel values (scale,
+// zero, dither, NaN) and store them row by row, coalesced.  Tiles too large for the buffers take the direct path.
+constexpr int kRiceStream = 16 * 1024;  // bytes of compressed stream staged (a 4096-pixel row of verbatim 4-byte values)
+constexpr int kRicePixels = 4096;       // decoded integers buffered
 __global__ void __launch_bounds__(64) k_rice_tiles(const coregrice::TileImage t, int* status) {
-    __shared__ unsigned char stream[kRiceLds];
+    __shared__ unsigned char stream[kRiceStream];
+    __shared__ int32_t qbuf[kRicePixels];
     const int n = blockIdx.x;
     const long long off = t.tile_offset[n];
     const int len = t.tile_nbytes[n];
-    const bool staged = len > 0 && len <= kRiceLds && off >= 0 && off + len <= t.heap_bytes;
-    if (staged) {
+    const coregrice::TileBox box = coregrice::tile_box(t, n);
+    const int npx = box.tw * box.th;
+    const bool in_heap = len > 0 && off >= 0 && off + len <= t.heap_bytes;
+    const bool staged = in_heap && len <= kRiceStream && npx <= kRicePixels;
+    if (!staged) {
+        if (threadIdx.x == 0) {
+            const int e = coregrice::decode_tile(t, n);
+            if (e) atomicOr(status, e);
+        }
+        return;
+    }
+    {
         const unsigned char* src = t.heap + off;
         for (int i = threadIdx.x; i < len; i += 64) stream[i] = src[i];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int e = coregrice::decode_tile(t, n, staged ? stream : nullptr);
-        if (e) atomicOr(status, e);
+        coregrice::QSink sink = {qbuf, 0};
+        const int e = coregrice::rice_decode_tile(stream, len, npx, t.blocksize, t.bytepix, sink);
+        if (e) atomicOr(status, 1);
+    }
+    __syncthreads();
+    const double scale = t.zscale ? t.zscale[n] : t.zscale0, zero = t.zzero ? t.zzero[n] : t.zzero0;
+    const bool dith = t.quantize == coregrice::Q_DITHER_1 || t.quantize == coregrice::Q_DITHER_2;
+    const int iseed = dith ? coregrice::dither_seed(t, n) : 0;
+    for (int i = threadIdx.x; i < npx; i += 64) {
+        const int ty = i / box.tw, tx = i - ty * box.tw;
+        const double v = coregrice::pixel_value(t, scale, zero, qbuf[i], dith ? coregrice::dither_index(t.randoms, iseed, i) : 0);
+        const long long at = (long long)(box.y0 + ty) * t.naxis1 + (box.x0 + tx);
+        if (t.out_dtype == coregrice::OUT_F32) ((float*)t.out)[at] = (float)v;
+        else ((double*)t.out)[at] = v;
     }
 }
 

@@ -71,68 +71,83 @@ struct TileImage {
     int32_t out_dtype;  // OUT_F32 / OUT_F64
 };
 
-// One pixel value out: integer image or quantized float, to the output array
+// What a decoded integer means: the physical pixel value.  `rand_idx`: index into cfitsio's random sequence for this pixel
+// (dithered float images; see dither_index).
+COREG_HD inline double pixel_value(const TileImage& t, double scale, double zero, int32_t q, int rand_idx) {
+#pragma clang fp contract(off)  // cfitsio multiplies, rounds, adds, rounds (x86-64 baseline): no FMA here
+    if (t.quantize == Q_NONE) {
+        if (t.has_blank && q == t.blank) return __builtin_nan("");
+        double v = (double)q;
+        if (t.scaled) v = v * t.bscale + t.bzero;  // (two roundings, as NumPy's float64(q) * bscale + bzero)
+        return v;
+    }
+    if (q == t.blank) return __builtin_nan("");
+    if (t.quantize == Q_DITHER_2 && q == kZeroValue) return 0.0;
+    if (t.quantize == Q_DITHER_1 || t.quantize == Q_DITHER_2)
+        return ((double)q - (double)t.randoms[rand_idx] + 0.5) * scale + zero;
+    return (double)q * scale + zero;
+}
+
+// cfitsio's walk through its random sequence, in closed form: pixel i of a tile whose walk starts at (iseed, nextrand =
+// (int)(rand[iseed] * 500)) uses rand[nextrand + i]; whenever the index reaches N_RANDOM the walk restarts at
+// (int)(rand[++iseed mod N] * 500).  (The sequence advances for null pixels too.)
+COREG_HD inline int dither_index(const float* randoms, int iseed, int i) {
+    int start = (int)(randoms[iseed] * 500);
+    while (start + i >= kNRandom) {
+        i -= kNRandom - start;
+        iseed = iseed + 1 == kNRandom ? 0 : iseed + 1;
+        start = (int)(randoms[iseed] * 500);
+    }
+    return start + i;
+}
+COREG_HD inline int dither_seed(const TileImage& t, int n) {
+    // cfitsio: unquantize(row = tile number (1-based) + ZDITHER0 - 1): iseed = (row - 1) % N_RANDOM
+    const long long row = (long long)(n + 1) + t.dither0 - 1;
+    return (int)(((row - 1) % kNRandom + kNRandom) % kNRandom);
+}
+
+// Where the decoded integers of a tile go.  PixelSink: straight to the output image, value by value (host; GPU tiles too
+// large for the staged path).  QSink: into a buffer of integers (the GPU kernel's lane 0; the other lanes turn them into
+// pixel values afterwards).
 struct PixelSink {
     const TileImage* im;
     double scale, zero;
     int iseed, nextrand;
-    // position
-    int x0, y0, tw, th, i;  // tile origin, tile extent, running index inside the tile
+    int x0, y0, tw, tx, ty;  // tile origin and width, running position inside the tile
     COREG_HD void put(int32_t q) {
-#pragma clang fp contract(off)  // cfitsio multiplies, rounds, adds, rounds (x86-64 baseline): no FMA here
         const TileImage& t = *im;
-        const int ty = i / tw, tx = i - ty * tw;
         const int64_t at = (int64_t)(y0 + ty) * t.naxis1 + (x0 + tx);
-        ++i;
-        double v;
-        if (t.quantize == Q_NONE) {
-            if (t.has_blank && q == t.blank) {
-                v = __builtin_nan("");
-            } else {
-                v = (double)q;
-                if (t.scaled) {
-                    v = v * t.bscale + t.bzero;  // (two roundings, as NumPy's float64(q) * bscale + bzero)
-                }
-            }
-        } else {
-            const bool dith = t.quantize == Q_DITHER_1 || t.quantize == Q_DITHER_2;
-            if (q == t.blank) {
-                v = __builtin_nan("");
-            } else if (t.quantize == Q_DITHER_2 && q == kZeroValue) {
-                v = 0.0;
-            } else if (dith) {
-                v = ((double)q - (double)t.randoms[nextrand] + 0.5) * scale + zero;
-            } else {
-                v = (double)q * scale + zero;
-            }
-            if (dith) {  // (the sequence advances for null pixels too)
-                ++nextrand;
-                if (nextrand == kNRandom) {
-                    ++iseed;
-                    if (iseed == kNRandom) iseed = 0;
-                    nextrand = (int)(t.randoms[iseed] * 500);
-                }
+        if (++tx == tw) {
+            tx = 0;
+            ++ty;
+        }
+        const double v = pixel_value(t, scale, zero, q, nextrand);
+        if (t.quantize == Q_DITHER_1 || t.quantize == Q_DITHER_2) {
+            ++nextrand;
+            if (nextrand == kNRandom) {
+                ++iseed;
+                if (iseed == kNRandom) iseed = 0;
+                nextrand = (int)(t.randoms[iseed] * 500);
             }
         }
         if (t.out_dtype == OUT_F32) ((float*)t.out)[at] = (float)v;
         else ((double*)t.out)[at] = v;
     }
 };
+struct QSink {
+    int32_t* q;
+    int i;
+    COREG_HD void put(int32_t v) { q[i++] = v; }
+};
 
 // position (1 .. 8) of the highest set bit of a non-zero byte: cfitsio's nonzero_count[] table
-COREG_HD inline int top_bit(unsigned b) {
-    int n = 0;
-    while (b) {
-        ++n;
-        b >>= 1;
-    }
-    return n;
-}
+COREG_HD inline int top_bit(unsigned b) { return 32 - __builtin_clz(b); }
 
 // cfitsio fits_rdecomp / fits_rdecomp_short / fits_rdecomp_byte, one routine: BYTEPIX = 4 / 2 / 1.
 // Returns 0, or 1 when the stream ends early / is inconsistent (the remaining pixels of the tile are then NaN-less garbage
 // free: they are written as the last good value so that nothing stays uninitialised; the caller reports the error).
-COREG_HD inline int rice_decode_tile(const unsigned char* c, int64_t clen, int nx, int nblock, int bytepix, PixelSink& sink) {
+template <typename Sink>
+COREG_HD inline int rice_decode_tile(const unsigned char* c, int64_t clen, int nx, int nblock, int bytepix, Sink& sink) {
     const int fsbits = bytepix == 4 ? 5 : (bytepix == 2 ? 4 : 3);
     const int fsmax = bytepix == 4 ? 25 : (bytepix == 2 ? 14 : 6);
     const int bbits = 1 << fsbits;
@@ -228,35 +243,43 @@ COREG_HD inline int rice_decode_tile(const unsigned char* c, int64_t clen, int n
     return err;
 }
 
+struct TileBox {
+    int x0, y0, tw, th;
+};
+COREG_HD inline TileBox tile_box(const TileImage& t, int n) {
+    const int ntx = (t.naxis1 + t.ztile1 - 1) / t.ztile1;
+    const int tyi = n / ntx, txi = n - tyi * ntx;
+    TileBox b;
+    b.x0 = txi * t.ztile1;
+    b.y0 = tyi * t.ztile2;
+    b.tw = t.naxis1 - b.x0 < t.ztile1 ? t.naxis1 - b.x0 : t.ztile1;
+    b.th = t.naxis2 - b.y0 < t.ztile2 ? t.naxis2 - b.y0 : t.ztile2;
+    return b;
+}
+
 // Tile `n` of the image: geometry, per-tile scale / zero, dither start, then the Rice stream.  Returns 0 ok, 1 corrupt
 // stream, 2 the tile is not Rice-coded (nothing written).
 // `stream`: the tile's compressed bytes somewhere faster than the heap (the GPU kernel stages them in LDS), or null
 COREG_HD inline int decode_tile(const TileImage& t, int n, const unsigned char* stream = nullptr) {
-    const int ntx = (t.naxis1 + t.ztile1 - 1) / t.ztile1;
-    const int tyi = n / ntx, txi = n - tyi * ntx;
+    const TileBox b = tile_box(t, n);
     PixelSink s;
     s.im = &t;
-    s.x0 = txi * t.ztile1;
-    s.y0 = tyi * t.ztile2;
-    s.tw = t.naxis1 - s.x0 < t.ztile1 ? t.naxis1 - s.x0 : t.ztile1;
-    s.th = t.naxis2 - s.y0 < t.ztile2 ? t.naxis2 - s.y0 : t.ztile2;
-    s.i = 0;
+    s.x0 = b.x0;
+    s.y0 = b.y0;
+    s.tw = b.tw;
+    s.tx = s.ty = 0;
     s.scale = t.zscale ? t.zscale[n] : t.zscale0;
     s.zero = t.zzero ? t.zzero[n] : t.zzero0;
     s.iseed = s.nextrand = 0;
     if (t.quantize == Q_DITHER_1 || t.quantize == Q_DITHER_2) {
-        // cfitsio: unquantize(row = tile number (1-based) + ZDITHER0 - 1): iseed = (row - 1) % N_RANDOM
-        long long row = (long long)(n + 1) + t.dither0 - 1;
-        s.iseed = (int)(((row - 1) % kNRandom + kNRandom) % kNRandom);
+        s.iseed = dither_seed(t, n);
         s.nextrand = (int)(t.randoms[s.iseed] * 500);
     }
     const int64_t off = t.tile_offset[n];
     const int64_t len = t.tile_nbytes[n];
     if (len <= 0) return 2;
-    if (off < 0 || off + len > t.heap_bytes) {
-        return 1;
-    }
-    return rice_decode_tile(stream ? stream : t.heap + off, len, s.tw * s.th, t.blocksize, t.bytepix, s);
+    if (off < 0 || off + len > t.heap_bytes) return 1;
+    return rice_decode_tile(stream ? stream : t.heap + off, len, b.tw * b.th, t.blocksize, t.bytepix, s);
 }
 
 }  // namespace coregrice
