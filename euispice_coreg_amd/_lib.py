@@ -110,6 +110,44 @@ def decode_tiled_host(ci, out):
     return status
 
 
+def encode_tiled_host(pixels, tile, bytepix=4, blocksize=32, quantize=0, dither0=1, scale=1.0):
+    """Rice-encode an image tile by tile on the host (cfitsio's encoder restated, csrc/riceenc.hpp): `pixels` float32 /
+    float64 (quantized first: `quantize` 1 NO_DITHER, 2 / 3 SUBTRACTIVE_DITHER_1 / _2, ZSCALE = `scale`, ZZERO = each tile's
+    minimum) or int32 (the stored integers of an integer image, BYTEPIX 1 / 2 / 4).
+    Returns (heap bytes, tile_nbytes, tile_offset, zscale or None, zzero or None)."""
+    a = np.ascontiguousarray(pixels)
+    if a.ndim != 2:
+        raise ValueError("image must be 2-D")
+    ny, nx = a.shape
+    tx, ty = int(tile[0]), int(tile[1])
+    nt = (-(-nx // tx)) * (-(-ny // ty))
+    if a.dtype == np.float32:
+        dt = COREG_F32
+    elif a.dtype == np.float64:
+        dt = COREG_F64
+    elif a.dtype == np.int32:
+        dt = 2  # COREG_I32
+    else:
+        raise TypeError("pixels must be float32, float64 or int32 (stored integers)")
+    is_float = dt != 2
+    n_blocks = nt * (-(-(tx * ty) // int(blocksize)) + 1)
+    cap = a.size * int(bytepix) + n_blocks + 8 * nt + 64
+    heap = np.empty(cap, dtype=np.uint8)
+    nbytes = np.zeros(nt, dtype=np.int32)
+    offs = np.zeros(nt, dtype=np.int64)
+    zs = np.zeros(nt, dtype=np.float64) if is_float else None
+    zz = np.zeros(nt, dtype=np.float64) if is_float else None
+    used = C.c_longlong(0)
+    rc = load_library().coreg_encode_tiled_host(a.ctypes.data, dt, ny, nx, tx, ty, int(bytepix), int(blocksize), int(quantize),
+                                                int(dither0), float(scale), heap.ctypes.data, cap, nbytes.ctypes.data,
+                                                offs.ctypes.data, zs.ctypes.data if is_float else None,
+                                                zz.ctypes.data if is_float else None, C.byref(used))
+    if rc != COREG_OK:
+        raise CoregError(rc, "coreg_encode_tiled_host: bad arguments, or a tile's range does not fit 32-bit integers at "
+                             "this scale")
+    return heap[:used.value].copy(), nbytes, offs, zs, zz
+
+
 def _is_raw(img):
     """utils.fits_io.RawImage (duck-typed: the binding does not import the FITS reader)."""
     return hasattr(img, "bitpix") and hasattr(img, "ptr")
@@ -143,6 +181,8 @@ SYMBOLS = [
      [_P, C.POINTER(FitsTiled), _WP, C.POINTER(CarrGrid), C.c_double, C.c_int]),
     ("coreg_prepare_reference_helioprojective_tiled", C.c_int, [_P, C.POINTER(FitsTiled), _WP, _WP, C.c_int]),
     ("coreg_decode_tiled_host", C.c_int, [C.POINTER(FitsTiled), _P, C.c_int, _P]),
+    ("coreg_encode_tiled_host", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_double, _P, C.c_longlong, _P, _P, _P, _P, C.POINTER(C.c_longlong)]),
     ("coreg_threshold_small", C.c_int, [_P, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_longlong)]),
     ("coreg_set_reference_on_grid", C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32]),
     ("coreg_prepare_reference_carrington", C.c_int,

@@ -20,6 +20,7 @@
 #include "geometry.hpp"
 #include "kernels.hpp"
 #include "ricecomp.hpp"
+#include "riceenc.hpp"
 
 using namespace coreg;
 
@@ -1852,6 +1853,62 @@ int coreg_decode_tiled_host(const coreg_fits_tiled* t, void* out, int dtype, int
     for (int k = 1; k < n_thr; ++k) th.emplace_back(work, std::min(nt, k * per), std::min(nt, (k + 1) * per));
     work(0, std::min(nt, per));
     for (auto& x : th) x.join();
+    return COREG_OK;
+}
+
+int coreg_encode_tiled_host(const void* pixels, int dtype, int ny, int nx, int tile_x, int tile_y, int bytepix,
+                            int blocksize, int quantize, int dither0, double scale, unsigned char* heap,
+                            long long heap_cap, int32_t* tile_nbytes, int64_t* tile_offset, double* zscale, double* zzero,
+                            long long* heap_used) {
+    if (!pixels || !heap || !tile_nbytes || !tile_offset || !heap_used || ny <= 0 || nx <= 0 || tile_x <= 0 || tile_y <= 0)
+        return COREG_EINVAL;
+    if (blocksize <= 0 || blocksize > 1024 || (bytepix != 1 && bytepix != 2 && bytepix != 4)) return COREG_EINVAL;
+    const bool is_float = dtype == COREG_F32 || dtype == COREG_F64;
+    if (is_float) {
+        if (quantize < coregrice::Q_NO_DITHER || quantize > coregrice::Q_DITHER_2 || !(scale > 0) || !std::isfinite(scale) ||
+            !zscale || !zzero || bytepix != 4)
+            return COREG_EINVAL;
+    } else if (dtype != COREG_I32) {
+        return COREG_EINVAL;  // integer images: the stored integers as int32, whatever BYTEPIX
+    }
+    static const std::vector<float> randoms = [] {
+        std::vector<float> r(coregrice::kNRandom);
+        coregrice::init_randoms(r.data());
+        return r;
+    }();
+    coregrice::TileImage t{};
+    t.naxis1 = nx;
+    t.naxis2 = ny;
+    t.ztile1 = tile_x;
+    t.ztile2 = tile_y;
+    t.dither0 = dither0;
+    const int ntx = (nx + tile_x - 1) / tile_x, nty = (ny + tile_y - 1) / tile_y;
+    std::vector<int32_t> q((size_t)tile_x * tile_y);
+    long long used = 0;
+    for (int n = 0; n < ntx * nty; ++n) {
+        const coregrice::TileBox b = coregrice::tile_box(t, n);
+        const int npx = b.tw * b.th;
+        if (is_float) {
+            const int iseed = coregrice::dither_seed(t, n);
+            const int e = dtype == COREG_F32
+                              ? coregrice::quantize_tile((const float*)pixels, nx, b, quantize, iseed, randoms.data(), scale,
+                                                         q.data(), &zzero[n])
+                              : coregrice::quantize_tile((const double*)pixels, nx, b, quantize, iseed, randoms.data(), scale,
+                                                         q.data(), &zzero[n]);
+            if (e) return COREG_EINVAL;  // (the tile's range does not fit 32-bit integers at this scale)
+            zscale[n] = scale;
+        } else {
+            const int32_t* src = (const int32_t*)pixels;
+            for (int y = 0; y < b.th; ++y)
+                std::memcpy(q.data() + (size_t)y * b.tw, src + (size_t)(b.y0 + y) * nx + b.x0, (size_t)b.tw * 4);
+        }
+        const int64_t len = coregrice::rice_encode_tile(q.data(), npx, blocksize, bytepix, heap + used, heap_cap - used);
+        if (len < 0) return COREG_ENOMEM;
+        tile_offset[n] = used;
+        tile_nbytes[n] = (int32_t)len;
+        used += len;
+    }
+    *heap_used = used;
     return COREG_OK;
 }
 

@@ -30,6 +30,7 @@ extern "C" {
 
 #define COREG_F32 0
 #define COREG_F64 1
+#define COREG_I32 2 /* coreg_encode_tiled_host only: the stored integers of an integer image */
 
 #define COREG_PROJ_TAN 0
 #define COREG_PROJ_CAR 1
@@ -185,6 +186,19 @@ int coreg_prepare_reference_helioprojective_tiled(coreg_handle* h, const coreg_f
  * ZBITPIX = -32 only) or float64.  tile_status (optional, [n_tiles]): 0 decoded, 1 corrupt stream, 2 not Rice-coded
  * (left untouched in `out`).  Returns COREG_OK unless an argument is bad. */
 int coreg_decode_tiled_host(const coreg_fits_tiled* t, void* out, int dtype, int32_t* tile_status);
+/* The writing side (host, no GPU): what astropy's CompImageHDU does when the reference writes a corrected file whose
+ * input was tile-compressed (utils/Util.py:137-138) -- cfitsio's RICE_1 encoder (`fits_rcomp*`) restated, and for
+ * floating-point pixels (dtype COREG_F32 / COREG_F64, BYTEPIX 4) its quantization q = NINT((v - ZZERO) / ZSCALE + r - 0.5)
+ * with ZZERO = the tile's smallest finite value and ZSCALE = `scale` for every tile (quantize 1 / 2 / 3 as above; NaN ->
+ * -2147483647).  Integer images: dtype COREG_I32, the STORED integers (after BZERO), BYTEPIX 1 / 2 / 4.  Tiles in
+ * row-major order; heap (capacity heap_cap; <= pixels * BYTEPIX + n_blocks + 8 bytes per tile always suffices),
+ * tile_nbytes / tile_offset [n_tiles] and, for floats, zscale / zzero [n_tiles] are filled, *heap_used set.
+ * utils/fits_io.write_compressed_image builds the table around it.  COREG_ENOMEM: heap_cap too small; COREG_EINVAL also
+ * when a tile's range does not fit 32-bit integers at this scale. */
+int coreg_encode_tiled_host(const void* pixels, int dtype, int ny, int nx, int tile_x, int tile_y, int bytepix,
+                            int blocksize, int quantize, int dither0, double scale, unsigned char* heap,
+                            long long heap_cap, int32_t* tile_nbytes, int64_t* tile_offset, double* zscale, double* zzero,
+                            long long* heap_used);
 
 /* Alignment._set_threshold_minmax_to_nan (alignment.py:876-887) on the resident image to align:
  * |v| < vmin -> NaN when has_min, |v| > vmax -> NaN when has_max.  *n_finite (optional) receives the number of finite

@@ -196,3 +196,41 @@ def test_session_drives_every_device_from_one_process(series, tmp_path, monkeypa
         f1, f2 = (os.path.join(str(tmp_path / d), os.path.basename(p)) for d in ("one", "two"))
         assert open(f1, "rb").read() == open(f2, "rb").read()
         assert fits_io.read_header(f1, -1)["CRVAL1"] == fits_io.read_header(f2, -1)["CRVAL1"]
+
+
+def test_session_on_a_tile_compressed_series(series, tmp_path):
+    """The series as EUI distributes it -- every image a Rice-compressed HDU (written here by
+    fits_io.write_compressed_image, lossless 16-bit integers as in level-1 files): the session uploads the compressed
+    bytes, the GPU decodes them, and the corrected files keep the compressed stream.  Same shifts as the session on the
+    plain files holding the same pixels."""
+    from euispice_coreg_amd.jitter_correction import jitter_correction_imagers
+    from euispice_coreg_amd.utils import fits_io
+    paths, frames, jit, _ = series
+    plain_dir, comp_dir = tmp_path / "plain", tmp_path / "comp"
+    plain_dir.mkdir()
+    comp_dir.mkdir()
+    plain, comp = [], []
+    for k, (img, hdr) in enumerate(frames):
+        px = np.clip(np.nan_to_num(img, nan=0.0) * 16.0, 0, 65535).astype(np.uint16)
+        name = f"solo_L1_eui-hrieuv174-image_{k:03d}.fits"
+        fits_io.write_images(str(plain_dir / name), [(None, {}), (px.astype(np.float32), hdr)])
+        fits_io.write_compressed_image(str(comp_dir / name), px, hdr)
+        plain.append(str(plain_dir / name))
+        comp.append(str(comp_dir / name))
+        assert fits_io.open_compressed(comp[-1], -1).on_gpu
+    lag = np.arange(-12.0, 12.5, 1.0)
+    kw = dict(lonlims=LON, latlims=LAT, shape=SHAPE, lag_crval1=lag, lag_crval2=lag, sublist_length=2, overlap=1)
+    done_p = jitter_correction_imagers(plain, str(tmp_path / "out_p"), **kw)
+    done_c = jitter_correction_imagers(comp, str(tmp_path / "out_c"), **kw)
+    assert [(a, r) for a, r, _ in done_p] == [(a, r) for a, r, _ in done_c]
+    for (_, _, rp), (_, _, rc) in zip(done_p, done_c):
+        assert np.array_equal(rp.corr, rc.corr, equal_nan=True)
+    for k, p in enumerate(comp):
+        o = os.path.join(str(tmp_path / "out_c"), os.path.basename(p))
+        ci_in, ci_out = fits_io.open_compressed(p, -1), fits_io.open_compressed(o, -1)
+        assert ci_out is not None and ci_out.on_gpu, "the corrected file is tile-compressed like its input"
+        assert bytes(ci_out._heap) == bytes(ci_in._heap)
+        hp = fits_io.read_header(os.path.join(str(tmp_path / "out_p"), os.path.basename(p)), -1)
+        assert ci_out.header["CRVAL1"] == hp["CRVAL1"] and ci_out.header["CRVAL2"] == hp["CRVAL2"]
+        if k:
+            assert abs(ci_out.header["CRVAL1"] - (frames[k][1]["CRVAL1"] + jit[k, 0])) < 1.0

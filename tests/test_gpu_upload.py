@@ -275,3 +275,48 @@ def test_alignment_on_a_tile_compressed_file_equals_the_decoded_image(tmp_path, 
     d, h = fits_io.read_image(dst, -1)
     assert np.array_equal(d, np.asarray(fits_io.open_compressed(src, -1)), equal_nan=True)
     assert h["CRVAL1"] == pytest.approx(-310.0 + res.shift_arcsec[0])
+
+
+@pytest.mark.parametrize("kind", ["float32 dithered (level 2)", "uint16 (level 1)"])
+def test_full_size_compressed_image_round_trip_through_the_gpu(gpu_handle, tmp_path, kind):
+    """A 2048 x 2048 image in the format EUI files have, written by this package (csrc/riceenc.hpp), decoded on the GPU:
+    the size-independent properties of a codec at full size -- encode -> GPU decode gives the input back (integers exactly,
+    quantized floats to half a step, NaN kept), the GPU's pixels are the host decoder's bit for bit, and a sweep on the
+    compressed image equals the sweep on the decoded pixels."""
+    from euispice_coreg_amd import _lib, synthetic
+    from euispice_coreg_amd.utils import fits_io
+    small, hs, large, hl, _ = synthetic.make_scene()
+    assert small.shape == (2048, 2048)
+    if kind.startswith("float32"):
+        img = small.astype(np.float32)
+        assert np.isnan(img).any()
+        kw = dict(quantize="SUBTRACTIVE_DITHER_2", dither0=4321)
+    else:
+        img = np.clip(np.nan_to_num(small, nan=0.0) * 8.0, 0, 65535).astype(np.uint16)
+        kw = {}
+    p = str(tmp_path / "full.fits")
+    info = fits_io.write_compressed_image(p, img, hs, **kw)
+    ci = fits_io.open_compressed(p, -1)
+    assert ci.on_gpu and ci.n_tiles == 2048 and info["compressed_bytes"] < 0.5 * img.nbytes
+    host = ci.decode()
+    # read the resident pixels back: an order-1 resample onto the image's own grid has weights (1, 0) on interior pixels
+    hdr = dict(hs)
+    gpu_handle.set_small(ci)
+    rb = gpu_handle.resample_helioprojective(hdr, hdr, order=1, dtype=np.float64)
+    m = np.isfinite(rb)
+    assert m.mean() > 0.9
+    assert np.array_equal(rb[m], host.astype(np.float64)[m])
+    if img.dtype.kind == "f":
+        ok = np.isfinite(img)
+        assert np.array_equal(np.isnan(host), ~ok)
+        assert np.abs(host[ok].astype(np.float64) - img[ok]).max() <= 0.5 * info["scale"] + np.spacing(np.float32(img[ok].max()))
+    else:
+        assert np.array_equal(host, img.astype(np.float64))
+    # sweeps: compressed upload against the decoded pixels
+    grid = _lib.Grid(H.CARR_LON, H.CARR_LAT, (512, 512))
+    gpu_handle.prepare_reference_carrington(large, hl, grid, 1.004, 2)
+    lags = _lib.LagSet(np.arange(-6.0, 7.0, 3.0), np.arange(-6.0, 7.0, 3.0), None, None, None)
+    a = gpu_handle.sweep_carrington(hs, grid, 1.004, lags)
+    gpu_handle.set_small(fits_io.native_pixels(host))
+    b = gpu_handle.sweep_carrington(hs, grid, 1.004, lags)
+    assert np.array_equal(a, b, equal_nan=True) and np.isfinite(a).all()
