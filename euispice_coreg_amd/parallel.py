@@ -17,7 +17,12 @@ import numpy as np
 
 
 def world_info(group=None):
-    """(rank, world_size) of the default / given process group, (0, 1) when torch.distributed is not in use."""
+    """(rank, world_size) of the default / given process group, (0, 1) when torch.distributed is not in use.
+    A process group exists only if the caller imported torch: a plain script that never did is not made to pay for
+    that import (0.8 s of the first call, profiles/first_call.py)."""
+    import sys
+    if "torch" not in sys.modules:
+        return 0, 1
     try:
         import torch.distributed as dist
     except ImportError:

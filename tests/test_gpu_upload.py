@@ -305,7 +305,10 @@ def test_full_size_compressed_image_round_trip_through_the_gpu(gpu_handle, tmp_p
     rb = gpu_handle.resample_helioprojective(hdr, hdr, order=1, dtype=np.float64)
     m = np.isfinite(rb)
     assert m.mean() > 0.9
-    assert np.array_equal(rb[m], host.astype(np.float64)[m])
+    # (at this size the pixel coordinates of the read-back are integers to 1e-13 only: the neighbour's weight is not an
+    # exact zero.  A wrong decode is off by a quantization step, 2e-1, or by thousands.)
+    d = np.abs(rb[m] - host.astype(np.float64)[m])
+    assert d.max() <= 1e-8, f"GPU decode differs from the host decode by up to {d.max()} on {(d > 1e-8).sum()} pixels"
     if img.dtype.kind == "f":
         ok = np.isfinite(img)
         assert np.array_equal(np.isnan(host), ~ok)
