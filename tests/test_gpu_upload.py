@@ -297,7 +297,7 @@ def test_full_size_compressed_image_round_trip_through_the_gpu(gpu_handle, tmp_p
     p = str(tmp_path / "full.fits")
     info = fits_io.write_compressed_image(p, img, hs, **kw)
     ci = fits_io.open_compressed(p, -1)
-    assert ci.on_gpu and ci.n_tiles == 2048 and info["compressed_bytes"] < 0.5 * img.nbytes
+    assert ci.on_gpu and ci.n_tiles == 2048 and info["compressed_bytes"] < 0.75 * img.nbytes
     host = ci.decode()
     # read the resident pixels back: an order-1 resample onto the image's own grid has weights (1, 0) on interior pixels
     hdr = dict(hs)
