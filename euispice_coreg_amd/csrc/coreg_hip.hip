@@ -462,18 +462,22 @@ int check_fits(coreg_handle* h, const coreg_fits_pixels* px, PixFmt* fmt) {
 // lanes stage the tile's compressed bytes in LDS (coalesced loads; the decoder then reads LDS, not one global byte per
 // dependent load), lane 0 leaves the decoded integers in LDS, and all 64 lanes turn them into pixel values (scale,
 // zero, dither, NaN) and store them row by row, coalesced.  Tiles too large for the buffers take the direct path.
-constexpr int kRiceStream = 16 * 1024;  // bytes of compressed stream staged (a 4096-pixel row of verbatim 4-byte values)
-constexpr int kRicePixels = 4096;       // decoded integers buffered
-__global__ void __launch_bounds__(64) k_rice_tiles(const coregrice::TileImage t, int* status) {
-    __shared__ unsigned char stream[kRiceStream];
-    __shared__ int32_t qbuf[kRicePixels];
+// The two buffers are sized per launch (dynamic LDS: q_cap integers, then stream_cap bytes) from the image's largest tile
+// and longest stream, up to the limits below: a 2048-pixel row of an EUI image needs 8 KB + ~3 KB, so every tile of the
+// image is resident at once (16 waves per CU decoding) instead of two rounds of five.
+constexpr int kRiceStream = 16 * 1024;  // most bytes of compressed stream staged (a 4096-pixel row of verbatim 4-byte values)
+constexpr int kRicePixels = 4096;       // most decoded integers buffered
+__global__ void __launch_bounds__(64) k_rice_tiles(const coregrice::TileImage t, int* status, int q_cap, int stream_cap) {
+    extern __shared__ int32_t rice_lds[];
+    int32_t* const qbuf = rice_lds;
+    unsigned char* const stream = (unsigned char*)(rice_lds + q_cap);
     const int n = blockIdx.x;
     const long long off = t.tile_offset[n];
     const int len = t.tile_nbytes[n];
     const coregrice::TileBox box = coregrice::tile_box(t, n);
     const int npx = box.tw * box.th;
     const bool in_heap = len > 0 && off >= 0 && off + len <= t.heap_bytes;
-    const bool staged = in_heap && len <= kRiceStream && npx <= kRicePixels;
+    const bool staged = in_heap && len <= stream_cap && npx <= q_cap;
     if (!staged) {
         if (threadIdx.x == 0) {
             const int e = coregrice::decode_tile(t, n);
@@ -605,7 +609,12 @@ int decode_tiled_device(coreg_handle* h, const coreg_fits_tiled* t, DevBuf& pix,
     }
     HIPCHK(h->up_flag.reserve(sizeof(int)));
     HIPCHK(hipMemsetAsync(h->up_flag.p, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL(k_rice_tiles, dim3((unsigned)nt), dim3(64), 0, h->stream, im, h->up_flag.as<int>());
+    int max_len = 0;
+    for (size_t k = 0; k < nt; ++k) max_len = std::max(max_len, (int)t->tile_nbytes[k]);
+    const int q_cap = (int)std::min<long long>((long long)std::min(t->ztile1, t->naxis1) * std::min(t->ztile2, t->naxis2), kRicePixels);
+    const int stream_cap = std::min((max_len + 15) & ~15, kRiceStream);
+    hipLaunchKernelGGL(k_rice_tiles, dim3((unsigned)nt), dim3(64), (size_t)q_cap * 4 + stream_cap, h->stream, im,
+                       h->up_flag.as<int>(), q_cap, stream_cap);
     HIPCHK(hipGetLastError());
     int flag = 0;
     HIPCHK(hipMemcpyAsync(&flag, h->up_flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
