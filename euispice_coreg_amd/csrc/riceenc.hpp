@@ -62,7 +62,8 @@ inline int64_t rice_encode_tile(const int32_t* q, int nx, int nblock, int bytepi
             uint32_t d = (nextpix - lastpix) & vmask;
             const bool neg = (d >> (bbits - 1)) & 1u;
             int64_t sd = neg ? (int64_t)d - ((int64_t)vmask + 1) : (int64_t)d;
-            const uint32_t z = (uint32_t)(sd < 0 ? ~(sd << 1) : (sd << 1)) & (bytepix == 4 ? 0xffffffffu : (vmask << 1 | 1u));
+            const uint64_t twice = (uint64_t)sd << 1;  // (two's complement: the shift of cfitsio's int arithmetic)
+            const uint32_t z = (uint32_t)(sd < 0 ? ~twice : twice) & (bytepix == 4 ? 0xffffffffu : (vmask << 1 | 1u));
             diff[j] = z;
             pixelsum += (double)z;
             lastpix = nextpix;
