@@ -2,7 +2,11 @@
 method='residus', CDELT2 lags, both CDELT semantics, degrees headers; round 4: the compile-time cubic kernel with
 `orders` = 1,2,3, and -- Carrington cases with several (cdelt, crota) combinations -- the sweep stitched from two
 runs of combinations, the one-shot "combo_begin" / "combo_end" option of a multi-GPU share).
-usage: python tests/deep_fuzz.py [n] [seed0] [scale] [orders, e.g. 1,2,3]"""
+With `forms` = 1 the images no longer go up as arrays only: per case, at random, the image to align and / or the reference
+image are written to disk first -- as a plain FITS data unit (float32 / float64 / scaled int16, uploaded raw and decoded
+on the GPU) or tile-compressed (RICE_1, quantized float32 with a random dither method, tiling and seed; the compressed
+bytes go up and the GPU decodes them) -- and the ORACLE gets the pixels the host readers decode from those files.
+usage: python tests/deep_fuzz.py [n] [seed0] [scale] [orders, e.g. 1,2,3] [forms 0|1]"""
 import os
 import sys
 import time
@@ -19,7 +23,38 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # image / grid size multiplier
     orders = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 2]
+    forms = len(sys.argv) > 5 and sys.argv[5] == "1"
+    import tempfile
     import numpy as np
+    from euispice_coreg_amd.utils import fits_io
+    tmpdir = tempfile.mkdtemp(prefix="coreg_fuzz_")
+    form_count = {}
+
+    def through_a_file(img, hdr, rng, tag):
+        """(what the library is handed, the pixels the oracle must see)"""
+        kind = str(rng.choice(["array", "raw_f32", "raw_f64", "raw_i16", "rice_f32", "rice_i16"]))
+        form_count[kind] = form_count.get(kind, 0) + 1
+        if kind == "array":
+            return img, img
+        p = os.path.join(tmpdir, tag + ".fits")
+        if kind == "raw_f32":
+            fits_io.write_images(p, [(None, {}), (img.astype(np.float32), hdr)])
+        elif kind == "raw_f64":
+            fits_io.write_images(p, [(None, {}), (img.astype(np.float64), hdr)])
+        elif kind in ("raw_i16", "rice_i16"):
+            lo, hi = np.nanmin(img), np.nanmax(img)
+            px = np.nan_to_num((img - lo) / max(hi - lo, 1e-30) * 60000.0 - 30000.0, nan=-32768.0).astype(np.int16)
+            if kind == "raw_i16":
+                fits_io.write_images(p, [(None, {}), (px, hdr)])
+            else:
+                fits_io.write_compressed_image(p, px, hdr, tile=None if rng.integers(0, 2) else (int(rng.integers(3, 40)), int(rng.integers(1, 9))))
+        else:
+            fits_io.write_compressed_image(p, img.astype(np.float32), hdr,
+                                           quantize=str(rng.choice(["NO_DITHER", "SUBTRACTIVE_DITHER_1", "SUBTRACTIVE_DITHER_2"])),
+                                           dither0=int(rng.integers(1, 10001)), scale=float(np.nanstd(img)) / float(rng.choice([16, 64, 1000])),
+                                           tile=None if rng.integers(0, 2) else (int(rng.integers(3, 40)), int(rng.integers(1, 9))))
+        up = fits_io.load_for_upload(p, -1)[0]
+        return up, np.asarray(fits_io.read_image(p, -1)[0], dtype=np.float64)
     n_split = 0
     h = _lib.CoregHandle(-1)
     bad = 0
@@ -34,6 +69,10 @@ def main():
         if rng.integers(0, 3) == 0 and sem == "intended":  # the reference dies on a CDELT2 lag (quirk Q2)
             lags[3] = [0.0, -0.02]
         frame = "carrington" if seed % 2 == 0 else "helio"
+        small_up, large_up = small, large
+        if forms:
+            small_up, small = through_a_file(small, hs, rng, "small")
+            large_up, large = through_a_file(large, hl, rng, "large")
         try:
             if frame == "carrington":
                 lon0 = float(rng.choice([228.0, 200.0, 150.0]))
@@ -43,7 +82,7 @@ def main():
                 solar_r = float(rng.choice([1.004, 1.0, 1.02]))
                 want = H.oracle_carrington(small, hs, large, hl, lags, shape, lonlims, latlims, order=order,
                                            solar_r=(solar_r,), cdelt_semantics=sem)
-                got = H.gpu_carrington(h, small, hs, large, hl, lags, shape, lonlims, latlims, order=order,
+                got = H.gpu_carrington(h, small_up, hs, large_up, hl, lags, shape, lonlims, latlims, order=order,
                                        solar_r=solar_r, cdelt_semantics=0 if sem == "intended" else 1)
                 ls = _lib.LagSet(*lags)
                 inner = ls.shape[2] * ls.shape[3] * ls.shape[4]
@@ -64,10 +103,10 @@ def main():
                     n_split += 1
                 tol = 1e-9
             else:
-                serial = bool(rng.integers(0, 2))
+                serial = bool(rng.integers(0, 2)) and not (forms and not isinstance(large_up, np.ndarray))
                 want = H.oracle_helio(small, hs, large, hl, lags, order=order, parallelism=not serial,
                                       cdelt_semantics=sem)
-                got = H.gpu_helio(h, small, hs, large, hl, lags, order=order, serial_semantics=serial,
+                got = H.gpu_helio(h, small_up, hs, large_up, hl, lags, order=order, serial_semantics=serial,
                                   cdelt_semantics=0 if sem == "intended" else 1)
                 tol = 1e-7
             for k, v in h.last_visit_counts().items():
@@ -79,7 +118,9 @@ def main():
         if (seed - seed0) % 20 == 19:
             print(f"[deep_fuzz] {seed - seed0 + 1}/{n} cases, {bad} failures, {time.time() - t0:.0f} s", flush=True)
     print(f"[deep_fuzz] done: {n} cases (orders {orders}, {n_split} stitched from two combination runs), {bad} failures; "
-          f"tile visits of the last launches: {kinds}")
+          f"tile visits of the last launches: {kinds}" + (f"; image forms: {form_count}" if forms else ""))
+    import shutil
+    shutil.rmtree(tmpdir, ignore_errors=True)
     return 1 if bad else 0
 
 

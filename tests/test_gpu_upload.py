@@ -323,3 +323,58 @@ def test_full_size_compressed_image_round_trip_through_the_gpu(gpu_handle, tmp_p
     gpu_handle.set_small(fits_io.native_pixels(host))
     b = gpu_handle.sweep_carrington(hs, grid, 1.004, lags)
     assert np.array_equal(a, b, equal_nan=True) and np.isfinite(a).all()
+
+
+def test_corrupt_compressed_streams_are_refused_by_the_gpu_decoder(gpu_handle):
+    """What the sanitizer harness proves of the shared decoder on the host (tests/test_rice_sanitizers_cpu.py) seen from
+    the GPU side: a truncated tile, a tile table pointing outside the heap and bit-flipped streams end in COREG_EINVAL or
+    in exactly the pixels the host decoder produces from the same bytes -- never in a fault -- and the handle keeps
+    working afterwards."""
+    import copy
+    import os
+    from tests.conftest import GOLDEN
+    from euispice_coreg_amd import _lib
+    from euispice_coreg_amd.utils import fits_io
+    path = os.path.join(GOLDEN, "compressed", "rice_f32_big.fits")
+    good = fits_io.open_compressed(path, -1)
+    hdr = dict(good.header, PC1_1=1.0, PC1_2=0.0, PC2_1=0.0, PC2_2=1.0, CROTA=0.0, CTYPE1="HPLN-TAN", CTYPE2="HPLT-TAN")
+
+    def variant():
+        ci = copy.copy(good)
+        ci.tile_nbytes, ci.tile_offset = good.tile_nbytes.copy(), good.tile_offset.copy()
+        ci._heap = np.array(good._heap)  # (a private, writable copy of the heap)
+        return ci
+
+    ci = variant()
+    ci.tile_nbytes[17] = 5
+    with pytest.raises(_lib.CoregError, match="truncated or corrupt"):
+        gpu_handle.set_small(ci)
+    ci = variant()
+    ci.tile_offset[3] = ci._heap.size - 2
+    with pytest.raises(_lib.CoregError, match="truncated or corrupt"):
+        gpu_handle.set_small(ci)
+    rng = np.random.default_rng(99)
+    flagged = same = 0
+    for _ in range(24):
+        ci = variant()
+        for _k in range(int(rng.integers(1, 6))):
+            ci._heap[int(rng.integers(0, ci._heap.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        out = np.empty(ci.shape, dtype=np.float32)
+        status = _lib.decode_tiled_host(ci, out)
+        try:
+            gpu_handle.set_small(ci)
+        except _lib.CoregError:
+            assert status.any(), "the GPU flagged a stream the host decoder accepts"
+            flagged += 1
+            continue
+        assert not status.any(), "the host decoder flagged a stream the GPU accepts"
+        rb = gpu_handle.resample_helioprojective(hdr, hdr, order=1, dtype=np.float64)
+        m = np.isfinite(rb) & np.isfinite(out)
+        assert np.array_equal(rb[m], out.astype(np.float64)[m])
+        same += 1
+    assert flagged + same == 24 and same > 0
+    # the handle is intact
+    gpu_handle.set_small(good)
+    rb = gpu_handle.resample_helioprojective(hdr, hdr, order=1, dtype=np.float64)
+    m = np.isfinite(rb)
+    assert np.array_equal(rb[m], np.asarray(good).astype(np.float64)[m])
