@@ -212,6 +212,7 @@ SYMBOLS = [
     ("coreg_set_pivots", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("coreg_last_stats", C.c_int, [_P, C.POINTER(Stats)]),
     ("coreg_last_visit_counts", C.c_int, [_P, C.POINTER(C.c_int64)]),
+    ("coreg_last_tap_fix", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("coreg_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("coreg_shift_header", C.c_int,
      [_WP, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _WP]),
@@ -658,6 +659,13 @@ class CoregHandle:
         self._chk(self._lib.coreg_last_visit_counts(self._h, c))
         return {"visits": c[0], "lds": c[1], "interior": c[2], "all_finite": c[3], "refined_lag_points": c[4],
                 "flagged_not_refined": c[5]}
+
+
+    def last_tap_fix(self) -> dict:
+        """Odd spline orders, helioprojective frame: samples of the last sweep re-evaluated with wcslib's arithmetic."""
+        c = (C.c_int64 * 3)()
+        self._chk(self._lib.coreg_last_tap_fix(self._h, c))
+        return {"samples": c[0], "lag_points": c[1], "overflow": bool(c[2])}
 
 
 class _HandleView(CoregHandle):

@@ -154,6 +154,11 @@ struct coreg_handle {
     DevBuf border_dev;
     PinBuf pin_border;
     int64_t opt_border_fix = 1;
+    // odd spline orders, general case: samples whose coordinate comes back within opt_tap_tol of an integer are
+    // re-evaluated with wcslib's own arithmetic (k_tap_scan / k_tap_fix)
+    int64_t opt_tap_fix = 1, opt_tap_cap = 1 << 24;
+    DevBuf tap_count, tap_list, tap_skip, tap_seg_slot, tap_seg_begin, tap_pixel, tap_xw, tap_yw;
+    long long tap_last[3] = {0, 0, 0};  // last sweep: samples listed, lag-points concerned, 1 = list overflowed (no fix)
     // multi-GPU point sharding (coreg_set_option "shard_world" / "shard_rank"): a sweep covers this rank's share of the
     // tile groups and leaves the six sums per lag slot in `sums`; coreg_finalize_sums turns the all-reduced sums into
     // coefficients
@@ -1027,6 +1032,10 @@ struct BorderFix {  // lag-points of a launch whose border pixels are decided by
     };
     std::vector<Item> items;
     std::vector<int> pixels;  // concatenated linear grid indices (host copy of h->border_dev)
+    // single samples near an integer coordinate (odd spline orders): device arrays ready for k_tap_fix
+    int tap_segs = 0;
+    int tap_mode = 0;
+    TapFixArgs tap = {};
 };
 
 int launch_sweep(coreg_handle* h, int mode, int order, int method, const double* params_dev,
@@ -1039,7 +1048,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     const int g_per = sharded ? n_groups / (int)h->opt_shard_world : n_groups;  // groups swept by this launch
     const int g_lo = sharded ? g_per * (int)h->opt_shard_rank : 0;
     // (the border correction is a property of the lag-point, not of a share of the grid: rank 0 carries it)
-    const bool fixing = fix && !fix->items.empty() && (!sharded || h->opt_shard_rank == 0);
+    const bool fixing = fix && (!fix->items.empty() || fix->tap_segs > 0) && (!sharded || h->opt_shard_rank == 0);
     HIPCHK(h->partials.reserve((size_t)(g_per + (fixing ? 1 : 0)) * kNumSums * n_slots * sizeof(double)));
 
     SweepArgs a;
@@ -1219,6 +1228,30 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
             if (h->small_f32) hipLaunchKernelGGL((k_parity_fix<float>), dim3(p.n_partial), dim3(256), 0, h->stream, p);
             else hipLaunchKernelGGL((k_parity_fix<double>), dim3(p.n_partial), dim3(256), 0, h->stream, p);
             hipLaunchKernelGGL(k_parity_fix_final, dim3(1), dim3(64), 0, h->stream, p);
+        }
+        if (fix->tap_segs > 0) {
+            TapFixArgs t = fix->tap;
+            t.img = b.img;
+            t.W = b.W;
+            t.H = b.H;
+            t.ref = b.ref;
+            t.ref_f32 = b.ref_f32;
+            t.gw = h->gW;
+            t.order = order;
+            t.round_f32 = b.round_f32;
+            t.residus = b.residus;
+            t.pivots = b.pivots;
+            t.hom = params_dev;
+            t.n_slots = n_slots;
+            t.slab = slab;
+            const dim3 tg((unsigned)fix->tap_segs), tb(256);
+            if (fix->tap_mode == MODE_HOMOGRAPHY_SERIES) {
+                if (h->small_f32) hipLaunchKernelGGL((k_tap_fix<float, MODE_HOMOGRAPHY_SERIES>), tg, tb, 0, h->stream, t);
+                else hipLaunchKernelGGL((k_tap_fix<double, MODE_HOMOGRAPHY_SERIES>), tg, tb, 0, h->stream, t);
+            } else {
+                if (h->small_f32) hipLaunchKernelGGL((k_tap_fix<float, MODE_HOMOGRAPHY>), tg, tb, 0, h->stream, t);
+                else hipLaunchKernelGGL((k_tap_fix<double, MODE_HOMOGRAPHY>), tg, tb, 0, h->stream, t);
+            }
         }
         HIPCHK(hipGetLastError());
     }
@@ -1423,6 +1456,118 @@ int upload_border_pixels(coreg_handle* h, const std::vector<int>& pixels) {
     if (!pixels.empty())
         HIPCHK(hipMemcpyAsync(h->border_dev.p, h->pin_border.p, pixels.size() * sizeof(int), hipMemcpyHostToDevice,
                               h->stream));
+    return COREG_OK;
+}
+
+// Odd spline orders, general case (kernels.hpp k_tap_scan / k_tap_fix).  Called between the precompute launch (whose
+// prologue has put the lag parameters on the device) and the sweep launch: list the (slot, pixel) samples whose mapped
+// coordinate lies within 1e-8 px of an integer, evaluate wcslib's chain for them on the host (`shifted_of(slot)` gives the
+// slot's shifted header), and leave everything k_tap_fix needs on the device.  The list is sorted (slot, pixel): one
+// workgroup per slot adds its entries in a fixed order.  A list beyond "tap_cap" entries (a pure CRVAL1 / CRVAL2 lag set
+// under an unrotated header at full size) is not applied at all -- recorded in tap_last, coreg_last_tap_fix.
+template <typename ShiftedOf>
+int prepare_tap_fix(coreg_handle* h, int sweep_mode, const coreg_wcs2d& target, long long n_slots,
+                    const std::vector<unsigned char>& skip, ShiftedOf shifted_of, BorderFix* fix) {
+    const unsigned cap = (unsigned)h->opt_tap_cap;
+    HIPCHK(h->tap_count.reserve(sizeof(unsigned)));
+    HIPCHK(h->tap_list.reserve((size_t)cap * sizeof(uint2)));
+    HIPCHK(h->tap_skip.reserve((size_t)n_slots));
+    HIPCHK(hipMemsetAsync(h->tap_count.p, 0, sizeof(unsigned), h->stream));
+    HIPCHK(hipMemcpyAsync(h->tap_skip.p, skip.data(), (size_t)n_slots, hipMemcpyHostToDevice, h->stream));
+    TapScanArgs a;
+    a.hom = h->lane_params.as<double>();
+    a.n_slots = n_slots;
+    a.skip = h->tap_skip.as<unsigned char>();
+    a.ref = h->ref.p;
+    a.ref_f32 = h->ref_dtype == COREG_F32 ? 1 : 0;
+    a.gw = h->gW;
+    a.gh = h->gH;
+    a.wmax = (double)(h->sW - 1);
+    a.hmax = (double)(h->sH - 1);
+    a.tol = 1e-8;  // wcslib's round-trip noise stays below 1e-9 px, the homography's below 1e-11
+    a.count = h->tap_count.as<unsigned>();
+    a.list = h->tap_list.as<uint2>();
+    a.cap = cap;
+    const unsigned gx = (unsigned)((n_slots + 255) / 256);
+    const unsigned gy = (unsigned)std::max(1, std::min(h->gH, (int)(4096 / std::max(1u, gx))));
+    a.rows_per_block = (h->gH + (int)gy - 1) / (int)gy;
+    const dim3 grid(gx, (unsigned)((h->gH + a.rows_per_block - 1) / a.rows_per_block));
+    if (sweep_mode == MODE_HOMOGRAPHY_SERIES)
+        hipLaunchKernelGGL((k_tap_scan<MODE_HOMOGRAPHY_SERIES>), grid, dim3(256), 0, h->stream, a);
+    else
+        hipLaunchKernelGGL((k_tap_scan<MODE_HOMOGRAPHY>), grid, dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    unsigned count = 0;
+    HIPCHK(hipMemcpyAsync(&count, h->tap_count.p, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->tap_last[0] = count;
+    h->tap_last[1] = 0;
+    h->tap_last[2] = count > cap ? 1 : 0;
+    if (count == 0 || count > cap) return COREG_OK;
+    std::vector<uint2> list(count);
+    HIPCHK(hipMemcpy(list.data(), h->tap_list.p, (size_t)count * sizeof(uint2), hipMemcpyDeviceToHost));
+    std::sort(list.begin(), list.end(), [](const uint2& l, const uint2& r) { return l.x != r.x ? l.x < r.x : l.y < r.y; });
+    std::vector<int> seg_slot, seg_begin;
+    for (unsigned k = 0; k < count; ++k)
+        if (k == 0 || list[k].x != list[k - 1].x) {
+            seg_slot.push_back((int)list[k].x);
+            seg_begin.push_back((int)k);
+        }
+    seg_begin.push_back((int)count);
+    const int n_seg = (int)seg_slot.size();
+    std::vector<unsigned> pixel(count);
+    std::vector<double> xw(count), yw(count);
+    WcslibTan wf;
+    wf.init(target);
+    const int gw = h->gW;
+    auto work = [&](int s0, int s1) {
+        for (int sg = s0; sg < s1; ++sg) {
+            WcslibTan wt;
+            wt.init(shifted_of(seg_slot[sg]));
+            for (int e = seg_begin[sg]; e < seg_begin[sg + 1]; ++e) {
+                pixel[e] = list[e].y;
+                wcslib_pixel_to_pixel(wf, wt, (double)(list[e].y % (unsigned)gw), (double)(list[e].y / (unsigned)gw), &xw[e],
+                                      &yw[e]);
+            }
+        }
+    };
+    unsigned nt = std::min<unsigned>(12, std::max(1u, std::thread::hardware_concurrency()));
+    if (count < 4096 || n_seg < 2) nt = 1;
+    if (nt <= 1) {
+        work(0, n_seg);
+    } else {
+        // segments dealt in runs of about equal entry counts
+        std::vector<std::thread> th;
+        int s0 = 0;
+        for (unsigned t = 0; t < nt && s0 < n_seg; ++t) {
+            const long long want = (long long)count * (t + 1) / nt;
+            int s1 = s0 + 1;
+            while (s1 < n_seg && seg_begin[s1] < want) ++s1;
+            if (t + 1 == nt) s1 = n_seg;
+            th.emplace_back(work, s0, s1);
+            s0 = s1;
+        }
+        for (auto& x : th) x.join();
+    }
+    HIPCHK(h->tap_seg_slot.reserve((size_t)n_seg * sizeof(int)));
+    HIPCHK(h->tap_seg_begin.reserve((size_t)(n_seg + 1) * sizeof(int)));
+    HIPCHK(h->tap_pixel.reserve((size_t)count * sizeof(unsigned)));
+    HIPCHK(h->tap_xw.reserve((size_t)count * sizeof(double)));
+    HIPCHK(h->tap_yw.reserve((size_t)count * sizeof(double)));
+    // (pageable sources, rare path: blocking copies)
+    HIPCHK(hipMemcpy(h->tap_seg_slot.p, seg_slot.data(), (size_t)n_seg * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->tap_seg_begin.p, seg_begin.data(), (size_t)(n_seg + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->tap_pixel.p, pixel.data(), (size_t)count * sizeof(unsigned), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->tap_xw.p, xw.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->tap_yw.p, yw.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+    fix->tap_segs = n_seg;
+    fix->tap_mode = sweep_mode;
+    fix->tap.seg_slot = h->tap_seg_slot.as<int>();
+    fix->tap.seg_begin = h->tap_seg_begin.as<int>();
+    fix->tap.pixel = h->tap_pixel.as<unsigned>();
+    fix->tap.xw = h->tap_xw.as<double>();
+    fix->tap.yw = h->tap_yw.as<double>();
+    h->tap_last[1] = n_seg;
     return COREG_OK;
 }
 
@@ -1706,6 +1851,11 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         h->opt_shard_rank = value;
     } else if (n == "border_fix") {
         h->opt_border_fix = value ? 1 : 0;  // 0: the zero lag keeps every border pixel (exact identity map)
+    } else if (n == "tap_fix") {
+        h->opt_tap_fix = value ? 1 : 0;
+    } else if (n == "tap_cap") {
+        if (value < 1 || value > (1 << 26)) return fail(h, COREG_EINVAL, "tap_cap must be in [1, 2^26]");
+        h->opt_tap_cap = value;
     } else if (n == "pitch") {
         h->opt_pitch = value;  // -1: automatic compile-time window pitch, 0: per-visit pitch, else one of pick_pitch's
     } else if (n == "taper_frac") {
@@ -2698,6 +2848,11 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     fam.init(*hdr_target, *hdr_small, lags->crval1, d.n1, lags->crval2, d.n2, d.nc > 1);
     BorderFix fix;
     std::vector<std::vector<unsigned char>> flags_host;  // per noise-decided lag-point (odd spline orders only)
+    // odd spline orders: what prepare_tap_fix needs to rebuild a slot's shifted header
+    const bool tap_fixing = h->opt_tap_fix && (order & 1) && (h->opt_shard_world <= 1 || h->opt_shard_rank == 0);
+    std::vector<coreg_wcs2d> tap_combo;      // the (cdelt, crota)-shifted header of each combination
+    std::vector<int> tap_slot_combo, tap_slot_i1, tap_slot_i2;
+    std::vector<unsigned char> tap_skip;     // padding lanes and lag-points the structured fix handles
     const int i1_lo = (int)(lag_begin / row), i1_hi = (int)((lag_end - 1) / row);
     const double nanv = std::numeric_limits<double>::quiet_NaN();
     for (long long c = 0; c < d.nc; ++c) {
@@ -2714,6 +2869,15 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
         const Mat3d B = HomographyFamily::combo(hc);
         const size_t at = hs.size();
         hs.resize(at + 9 * slots.i1.size());
+        if (tap_fixing) {
+            tap_combo.push_back(hc);
+            for (size_t s = 0; s < slots.i1.size(); ++s) {
+                tap_slot_combo.push_back((int)tap_combo.size() - 1);
+                tap_slot_i1.push_back(slots.outidx[s] < 0 ? 0 : slots.i1[s]);
+                tap_slot_i2.push_back(slots.outidx[s] < 0 ? 0 : slots.i2[s]);
+                tap_skip.push_back(slots.outidx[s] < 0 ? 1 : 0);
+            }
+        }
         for (size_t s = 0; s < slots.i1.size(); ++s) {
             double* hm = &hs[at + 9 * s];
             if (slots.outidx[s] < 0) {  // padding lane: NaN map -> never in bounds
@@ -2740,6 +2904,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                             flags_host.push_back(wcslib_tap_shift_flags(h, *hdr_target, hl, inv));  // (copy: the cache may evict)
                         }
                         if (it.n > 0 || it.flags_off >= 0) fix.items.push_back(it);
+                        if (tap_fixing) tap_skip[(size_t)it.slot] = 1;  // (its whole grid sits on integers: k_parity_fix)
                     }
                 }
             }
@@ -2811,6 +2976,17 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                              hipMemcpyHostToDevice));
     }
     RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles, pick_groups(h, n_batches, n_tiles), n_batches));
+    h->tap_last[0] = h->tap_last[1] = h->tap_last[2] = 0;
+    if (tap_fixing)
+        RETCHK(prepare_tap_fix(
+            h, sweep_mode, *hdr_target, (long long)ns, tap_skip,
+            [&](int slot) {
+                coreg_wcs2d hl = tap_combo[(size_t)tap_slot_combo[(size_t)slot]];
+                hl.crval1 = hdr_small->crval1 + lags->crval1[tap_slot_i1[(size_t)slot]];
+                hl.crval2 = hdr_small->crval2 + lags->crval2[tap_slot_i2[(size_t)slot]];
+                return hl;
+            },
+            &fix));
     RETCHK(launch_sweep(h, sweep_mode, order, method, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
                         n_tiles, lag_begin, out_dev, nullptr, &fix, 0,
                         pick_pitch(h, plan, h->opt_use_lds ? lds_window_elems(h) : 0, order)));
@@ -2936,6 +3112,12 @@ int coreg_last_visit_counts(coreg_handle* h, int64_t* counts6) {
     if (h->counters.p) HIPCHK(hipMemcpy(refined, h->counters.p, sizeof(refined), hipMemcpyDeviceToHost));
     counts5[4] = refined[0];
     counts6[5] = refined[1];
+    return COREG_OK;
+}
+
+int coreg_last_tap_fix(coreg_handle* h, int64_t* counts3) {
+    if (!h || !counts3) return COREG_EINVAL;
+    for (int k = 0; k < 3; ++k) counts3[k] = h->tap_last[k];
     return COREG_OK;
 }
 

@@ -1915,6 +1915,123 @@ __global__ void k_parity_fix_final(const ParityFixArgs a) {
     a.slab[(size_t)threadIdx.x * a.n_slots + a.slot] += t;
 }
 
+// ---- odd spline orders: single samples decided by wcslib's rounding noise (the general case) -------------------------
+// The two passes above deal with lag-points whose WHOLE grid sits on integers (zero CRVAL lags).  Any other lag can bring
+// single coordinates -- or, for a pure CRVAL1 / CRVAL2 lag under an unrotated header, curves of them -- back within
+// 1e-9 px of an integer, where the sign of the noise of the reference's wcslib round trip (alignment.py:1038-1069)
+// picks the taps of an odd-order spline, hence which neighbour's NaN poisons the sample.  k_tap_scan lists every
+// (lag slot, grid pixel) whose mapped coordinate lies within `tol` of an integer (tol far above the noise, far below a
+// pixel); the host evaluates wcslib's own chain for exactly those (geometry.hpp WcslibTan) and k_tap_fix replaces their
+// contributions: minus the sample at the homography's coordinate (what k_sweep added), plus the sample at wcslib's.
+struct TapScanArgs {
+    const double* hom;          // lane parameters of the launch, SoA [9][n_slots]
+    long long n_slots;
+    const unsigned char* skip;  // [n_slots] 1: the slot's whole grid is handled by k_border_fix / k_parity_fix
+    const void* ref;            // reference on grid (pixels that never enter the sums are not listed)
+    int ref_f32;
+    int gw, gh;
+    double wmax, hmax, tol;
+    unsigned int* count;        // [1] entries wanted (may exceed cap)
+    uint2* list;                // [cap] {slot, linear grid index}
+    unsigned int cap;
+    int rows_per_block;
+};
+template <int MODE>
+__global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
+    const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = slot < a.n_slots && !a.skip[slot];
+    H9 hm;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) hm.h[k] = live ? a.hom[(long long)k * a.n_slots + slot] : __builtin_nan("");
+    LaunchU cu = {};
+    const int j0 = blockIdx.y * a.rows_per_block, j1 = min(j0 + a.rows_per_block, a.gh);
+    for (int j = j0; j < j1; ++j)
+        for (int i = 0; i < a.gw; ++i) {
+            const long long idx = (long long)j * a.gw + i;
+            const double araw = a.ref_f32 ? (double)((const float*)a.ref)[idx] : ((const double*)a.ref)[idx];
+            if (!isfinite(araw)) continue;  // (uniform over the block)
+            double x, y;
+            apply_map<MODE>(hm, cu, (double)i, (double)j, x, y);  // the coordinates k_sweep uses (NaN for dead lanes)
+            const int inr = (int)(x >= -a.tol) & (int)(x <= a.wmax + a.tol) & (int)(y >= -a.tol) & (int)(y <= a.hmax + a.tol);
+            const int near = (int)(fabs(x - rint(x)) < a.tol) | (int)(fabs(y - rint(y)) < a.tol);
+            if (inr & near) {
+                const unsigned k = atomicAdd(a.count, 1u);
+                if (k < a.cap) a.list[k] = make_uint2((unsigned)slot, (unsigned)idx);
+            }
+        }
+}
+struct TapFixArgs {
+    const void* img;
+    int W, H;
+    const void* ref;
+    int ref_f32, gw;
+    int order, round_f32, residus;
+    const double* pivots;
+    const double* hom;
+    long long n_slots;
+    const int* seg_slot;        // [n_seg] one workgroup per listed slot (fixed summation order)
+    const int* seg_begin;       // [n_seg + 1] its entries, sorted by pixel
+    const unsigned int* pixel;  // [n] linear grid index
+    const double* xw;           // [n] wcslib's coordinates of that pixel under the slot's shifted header
+    const double* yw;
+    double* slab;               // [kNumSums][n_slots] the extra slab
+};
+template <typename TS, int MODE>
+__global__ void __launch_bounds__(256) k_tap_fix(const TapFixArgs a) {
+    __shared__ double red[256];
+    const int seg = blockIdx.x;
+    const long long slot = a.seg_slot[seg];
+    const double pivot_a = a.pivots[0], pivot_b = a.pivots[1];
+    H9 hm;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) hm.h[k] = a.hom[(long long)k * a.n_slots + slot];
+    LaunchU cu = {};
+    double s[kNumSums];
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) s[k] = 0.0;
+    for (int e = a.seg_begin[seg] + (int)threadIdx.x; e < a.seg_begin[seg + 1]; e += 256) {
+        const long long idx = a.pixel[e];
+        const double araw = a.ref_f32 ? (double)((const float*)a.ref)[idx] : ((const double*)a.ref)[idx];
+        if (!isfinite(araw)) continue;
+        const int i = (int)(idx % a.gw), j = (int)(idx / a.gw);
+        double nx, ny;
+        apply_map<MODE>(hm, cu, (double)i, (double)j, nx, ny);
+        for (int pass = 0; pass < 2; ++pass) {  // 0: take out what the sweep added; 1: add what the reference samples
+            bool inb;
+            double v = spline_global_rt<TS>((const TS*)a.img, a.W, a.H, pass ? a.xw[e] : nx, pass ? a.yw[e] : ny, a.order, inb);
+            if (!inb) continue;
+            const double sign = pass ? 1.0 : -1.0;
+            if (a.round_f32) v = (double)(float)v;
+            if (a.residus) {
+                const double d = (araw - v) * (1.0 / sqrt(araw));
+                if (isfinite(d)) {
+                    s[0] += sign;
+                    s[2] += sign * d;
+                    s[4] += sign * d * d;
+                }
+            } else if (isfinite(v)) {
+                const double av = araw - pivot_a, bm = v - pivot_b;
+                s[0] += sign;
+                s[1] += sign * av;
+                s[2] += sign * bm;
+                s[3] += sign * av * av;
+                s[4] += sign * bm * bm;
+                s[5] += sign * av * bm;
+            }
+        }
+    }
+    for (int k = 0; k < kNumSums; ++k) {
+        red[threadIdx.x] = s[k];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.slab[(size_t)k * a.n_slots + slot] += red[0];
+        __syncthreads();
+    }
+}
+
 // ---- finalize: add the tile-group slabs in a fixed order, Pearson coefficient (c_correlate.py:39-72) -------------
 // Ill-conditioned lag-points.  The coefficient comes from six sums taken about two GLOBAL pivots (the images' means); when
 // the samples of a lag-point lie far from a pivot compared with their own spread -- a handful of samples, or an overlap

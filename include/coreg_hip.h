@@ -309,6 +309,10 @@ int coreg_last_stats(coreg_handle* h, coreg_stats* out);
  * counts6[5]: lag-points that were flagged likewise but kept their one-pass value because their block of 16 lag slots
  * had used up its "refine_max" re-evaluations.  Waits for the stream. */
 int coreg_last_visit_counts(coreg_handle* h, int64_t* counts6);
+/* Odd spline orders in the helioprojective frame ("tap_fix", below): counts3[0] samples of the last sweep whose mapped
+ * coordinate lay within 1e-8 px of an integer and were re-evaluated with wcslib's own arithmetic, counts3[1] lag-points
+ * concerned, counts3[2] = 1 when the list exceeded "tap_cap" and nothing was applied. */
+int coreg_last_tap_fix(coreg_handle* h, int64_t* counts3);
 
 /* Tuning / test knobs (name -> integer value). Known names:
  *   "use_lds"      1 (default) stage the gather window in LDS, 0 gather from global memory
@@ -323,6 +327,12 @@ int coreg_last_visit_counts(coreg_handle* h, int64_t* counts6);
  *                  are degenerate everywhere -- flat images, a handful of samples per lag-point -- to a few tens of ms;
  *                  the flagged lag-points beyond it keep the one-pass value and are counted, coreg_last_visit_counts);
  *                  0 = no limit
+ *   "tap_fix"      1 (default): helioprojective sweeps with an odd spline order re-evaluate, with wcslib's own arithmetic
+ *                  on the host, every sample whose mapped coordinate comes back within 1e-8 px of an integer -- there
+ *                  the sign of the rounding noise of the reference's round trip (alignment.py:1038-1069) picks the
+ *                  taps, hence which neighbour's NaN poisons the sample (one scan kernel before the sweep, one
+ *                  correction kernel after it; orders 0, 2, 4 never pay for it); 0: the homography's coordinate decides
+ *   "tap_cap"      2^24 (default): most samples listed per sweep; beyond it nothing is applied (coreg_last_tap_fix)
  *   "tile_w"       0 (default, auto) or a power of two in [4, 256]: grid-tile width in points (tile = 1024 pts)
  *   "n_groups"     0 (default, auto): tile groups (partial-sum slabs) per lag batch
  *   "lds_bytes"    dynamic LDS per workgroup for the float64 gather window (default and max 159 KiB)

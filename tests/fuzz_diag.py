@@ -1,6 +1,6 @@
 """Look into ONE case of tests/deep_fuzz.py (helioprojective frame): which lag-point deviates from the oracle, by how much,
 and whether the deviation belongs to the image form (file upload) or to the sweep itself.
-usage: python tests/fuzz_diag.py seed scale order sem(intended|reference) forms(0|1)"""
+usage: python tests/fuzz_diag.py seed scale order sem(intended|reference) forms(0|1) [orders of the run, default 1,2,3]"""
 import os
 import sys
 
@@ -13,7 +13,8 @@ def main():
     from tests import helpers as H
     from tests import deep_fuzz as DF
     seed, scale, order, sem, forms = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5] == "1"
-    case = DF.build_case(seed, scale, [1, 2, 3], forms)
+    orders = [int(v) for v in sys.argv[6].split(",")] if len(sys.argv) > 6 else [1, 2, 3]
+    case = DF.build_case(seed, scale, orders, forms)
     print({k: v for k, v in case.items() if k in ("order", "sem", "frame", "serial", "forms_used")})
     assert case["frame"] == "helio" and case["order"] == order and case["sem"] == sem
     h = _lib.CoregHandle(-1)
@@ -27,7 +28,8 @@ def main():
         ls = _lib.LagSet(*lags)
         print(f"{name}: max|dcorr| = {np.nanmax(d):.3e} at index {k}: lags = "
               f"{[float(a[i]) for a, i in zip(ls.arrays, k[:5])]}, got {got[k]:.12f} want {want[k]:.12f}; "
-              f"second largest {np.sort(d[np.isfinite(d)])[-2]:.3e}; n > 1e-7: {(d > 1e-7).sum()} of {d.size}")
+              f"second largest {np.sort(d[np.isfinite(d)])[-2]:.3e}; n > 1e-7: {(d > 1e-7).sum()} of {d.size}; "
+              f"tap fix: {h.last_tap_fix()}")
     for o in (1, 2, 3):
         want_o = H.oracle_helio(small, hs, large, hl, lags, order=o, parallelism=not case["serial"], cdelt_semantics=sem)
         got_o = H.gpu_helio(h, small, hs, large, hl, lags, order=o, serial_semantics=case["serial"],
