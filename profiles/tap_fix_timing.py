@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""What the general noise-decided-sample pass of odd spline orders costs ("tap_fix": k_tap_scan before the sweep, wcslib's
+chain on the host for the listed samples, k_tap_fix after it) on cfg2 -- 2048^2 image against the sub-map of a 3072^2
+reference, helioprojective, 61 x 61 CRVAL lags -- for orders 1 and 3, with the scene's header as it is and with a roll of
+3 degrees (an unrotated header brings whole curves of coordinates back onto integers for pure CRVAL1 / CRVAL2 lags).
+usage: python profiles/tap_fix_timing.py       -> one JSON line per case"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from euispice_coreg_amd import _lib, synthetic  # noqa: E402
+
+
+def main():
+    h = _lib.CoregHandle(0)
+    small, hs, large, hl, _ = synthetic.make_scene()
+    lags = _lib.LagSet(np.arange(-30, 31, 1.0), np.arange(-30, 31, 1.0), None, None, None)
+    for roll in (None, 3.0):
+        hdr = dict(hs)
+        if roll is not None:
+            rho, lam = np.deg2rad(roll), hdr["CDELT2"] / hdr["CDELT1"]
+            hdr.update(CROTA=roll, PC1_1=float(np.cos(rho)), PC2_2=float(np.cos(rho)), PC1_2=float(-lam * np.sin(rho)),
+                       PC2_1=float(np.sin(rho) / lam))
+        for order in (1, 3, 2):
+            h.set_small(small)
+            h.prepare_reference_helioprojective(large, hl, hdr, order)
+            out = {}
+            for fix in (0, 1):
+                h.set_option("tap_fix", fix)
+                h.sweep_helioprojective(hdr, hdr, lags, order=order)
+                best = 1e9
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    out[fix] = h.sweep_helioprojective(hdr, hdr, lags, order=order)
+                    best = min(best, time.perf_counter() - t0)
+                res = {"header_crota": hdr.get("CROTA", 0.0), "order": order, "tap_fix": fix, "sweep_ms": round(best * 1e3, 2),
+                       "kernel_ms": round(h.last_stats()["sweep_kernel_ms"], 2)}
+                if fix:
+                    res.update(h.last_tap_fix())
+                    d = np.abs(out[1] - out[0])
+                    res["lag_points_changed"] = int((d > 0).sum())
+                    res["largest_change"] = float(np.nanmax(d))
+                print(json.dumps(res), flush=True)
+    h.close()
+
+
+if __name__ == "__main__":
+    main()
