@@ -20,9 +20,9 @@ def main():
     h = _lib.CoregHandle(0)
     small, hs, large, hl, _ = synthetic.make_scene()
     lags = _lib.LagSet(np.arange(-30, 31, 1.0), np.arange(-30, 31, 1.0), None, None, None)
-    for roll in (None, 3.0):
+    for roll in (0.0, 3.0):
         hdr = dict(hs)
-        if roll is not None:
+        if True:
             rho, lam = np.deg2rad(roll), hdr["CDELT2"] / hdr["CDELT1"]
             hdr.update(CROTA=roll, PC1_1=float(np.cos(rho)), PC2_2=float(np.cos(rho)), PC1_2=float(-lam * np.sin(rho)),
                        PC2_1=float(np.sin(rho) / lam))

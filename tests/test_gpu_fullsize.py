@@ -324,11 +324,19 @@ def test_zero_lag_order1_full_size_follows_wcslib_taps(gpu_handle, big_scene):
     assert O._wcstan_lib() is not None, "oracle/_build/liboracle_wcstan.so missing: run __graft_entry__.build()"
     lags = (np.array([0.0, 17.0]), np.array([-9.0, 0.0]), None, None, None)
     got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=1)[..., 0, 0, 0, 0]
-    gpu_handle.set_option("border_fix", 0)  # exact identity map for the zero lag: no wcslib decision at all
+    gpu_handle.set_option("border_fix", 0)  # exact identity map for the zero lag ...
     try:
+        # ... which the general pass of odd orders ("tap_fix": every sample within 1e-8 px of an integer re-evaluated with
+        # wcslib's chain, here all 4 194 304 of the zero lag) then decides by itself, to the same coefficient
+        general = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=1, prepare=False)[..., 0, 0, 0, 0]
+        tf = gpu_handle.last_tap_fix()
+        gpu_handle.set_option("tap_fix", 0)  # no wcslib decision at all
         raw = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=1, prepare=False)[..., 0, 0, 0, 0]
     finally:
         gpu_handle.set_option("border_fix", 1)
+        gpu_handle.set_option("tap_fix", 1)
+    assert not tf["overflow"] and tf["samples"] > 4_000_000 and abs(general[0, 1] - got[0, 1]) < 1e-9
+    assert np.array_equal(np.delete(general.ravel(), 1), np.delete(got.ravel(), 1))
     st = H.oracle_state(small, hs, large, hl, lags, order=1)
     O.set_initial_header_values(st)
     sub = O.create_submap_of_large_data(st)
