@@ -68,3 +68,32 @@ def test_fuzz_helioprojective(gpu_handle, seed):
     want = H.oracle_helio(small, hs, large, hl, lags, order=order, parallelism=not serial)
     got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order, serial_semantics=serial)
     H.assert_corr_close(got, want, 1e-7, f"fuzz helio seed={seed} serial={serial}")
+
+
+@pytest.mark.parametrize("seed, scale, orders, forms, before", [(80463, 1, [1, 2], False, 6.8e-6), (160089, 3, [1, 2, 3], True, 7.3e-7)])
+def test_single_samples_decided_by_wcslib_noise(gpu_handle, seed, scale, orders, forms, before):
+    """The two cases the long fuzz runs of rounds 3 and 4 met above the helioprojective tolerance: an odd
+    spline order, an unrotated header and a pure CRVAL2 / CRVAL1 lag bring a curve of coordinates back within 1e-10 px of
+    integers, where wcslib's rounding noise picks the taps -- hence which neighbour's NaN poisons the sample.  The general
+    pass of odd orders ("tap_fix": k_tap_scan, wcslib's chain on the host, k_tap_fix) re-evaluates exactly those samples:
+    within the tolerance now, and the documented deviation is back when the pass is switched off."""
+    from tests import deep_fuzz as DF
+    c = DF.build_case(seed, scale, orders, forms)
+    assert c["frame"] == "helio" and c["order"] in (1, 3) and c["hs"]["CROTA"] == 0.0
+    sem = 0 if c["sem"] == "intended" else 1
+    want = H.oracle_helio(c["small"], c["hs"], c["large"], c["hl"], c["lags"], order=c["order"], parallelism=not c["serial"],
+                          cdelt_semantics=c["sem"])
+    got = H.gpu_helio(gpu_handle, c["small_up"], c["hs"], c["large_up"], c["hl"], c["lags"], order=c["order"],
+                      serial_semantics=c["serial"], cdelt_semantics=sem)
+    tf = gpu_handle.last_tap_fix()
+    H.assert_corr_close(got, want, 1e-7, f"seed={seed}")
+    assert np.nanmax(np.abs(got - want)) < 1e-9 and tf["samples"] > 100 and not tf["overflow"]
+    gpu_handle.set_option("tap_fix", 0)
+    try:
+        raw = H.gpu_helio(gpu_handle, c["small_up"], c["hs"], c["large_up"], c["hl"], c["lags"], order=c["order"],
+                          serial_semantics=c["serial"], cdelt_semantics=sem)
+    finally:
+        gpu_handle.set_option("tap_fix", 1)
+    assert gpu_handle.last_tap_fix()["samples"] == 0
+    assert 0.5 * before < np.nanmax(np.abs(raw - want)) < 2.0 * before
+    assert (np.abs(raw - got) > 0).sum() <= 4  # (the lag-point concerned, and its no-op CDELT1 twin)
