@@ -46,6 +46,23 @@ def main():
                     res["lag_points_changed"] = int((d > 0).sum())
                     res["largest_change"] = float(np.nanmax(d))
                 print(json.dumps(res), flush=True)
+    # serial semantics (parallelism=False: the target is the reference's own, coarser grid -- every 64-pixel segment of
+    # the scan spans many integers and is tested pixel by pixel)
+    hdr = dict(hs)
+    h.set_small(small)
+    h.set_reference_on_grid(np.asarray(large, dtype=np.float64))
+    lags21 = _lib.LagSet(np.arange(-10, 11, 1.0), np.arange(-10, 11, 1.0), None, None, None)
+    for order in (1, 3):
+        for fix in (0, 1):
+            h.set_option("tap_fix", fix)
+            h.sweep_helioprojective(hl, hdr, lags21, order=order)
+            t0 = time.perf_counter()
+            h.sweep_helioprojective(hl, hdr, lags21, order=order)
+            res = {"semantics": "serial (target = the 3072^2 reference grid)", "lags": lags21.size, "order": order, "tap_fix": fix,
+                   "sweep_ms": round((time.perf_counter() - t0) * 1e3, 2), "kernel_ms": round(h.last_stats()["sweep_kernel_ms"], 2)}
+            if fix:
+                res.update(h.last_tap_fix())
+            print(json.dumps(res), flush=True)
     h.close()
 
 
