@@ -1467,7 +1467,7 @@ int upload_border_pixels(coreg_handle* h, const std::vector<int>& pixels) {
 // under an unrotated header at full size) is not applied at all -- recorded in tap_last, coreg_last_tap_fix.
 template <typename ShiftedOf>
 int prepare_tap_fix(coreg_handle* h, int sweep_mode, const coreg_wcs2d& target, long long n_slots,
-                    const std::vector<unsigned char>& skip, ShiftedOf shifted_of, BorderFix* fix) {
+                    const std::vector<unsigned char>& skip, const double box[4], ShiftedOf shifted_of, BorderFix* fix) {
     const unsigned cap = (unsigned)h->opt_tap_cap;
     HIPCHK(h->tap_count.reserve(sizeof(unsigned)));
     HIPCHK(h->tap_list.reserve((size_t)cap * sizeof(uint2)));
@@ -1488,10 +1488,18 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, const coreg_wcs2d& target, 
     a.count = h->tap_count.as<unsigned>();
     a.list = h->tap_list.as<uint2>();
     a.cap = cap;
+    // the sweep's cull box (target pixels that can map into the image for some lag, 3 px of margin): [x0, x1, y0, y1]
+    a.i_lo = (int)std::max(0.0, std::min((double)h->gW, box[0]));
+    a.i_hi = (int)std::min((double)(h->gW - 1), std::max(-1.0, box[1]));
+    a.j_lo = (int)std::max(0.0, std::min((double)h->gH, box[2]));
+    a.j_hi = (int)std::min((double)(h->gH - 1), std::max(-1.0, box[3]));
+    h->tap_last[0] = h->tap_last[1] = h->tap_last[2] = 0;
+    if (a.i_hi < a.i_lo || a.j_hi < a.j_lo) return COREG_OK;
+    const int n_rows = a.j_hi - a.j_lo + 1;
     const unsigned gx = (unsigned)((n_slots + 255) / 256);
-    const unsigned gy = (unsigned)std::max(1, std::min(h->gH, (int)(4096 / std::max(1u, gx))));
-    a.rows_per_block = (h->gH + (int)gy - 1) / (int)gy;
-    const dim3 grid(gx, (unsigned)((h->gH + a.rows_per_block - 1) / a.rows_per_block));
+    const unsigned gy = (unsigned)std::max(1, std::min(n_rows, (int)(4096 / std::max(1u, gx))));
+    a.rows_per_block = (n_rows + (int)gy - 1) / (int)gy;
+    const dim3 grid(gx, (unsigned)((n_rows + a.rows_per_block - 1) / a.rows_per_block));
     if (sweep_mode == MODE_HOMOGRAPHY_SERIES)
         hipLaunchKernelGGL((k_tap_scan<MODE_HOMOGRAPHY_SERIES>), grid, dim3(256), 0, h->stream, a);
     else
@@ -2977,9 +2985,10 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     }
     RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles, pick_groups(h, n_batches, n_tiles), n_batches));
     h->tap_last[0] = h->tap_last[1] = h->tap_last[2] = 0;
+    const double tap_box[4] = {pa.f0lo, pa.f0hi, pa.f1lo, pa.f1hi};
     if (tap_fixing)
         RETCHK(prepare_tap_fix(
-            h, sweep_mode, *hdr_target, (long long)ns, tap_skip,
+            h, sweep_mode, *hdr_target, (long long)ns, tap_skip, tap_box,
             [&](int slot) {
                 coreg_wcs2d hl = tap_combo[(size_t)tap_slot_combo[(size_t)slot]];
                 hl.crval1 = hdr_small->crval1 + lags->crval1[tap_slot_i1[(size_t)slot]];

@@ -1935,6 +1935,7 @@ struct TapScanArgs {
     uint2* list;                // [cap] {slot, linear grid index}
     unsigned int cap;
     int rows_per_block;
+    int i_lo, i_hi, j_lo, j_hi;  // (inclusive) the cull box of the sweep: no pixel outside it maps into the image
 };
 // One thread per (lag slot, grid row).  Along a row the mapped coordinate is x(i) = (a i + b) / (c i + d): the offsets
 // x - i and y - j are evaluated at the ends of 64-pixel segments and bounded in between by the chord plus
@@ -1951,8 +1952,8 @@ __global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) hm.h[k] = a.hom[(long long)k * a.n_slots + slot];
     LaunchU cu = {};
-    const int j0 = blockIdx.y * a.rows_per_block, j1 = min(j0 + a.rows_per_block, a.gh);
-    const double last = (double)(a.gw - 1);
+    const int j0 = a.j_lo + blockIdx.y * a.rows_per_block, j1 = min(j0 + a.rows_per_block, a.j_hi + 1);
+    const double last = (double)a.i_hi;
     for (int j = j0; j < j1; ++j) {
         const double dj = (double)j;
         // bound of |f''| along the row, for x and for y (NaN maps fail every comparison below: nothing is listed)
@@ -1967,9 +1968,9 @@ __global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
         const double bulge_y = 1.25 * f2y * (double)(L * L) / 8.0 + 1e-12 + a.tol;
         const bool sane = dmin > 0.5 && bulge_x < 0.25 && bulge_y < 0.25;  // else: every segment is tested
         double x0, y0;
-        apply_map<MODE>(hm, cu, 0.0, dj, x0, y0);
-        for (int i0 = 0; i0 < a.gw; i0 += L) {
-            const int i1 = min(i0 + L, a.gw - 1);
+        apply_map<MODE>(hm, cu, (double)a.i_lo, dj, x0, y0);
+        for (int i0 = a.i_lo; i0 <= a.i_hi; i0 += L) {
+            const int i1 = min(i0 + L, a.i_hi);
             double x1, y1;
             apply_map<MODE>(hm, cu, (double)i1, dj, x1, y1);
             const double fx0 = x0 - (double)i0, fx1 = x1 - (double)i1, fy0 = y0 - dj, fy1 = y1 - dj;
@@ -1979,7 +1980,7 @@ __global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
             // fail the range test one by one)
             const bool hit = !sane || !(ceil(xlo) > xhi) || !(ceil(ylo) > yhi);
             if (hit) {
-                const int iend = (i0 + L >= a.gw) ? a.gw : i1;  // (the shared end point belongs to the next segment)
+                const int iend = (i0 + L > a.i_hi) ? a.i_hi + 1 : i1;  // (the shared end point belongs to the next segment)
                 for (int i = i0; i < iend; ++i) {
                     const long long idx = (long long)j * a.gw + i;
                     const double araw = a.ref_f32 ? (double)((const float*)a.ref)[idx] : ((const double*)a.ref)[idx];
