@@ -261,7 +261,9 @@ class CompressedImage:
         self.zbitpix = int(th["ZBITPIX"])
         self.shape = (int(th["ZNAXIS2"]), int(th["ZNAXIS1"]))
         self.ztile = (int(th.get("ZTILE1", self.shape[1])), int(th.get("ZTILE2", 1)))
-        self.cmptype = str(th["ZCMPTYPE"]).strip()
+        self.cmptype = str(th["ZCMPTYPE"]).strip().upper()
+        if self.cmptype == "RICE_ONE":  # (the name early cfitsio versions wrote; cfitsio reads both)
+            self.cmptype = "RICE_1"
         params = {str(th["ZNAME%d" % i]).strip(): th["ZVAL%d" % i] for i in range(1, 20) if "ZNAME%d" % i in th}
         self.blocksize = int(params.get("BLOCKSIZE", 32))
         self.bytepix = int(params.get("BYTEPIX", 4))
