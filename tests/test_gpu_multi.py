@@ -324,3 +324,35 @@ def test_multi_helioprojective_and_plate_carree_3d_lag_sets(gpu_handle, monkeypa
         gotc = m.sweep_helioprojective(chl, chs, cls)
         assert m.last_mode == "combos"
         assert np.array_equal(np.isnan(gotc), np.isnan(wantc)) and np.nanmax(np.abs(gotc - wantc)) <= 1e-12
+
+
+def test_multi_odd_order_noise_decided_samples(gpu_handle, monkeypatch):
+    """An odd spline order under an unrotated header, lag axes through 0 (pure CRVAL1 and pure CRVAL2 lags bring curves of
+    coordinates back onto integers; the zero lag, its whole grid): every device re-evaluates the noise-decided samples of
+    its own lag-points with wcslib's chain ("tap_fix"), and -- in the grid-share mode -- device 0 carries the
+    correction for all.  Same map as the single handle, and the oracle's."""
+    from euispice_coreg_amd import _lib
+    monkeypatch.setenv("COREG_VIRTUAL_DEVICES", "3")
+    small, hs, large, hl, _ = H.scene(nan_frac=0.02)
+    hs = dict(hs, CROTA=0.0, PC1_1=1.0, PC1_2=0.0, PC2_1=0.0, PC2_2=1.0)
+    for order, lags in ((1, (np.arange(-6.0, 7.0, 3.0), np.arange(-4.0, 5.0, 2.0), None, None, [0.0, 0.3])),
+                        (3, (np.array([0.0, 2.5]), np.array([0.0]), None, None, None))):  # (2 lag-points: grid shares)
+        want = H.oracle_helio(small, hs, large, hl, lags, order=order)
+        single = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order)
+        assert gpu_handle.last_tap_fix()["samples"] > 0
+        H.assert_corr_close(single, want, 1e-7, f"single handle, order {order}")
+        ls = _lib.LagSet(*lags)
+        with _lib.MultiHandle() as m:
+            m.set_small(small)
+            m.prepare_reference_helioprojective(large, hl, hs, order)
+            modes = set()
+            for force in ((-1, 1, 4, 2) if ls.size > 2 else (-1,)):
+                m.set_option("force_mode", force)
+                got = m.sweep_helioprojective(hs, hs, ls, order=order).reshape(single.shape)
+                modes.add(m.last_mode)
+                assert np.array_equal(np.isnan(got), np.isnan(single))
+                assert np.nanmax(np.abs(got - single)) <= 1e-12, (order, m.last_mode)
+                H.assert_corr_close(got, want, 1e-7, f"{m.last_mode}, order {order}")
+            m.set_option("force_mode", -1)
+            assert "points" in modes  # (the planner's choice for lag sets this small: device 0 carries the correction)
+            assert ls.size <= 2 or {"blocks", "combos", "slices"} <= modes
