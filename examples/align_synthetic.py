@@ -5,7 +5,9 @@ and an FSI-like reference as FITS files, align them exactly as with euispice_cor
 print the recovered shift and write the corrected FITS.  Needs an MI355X and the built library
 (python -c "import __graft_entry__ as g; g.build()").
 
-    python examples/align_synthetic.py [size]      # size of the small image, default 1024
+    python examples/align_synthetic.py [size] [--compressed]   # size of the small image, default 1024;
+                                                               # --compressed: the image to align is written the way
+                                                               # EUI files are (Rice-compressed tiles, decoded on the GPU)
 """
 import os
 import sys
@@ -22,11 +24,16 @@ from euispice_coreg_amd.utils import fits_io  # noqa: E402
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n = int(args[0]) if args else 1024
     d = tempfile.mkdtemp(prefix="coreg_example_")
     small, hs, large, hl, truth = synthetic.make_scene(small_n=n, large_n=3 * n // 2)
     path_hri, path_fsi = os.path.join(d, "hri.fits"), os.path.join(d, "fsi.fits")
-    fits_io.write_images(path_hri, [(None, {}), (small.astype(np.float32), hs)])
+    if "--compressed" in sys.argv:
+        info = fits_io.write_compressed_image(path_hri, small.astype(np.float32), hs, quantize="SUBTRACTIVE_DITHER_2")
+        print(f"image to align: tile-compressed, {info['compressed_bytes'] / small.size:.2f} bytes per pixel")
+    else:
+        fits_io.write_images(path_hri, [(None, {}), (small.astype(np.float32), hs)])
     fits_io.write_images(path_fsi, [(None, {}), (large.astype(np.float32), hl)])
     print(f"injected pointing error: CRVAL ({truth['lag_crval1']}, {truth['lag_crval2']}) arcsec, "
           f"CROTA {truth['lag_crota']} deg")
