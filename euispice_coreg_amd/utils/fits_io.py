@@ -55,6 +55,7 @@ def _parse_value(s: str):
 def _read_header(f):
     hdr = Header()
     raw = b""
+    last_key = None
     while True:
         block = f.read(BLOCK)
         if len(block) < BLOCK:
@@ -69,9 +70,19 @@ def _read_header(f):
             if key == "END":
                 done = True
                 break
+            if key == "CONTINUE" and last_key is not None:
+                # the long-string convention: a string value ending in '&' goes on in the next card's string
+                prev = hdr.get(last_key)
+                if isinstance(prev, str) and prev.endswith("&"):
+                    part = _parse_value(card[8:])
+                    hdr[last_key] = prev[:-1] + (part if isinstance(part, str) else "")
+                    continue
             if not key or key in ("COMMENT", "HISTORY") or card[8:10] != "= ":
+                if key:
+                    last_key = None
                 continue
             hdr[key] = _parse_value(card[10:])
+            last_key = key
         if done:
             break
     return hdr, raw
@@ -597,6 +608,20 @@ def _card(key, value):
         body = ""
     else:
         sv = str(value).replace("'", "''")
+        if len(sv) > 68:
+            # the long-string convention (CONTINUE cards): chunks of at most 67 characters + '&', cut so that a doubled
+            # quote is never split
+            chunks = []
+            while len(sv) > 68:
+                cut = 67
+                if (cut - len(sv[:cut].rstrip("'"))) % 2 == 1:  # (quotes are doubled: an odd run would split a pair)
+                    cut -= 1
+                chunks.append(sv[:cut] + "&")
+                sv = sv[cut:]
+            chunks.append(sv)
+            cards = [f"{key:<8}= '{chunks[0]}'".ljust(80)]
+            cards += [f"CONTINUE  '{c}'".ljust(80) for c in chunks[1:]]
+            return "".join(cards)
         body = "'" + f"{sv:<8}" + "'"
     return f"{key:<8}= {body}"[:80].ljust(80)
 

@@ -458,3 +458,33 @@ def test_write_corrected_fits_copies_data_units_and_rewrites_only_the_selected_h
     assert fits_io._scan(out)[0][1]["CRVAL1"] == pytest.approx(hs["CRVAL1"] + 2 * R.shift_arcsec[0], rel=1e-13)
     with pytest.raises(ValueError):
         R.write_corrected_fits(["no-such-window"], out)
+
+
+def test_long_string_keywords_follow_the_continue_convention(tmp_path):
+    """Instrument headers carry strings longer than a card (lists of parent files, processing history): the FITS
+    long-string convention -- a value ending in '&' goes on in the CONTINUE cards that follow.  Read whole, written back as
+    CONTINUE cards, and carried verbatim through write_corrected_fits (which copies every card it does not correct)."""
+    from euispice_coreg_amd.hdrshift import AlignmentResults
+    from euispice_coreg_amd.utils import fits_io
+    from tests.test_oracle_golden import REF_CORR
+    rng = np.random.default_rng(0)
+    p = str(tmp_path / "l.fits")
+    for t in range(60):
+        v = "".join(rng.choice(list("ab '&/=,"), size=int(rng.integers(60, 400)))).rstrip()
+        v = v + "x" if v.endswith("&") or not v else v
+        hdr = {"CRVAL1": 1.0, "LONGSTR": v, "AMPERSND": "ends with &", "AFTER": 7}
+        fits_io.write_images(p, [(None, {}), (np.zeros((2, 2), np.float32), hdr)])
+        h = fits_io.read_header(p, -1)
+        assert h["LONGSTR"] == v and h["AFTER"] == 7 and h["AMPERSND"] == "ends with &"
+        raw = open(p, "rb").read()
+        assert len(raw) % 2880 == 0 and (len(v.replace("'", "''")) <= 68 or b"CONTINUE  '" in raw)
+    parents = ", ".join(f"solo_L1_eui-hrieuv174-image_20220317T0950{k:02d}277_V01.fits" for k in range(6))
+    hdr = {"CRVAL1": 10.0, "CRVAL2": 20.0, "CDELT1": 0.5, "CDELT2": 0.5, "CROTA": 0.0, "CUNIT1": "arcsec", "CUNIT2": "arcsec",
+           "CRPIX1": 3.0, "CRPIX2": 3.0, "PARENT": parents, "PC1_1": 1.0, "PC1_2": 0.0, "PC2_1": 0.0, "PC2_2": 1.0}
+    src, dst = str(tmp_path / "in.fits"), str(tmp_path / "out.fits")
+    fits_io.write_images(src, [(None, {}), (np.ones((6, 6), np.float32), hdr)])
+    R = AlignmentResults(REF_CORR, np.arange(15, 26, 1), np.arange(5, 11, 1), None, [0], [0], "arcsec", image_to_align_path=src)
+    R.write_corrected_fits([-1], dst)
+    h = fits_io.read_header(dst, -1)
+    assert h["PARENT"] == parents and h["CRVAL1"] == pytest.approx(10.0 + R.shift_arcsec[0])
+    assert open(dst, "rb").read().count(b"CONTINUE  '") == open(src, "rb").read().count(b"CONTINUE  '") > 0
