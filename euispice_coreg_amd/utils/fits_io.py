@@ -798,7 +798,16 @@ def _patch_header(raw, updates):
     for i, c in enumerate(cards):
         key = c[:8].decode("ascii", "replace").strip()
         if key in left and c[8:10] == b"= ":
-            cards[i] = _card(key, left.pop(key)).encode("ascii")
+            new = _card(key, left.pop(key))
+            # keep the card's comment (astropy's header update does): numeric and logical values only -- a '/' inside a
+            # string value is not a comment
+            old_txt = c.decode("ascii", "replace")
+            if len(new) == 80 and "'" not in old_txt[10:] and " /" in old_txt[10:]:
+                comment = old_txt[10:].split("/", 1)[1].rstrip()
+                body = new.rstrip()
+                if len(body) + 3 + len(comment) <= 80:
+                    new = (body + " /" + comment).ljust(80)
+            cards[i] = new.encode("ascii")
     cards += [_card(k, v).encode("ascii") for k, v in left.items()]
     blob = b"".join(cards) + b"END".ljust(80)
     return blob + b" " * ((-len(blob)) % BLOCK)

@@ -122,6 +122,12 @@ def test_write_corrected_fits_keeps_the_compressed_stream_and_patches_the_header
     for k in ("ZCMPTYPE", "ZTILE1", "TFORM1", "ZDITHER0", "NAXIS1", "PCOUNT"):
         assert h_out[1][k] == h_in[1][k]
     assert b"/ compression algorithm" in b[2880:sp_out[1][0]]
+    # the corrected cards keep their own comments too (astropy's header update does)
+    for card in (a[2880 + i:2880 + i + 80] for i in range(0, sp_in[1][0] - 2880, 80)):
+        if card[:8].rstrip() in (b"CRVAL1", b"CRVAL2") and b" /" in card[10:]:
+            comment = card[10:].split(b"/", 1)[1].rstrip()
+            assert any(o[:8] == card[:8] and o.rstrip().endswith(comment)
+                       for o in (b[2880 + i:2880 + i + 80] for i in range(0, sp_out[1][0] - 2880, 80)))
     assert R.return_corrected_header(-1)["CRVAL1"] == hdr["CRVAL1"]
 
 
