@@ -788,12 +788,75 @@ def _copy_range(fi, fo, pos, n):
             left -= len(chunk)
 
 
-def _patch_header(raw, updates):
+def _sum32(buf, start=0):
+    """The FITS checksum accumulator (FITS standard 4.0, appendix J): big-endian 32-bit words added in ones' complement
+    arithmetic (end-around carry).  `buf`: bytes-like, a multiple of 4 long."""
+    a = np.frombuffer(buf, dtype=">u4")
+    total = int(start) + int(a.sum(dtype=np.uint64)) if a.size else int(start)
+    while total >> 32:
+        total = (total & 0xFFFFFFFF) + (total >> 32)
+    return total
+
+
+def _encode_checksum(total):
+    """The 16 characters of a CHECKSUM card for an HDU whose words (with the card's value set to sixteen '0') add up to
+    `total`: the complement, one byte per four ASCII characters, punctuation avoided, rotated one place to the right
+    because the value starts at column 12 of its card (cfitsio `ffesum`, appendix J of the standard)."""
+    value = 0xFFFFFFFF - total
+    exclude = (0x3A, 0x3B, 0x3C, 0x3D, 0x3E, 0x3F, 0x40, 0x5B, 0x5C, 0x5D, 0x5E, 0x5F, 0x60)
+    asc = [0] * 16
+    for ii in range(4):
+        byte = (value >> (24 - 8 * ii)) & 0xFF
+        ch = [byte // 4 + 0x30] * 4
+        ch[0] += byte % 4
+        check = True
+        while check:
+            check = False
+            for ex in exclude:
+                for jj in (0, 2):
+                    if ch[jj] == ex or ch[jj + 1] == ex:
+                        ch[jj] += 1
+                        ch[jj + 1] -= 1
+                        check = True
+        for jj in range(4):
+            asc[4 * jj + ii] = ch[jj]
+    return "".join(chr(asc[(ii + 15) % 16]) for ii in range(16))
+
+
+def _refresh_checksum(blob, datasum=None):
+    """A header (bytes, whole blocks) whose CHECKSUM card -- when it has one -- is made valid again for this header and a
+    data unit whose words add up to `datasum` (default: what the header's own DATASUM card says; a header without that card
+    is returned unchanged unless `datasum` is given).  A DATASUM card is rewritten when `datasum` is given."""
+    cards = [blob[i:i + 80] for i in range(0, len(blob), 80)]
+    ic = next((i for i, c in enumerate(cards) if c[:9] == b"CHECKSUM="), None)
+    idat = next((i for i, c in enumerate(cards) if c[:9] == b"DATASUM ="), None)
+    if datasum is not None and idat is not None:
+        comment = cards[idat].decode("ascii", "replace")[10:].split("/", 1)
+        comment = " /" + comment[1].rstrip() if len(comment) > 1 and "'" not in comment[1] else ""
+        cards[idat] = (f"DATASUM = '{int(datasum):<10d}'" + comment)[:80].ljust(80).encode("ascii")
+    if ic is None:
+        return b"".join(cards)
+    if datasum is None:
+        if idat is None:
+            return blob
+        try:
+            datasum = int(_parse_value(cards[idat].decode("ascii", "replace")[10:]))
+        except (TypeError, ValueError):
+            return blob
+    tail = cards[ic][29:]  # (the comment: "/ HDU checksum updated ...")
+    cards[ic] = b"CHECKSUM= '0000000000000000'" + b" " + tail if len(tail) == 51 else (b"CHECKSUM= '0000000000000000'").ljust(80)
+    total = _sum32(b"".join(cards), start=datasum)
+    cards[ic] = cards[ic][:11] + _encode_checksum(total).encode("ascii") + cards[ic][27:]
+    return b"".join(cards)
+
+
+def _patch_header(raw, updates, remove=()):
     """The header blocks `raw` (bytes, END card included) with the cards of `updates` (key -> value) replaced in place,
-    new keys inserted before END; every other card -- comments, table structure, compression keywords -- untouched."""
+    new keys inserted before END, the cards of `remove` taken out; every other card -- comments, HISTORY, table
+    structure, compression keywords -- untouched."""
     cards = [raw[i:i + 80] for i in range(0, len(raw), 80)]
     end = next(i for i, c in enumerate(cards) if c[:8].rstrip() == b"END")
-    cards = cards[:end]
+    cards = [c for c in cards[:end] if not (c[8:10] == b"= " and c[:8].decode("ascii", "replace").strip() in remove)]
     left = dict(updates)
     for i, c in enumerate(cards):
         key = c[:8].decode("ascii", "replace").strip()
@@ -854,7 +917,8 @@ def rewrite_with_corrected_headers(path_in, path_out, is_selected, correct):
                     # compressed stream keeps the original pixels.)
                     changed = {k: v for k, v in hdr.items() if k not in before or before[k] != v or
                                type(before[k]) is not type(v)}
-                    fo.write(_patch_header(raw_hdr, changed))
+                    # (the table and its heap are the input's: DATASUM still holds, CHECKSUM is made valid again)
+                    fo.write(_refresh_checksum(_patch_header(raw_hdr, changed)))
                     _copy_range(fi, fo, data_pos, min(padded, size - data_pos))
                     if data_pos + padded > size:
                         fo.write(b"\0" * (data_pos + padded - size))
@@ -862,10 +926,13 @@ def rewrite_with_corrected_headers(path_in, path_out, is_selected, correct):
                 if not is_image:
                     raise NotImplementedError("only image HDUs (plain or tile-compressed) can be corrected")
                 f32 = int(hdr["BITPIX"]) == -32 and hdr.get("BSCALE", 1) == 1 and hdr.get("BZERO", 0) == 0
+                changed = {k: v for k, v in hdr.items() if k not in before or before[k] != v or type(before[k]) is not type(v)}
+                gone = tuple(k for k in before if k not in hdr)
                 if nbytes == 0:
-                    fo.write(_header_blob(i, 8, (), hdr))
+                    fo.write(_refresh_checksum(_patch_header(raw_hdr, changed, gone)))
                 elif f32 and int(hdr.get("GCOUNT", 1)) == 1 and int(hdr.get("PCOUNT", 0)) == 0:
-                    fo.write(_header_blob(i, -32, shape, hdr))
+                    # the header keeps every card it had (comments, HISTORY, long strings); only the corrected ones change
+                    fo.write(_refresh_checksum(_patch_header(raw_hdr, changed, gone)))
                     if data_pos + padded <= size:
                         _copy_range(fi, fo, data_pos, padded)
                     else:  # a file without its final padding
@@ -873,10 +940,13 @@ def rewrite_with_corrected_headers(path_in, path_out, is_selected, correct):
                         fo.write(b"\0" * (padded - nbytes))
                 else:
                     fi.seek(data_pos)
-                    data = np.array(_decode(hdr, fi.read(nbytes), nbytes, shape), dtype="<f4")
-                    fo.write(_header_blob(i, -32, shape, hdr))
+                    data = np.array(_decode(before, fi.read(nbytes), nbytes, shape), dtype="<f4")
                     raw = data.astype(">f4").tobytes()
-                    fo.write(raw + b"\0" * ((-len(raw)) % BLOCK))
+                    raw += b"\0" * ((-len(raw)) % BLOCK)
+                    changed["BITPIX"] = -32
+                    blob = _patch_header(raw_hdr, changed, gone + ("BSCALE", "BZERO", "BLANK"))
+                    fo.write(_refresh_checksum(blob, datasum=_sum32(raw) if b"DATASUM =" in blob or b"CHECKSUM=" in blob else None))
+                    fo.write(raw)
     if final is not None:
         os.replace(path_out, final)
     return n_corrected

@@ -488,3 +488,58 @@ def test_long_string_keywords_follow_the_continue_convention(tmp_path):
     h = fits_io.read_header(dst, -1)
     assert h["PARENT"] == parents and h["CRVAL1"] == pytest.approx(10.0 + R.shift_arcsec[0])
     assert open(dst, "rb").read().count(b"CONTINUE  '") == open(src, "rb").read().count(b"CONTINUE  '") > 0
+
+
+def test_write_corrected_fits_leaves_valid_checksums(tmp_path):
+    """CHECKSUM / DATASUM (FITS standard 4.0, appendix J).  The fixture was written by astropy 4.3.1 with checksum=True
+    (tests/golden/make_golden_checksum.py, which also had astropy verify the corrected file this package writes from it):
+    every plain HDU of it adds up to -0 under the package's accumulator and its DATASUM card is the sum of its data unit
+    -- that pins `_sum32` / `_encode_checksum` -- and the corrected file keeps that property: the header changed, the
+    float32 data unit is the input's (DATASUM kept), the unsigned-16 one became float32 (DATASUM recomputed).  The
+    reference, like astropy's default, leaves the stale cards of the input behind."""
+    from euispice_coreg_amd.hdrshift import AlignmentResults
+    from euispice_coreg_amd.utils import fits_io
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checksum", "three_hdus_checksum.fits")
+
+    def hdus(path):
+        raw = open(path, "rb").read()
+        out = []
+        with open(path, "rb") as f:
+            while True:
+                start = f.tell()
+                h, _ = fits_io._read_header(f)
+                if h is None:
+                    break
+                n, _shape = fits_io._data_size(h)
+                pos, pad = f.tell(), (n + 2879) // 2880 * 2880
+                f.seek(pad, 1)
+                out.append((h, fits_io._sum32(raw[start:pos + pad]), fits_io._sum32(raw[pos:pos + pad]), raw[start:pos]))
+        return out
+
+    before = hdus(src)
+    assert [h.get("EXTNAME") for h, *_ in before] == [None, "F32", "U16", "RICE"]
+    for h, total, dsum, _ in before[:3]:
+        assert total == 0xFFFFFFFF and int(h["DATASUM"]) == dsum
+    corr = np.zeros((5, 5, 1, 1, 1, 1))
+    corr[2, 3] = 1.0
+    lag = np.arange(-2.0, 3.0)
+    R = AlignmentResults(corr, lag, lag, None, [0], [0.5], "arcsec", image_to_align_path=src)
+    dst = str(tmp_path / "corrected.fits")
+    R.write_corrected_fits([1, 2, 3], dst)
+    after = hdus(dst)
+    for k in (0, 1, 2):
+        h, total, dsum, raw_hdr = after[k]
+        assert total == 0xFFFFFFFF and int(h["DATASUM"]) == dsum, h.get("EXTNAME")
+    assert after[1][2] == before[1][2] and after[2][2] != before[2][2] and after[2][0]["BITPIX"] == -32
+    assert after[1][0]["CHECKSUM"] != before[1][0]["CHECKSUM"] and after[1][0]["CRVAL1"] != before[1][0]["CRVAL1"]
+    # comments, HISTORY and the checksum card's own comment survive the correction
+    assert b"/ [arcsec] reference value" in after[1][3] and b"HISTORY made for the checksum test" in after[1][3]
+    assert b"/ HDU checksum updated" in after[1][3]
+    # the tile-compressed HDU: astropy 4.3.1 wrote cards that do not describe the bytes on disk; they are kept as
+    # consistent as they were (header + DATASUM card add up the same way), the compressed stream is the input's
+    assert after[3][2] == before[3][2]
+    hb, ha = before[3][0], after[3][0]
+    assert ha["DATASUM"] == hb["DATASUM"] and ha["CRVAL1"] != hb["CRVAL1"]
+    assert fits_io._sum32(after[3][3], start=int(ha["DATASUM"])) == fits_io._sum32(before[3][3], start=int(hb["DATASUM"]))
+    d, _ = fits_io.read_image(dst, "RICE")
+    assert np.array_equal(d, fits_io.read_image(src, "RICE")[0])
