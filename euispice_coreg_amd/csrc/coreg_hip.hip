@@ -1468,11 +1468,13 @@ int upload_border_pixels(coreg_handle* h, const std::vector<int>& pixels) {
 template <typename ShiftedOf>
 int prepare_tap_fix(coreg_handle* h, int sweep_mode, const coreg_wcs2d& target, long long n_slots,
                     const std::vector<unsigned char>& skip, const double box[4], ShiftedOf shifted_of, BorderFix* fix) {
-    const unsigned cap = (unsigned)h->opt_tap_cap;
+    // the list starts small (64 K entries, or what an earlier sweep needed) and is grown -- and the scan repeated --
+    // only when a sweep lists more, up to "tap_cap"
+    const unsigned cap_max = (unsigned)h->opt_tap_cap;
+    unsigned cap = (unsigned)std::min<size_t>(cap_max, std::max<size_t>((size_t)1 << 16, h->tap_list.cap / sizeof(uint2)));
     HIPCHK(h->tap_count.reserve(sizeof(unsigned)));
     HIPCHK(h->tap_list.reserve((size_t)cap * sizeof(uint2)));
     HIPCHK(h->tap_skip.reserve((size_t)n_slots));
-    HIPCHK(hipMemsetAsync(h->tap_count.p, 0, sizeof(unsigned), h->stream));
     HIPCHK(hipMemcpyAsync(h->tap_skip.p, skip.data(), (size_t)n_slots, hipMemcpyHostToDevice, h->stream));
     TapScanArgs a;
     a.hom = h->lane_params.as<double>();
@@ -1500,14 +1502,22 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, const coreg_wcs2d& target, 
     const unsigned gy = (unsigned)std::max(1, std::min(n_rows, (int)(4096 / std::max(1u, gx))));
     a.rows_per_block = (n_rows + (int)gy - 1) / (int)gy;
     const dim3 grid(gx, (unsigned)((n_rows + a.rows_per_block - 1) / a.rows_per_block));
-    if (sweep_mode == MODE_HOMOGRAPHY_SERIES)
-        hipLaunchKernelGGL((k_tap_scan<MODE_HOMOGRAPHY_SERIES>), grid, dim3(256), 0, h->stream, a);
-    else
-        hipLaunchKernelGGL((k_tap_scan<MODE_HOMOGRAPHY>), grid, dim3(256), 0, h->stream, a);
-    HIPCHK(hipGetLastError());
     unsigned count = 0;
-    HIPCHK(hipMemcpyAsync(&count, h->tap_count.p, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int pass = 0; pass < 2; ++pass) {
+        a.list = h->tap_list.as<uint2>();
+        a.cap = cap;
+        HIPCHK(hipMemsetAsync(h->tap_count.p, 0, sizeof(unsigned), h->stream));
+        if (sweep_mode == MODE_HOMOGRAPHY_SERIES)
+            hipLaunchKernelGGL((k_tap_scan<MODE_HOMOGRAPHY_SERIES>), grid, dim3(256), 0, h->stream, a);
+        else
+            hipLaunchKernelGGL((k_tap_scan<MODE_HOMOGRAPHY>), grid, dim3(256), 0, h->stream, a);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&count, h->tap_count.p, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (count <= cap || count > cap_max) break;
+        cap = count;  // (the scan is deterministic in what it lists: the second pass finds exactly `count` entries)
+        HIPCHK(h->tap_list.reserve((size_t)cap * sizeof(uint2)));
+    }
     h->tap_last[0] = count;
     h->tap_last[1] = 0;
     h->tap_last[2] = count > cap ? 1 : 0;
