@@ -1524,29 +1524,35 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, const coreg_wcs2d& target, 
     if (count == 0 || count > cap) return COREG_OK;
     std::vector<uint2> list(count);
     HIPCHK(hipMemcpy(list.data(), h->tap_list.p, (size_t)count * sizeof(uint2), hipMemcpyDeviceToHost));
-    std::sort(list.begin(), list.end(), [](const uint2& l, const uint2& r) { return l.x != r.x ? l.x < r.x : l.y < r.y; });
+    // group by slot (counting sort), then every segment is put in pixel order by the thread that evaluates it: the
+    // summation order of k_tap_fix does not depend on the order the scan's atomics happened to list the samples in
+    std::vector<int> first((size_t)n_slots + 1, 0);
+    for (unsigned k = 0; k < count; ++k) ++first[(size_t)list[k].x + 1];
+    for (long long sl = 0; sl < n_slots; ++sl) first[(size_t)sl + 1] += first[(size_t)sl];
+    std::vector<unsigned> pixel(count);
+    {
+        std::vector<int> at(first.begin(), first.end() - 1);
+        for (unsigned k = 0; k < count; ++k) pixel[(size_t)at[list[k].x]++] = list[k].y;
+    }
     std::vector<int> seg_slot, seg_begin;
-    for (unsigned k = 0; k < count; ++k)
-        if (k == 0 || list[k].x != list[k - 1].x) {
-            seg_slot.push_back((int)list[k].x);
-            seg_begin.push_back((int)k);
+    for (long long sl = 0; sl < n_slots; ++sl)
+        if (first[(size_t)sl + 1] > first[(size_t)sl]) {
+            seg_slot.push_back((int)sl);
+            seg_begin.push_back(first[(size_t)sl]);
         }
     seg_begin.push_back((int)count);
     const int n_seg = (int)seg_slot.size();
-    std::vector<unsigned> pixel(count);
     std::vector<double> xw(count), yw(count);
     WcslibTan wf;
     wf.init(target);
     const int gw = h->gW;
     auto work = [&](int s0, int s1) {
         for (int sg = s0; sg < s1; ++sg) {
+            std::sort(pixel.begin() + seg_begin[sg], pixel.begin() + seg_begin[sg + 1]);
             WcslibTan wt;
             wt.init(shifted_of(seg_slot[sg]));
-            for (int e = seg_begin[sg]; e < seg_begin[sg + 1]; ++e) {
-                pixel[e] = list[e].y;
-                wcslib_pixel_to_pixel(wf, wt, (double)(list[e].y % (unsigned)gw), (double)(list[e].y / (unsigned)gw), &xw[e],
-                                      &yw[e]);
-            }
+            for (int e = seg_begin[sg]; e < seg_begin[sg + 1]; ++e)
+                wcslib_pixel_to_pixel(wf, wt, (double)(pixel[e] % (unsigned)gw), (double)(pixel[e] / (unsigned)gw), &xw[e], &yw[e]);
         }
     };
     unsigned nt = std::min<unsigned>(12, std::max(1u, std::thread::hardware_concurrency()));
