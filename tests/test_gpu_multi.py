@@ -356,3 +356,30 @@ def test_multi_odd_order_noise_decided_samples(gpu_handle, monkeypatch):
             m.set_option("force_mode", -1)
             assert "points" in modes  # (the planner's choice for lag sets this small: device 0 carries the correction)
             assert ls.size <= 2 or {"blocks", "combos", "slices"} <= modes
+
+
+def test_multi_tile_compressed_images_on_every_device(gpu_handle, monkeypatch, tmp_path):
+    """Tile-compressed files (EUI's format) through the all-GPU driver: every device uploads the compressed bytes -- a
+    fraction of the pixels' -- and decodes them itself, for the image to align and for the reference image, both
+    frames.  Same maps as the single handle on the host-decoded pixels."""
+    from euispice_coreg_amd import _lib
+    from euispice_coreg_amd.utils import fits_io
+    monkeypatch.setenv("COREG_VIRTUAL_DEVICES", "3")
+    small, hs, large, hl, _ = H.scene()
+    ps, pl = str(tmp_path / "s.fits"), str(tmp_path / "l.fits")
+    fits_io.write_compressed_image(ps, small.astype(np.float32), hs, quantize="SUBTRACTIVE_DITHER_2", dither0=77, tile=(32, 8))
+    fits_io.write_compressed_image(pl, np.clip(np.nan_to_num(large) * 8.0, 0, 65535).astype(np.uint16), hl)
+    cs, cl = fits_io.open_compressed(ps, -1), fits_io.open_compressed(pl, -1)
+    assert cs.on_gpu and cl.on_gpu
+    ds, dl = fits_io.native_pixels(cs.decode()), fits_io.native_pixels(cl.decode())
+    lags = (np.arange(9.0, 25.0, 2.0), np.arange(-15.0, -3.0, 2.0), None, None, [0.0, 0.3])
+    want_c = _single_carr(gpu_handle, ds, hs, dl, hl, lags)
+    want_h = H.gpu_helio(gpu_handle, ds, hs, dl, hl, lags).ravel()
+    with _lib.MultiHandle() as m:
+        got_c = _multi_carr(m, cs, hs, cl, hl, lags)
+        m.set_small(cs)
+        m.prepare_reference_helioprojective(cl, hl, hs, 2)
+        got_h = m.sweep_helioprojective(hs, hs, _lib.LagSet(*lags))
+    assert np.array_equal(np.isnan(got_c), np.isnan(want_c)) and np.nanmax(np.abs(got_c - want_c)) <= 1e-12
+    assert np.array_equal(np.isnan(got_h), np.isnan(want_h)) and np.nanmax(np.abs(got_h - want_h)) <= 1e-12
+    assert np.isfinite(got_c).any() and np.isfinite(got_h).any()
