@@ -501,19 +501,34 @@ def load_for_upload(path, window=-1):
     return read_image(path, window)
 
 
+_SCAN_CACHE = {}  # (abs path, mtime_ns, size) -> ([header], [span]) of the last few files looked at
+
+
 def _scan(path):
-    """Headers of every HDU and where each data unit lies: ([header], [(offset, nbytes, shape) or None])."""
-    hdus, spans = [], []
-    with open(path, "rb") as f:
-        while True:
-            hdr, _ = _read_header(f)
-            if hdr is None:
-                break
-            nbytes, shape = _data_size(hdr)
-            spans.append((f.tell(), nbytes, shape) if nbytes else None)
-            f.seek(((nbytes + BLOCK - 1) // BLOCK) * BLOCK, os.SEEK_CUR)
-            hdus.append(hdr)
-    return hdus, spans
+    """Headers of every HDU and where each data unit lies: ([header], [(offset, nbytes, shape) or None]).  A drop-in call
+    asks for the same file's headers several times (header of the reference, header of the image, the raw view of
+    either): parsed once per file state (path, modification time, size); the headers handed out are copies."""
+    st = os.stat(path)
+    key = (os.path.abspath(os.fspath(path)), st.st_mtime_ns, st.st_size)
+    hit = _SCAN_CACHE.get(key)
+    if hit is None:
+        hdus, spans = [], []
+        with open(path, "rb") as f:
+            while True:
+                hdr, _ = _read_header(f)
+                if hdr is None:
+                    break
+                nbytes, shape = _data_size(hdr)
+                spans.append((f.tell(), nbytes, shape) if nbytes else None)
+                f.seek(((nbytes + BLOCK - 1) // BLOCK) * BLOCK, os.SEEK_CUR)
+                hdus.append(hdr)
+        if len(_SCAN_CACHE) >= 16:  # (threads of a jitter session share it: every step tolerates the other's)
+            try:
+                _SCAN_CACHE.pop(next(iter(_SCAN_CACHE)), None)
+            except (StopIteration, RuntimeError):
+                pass
+        hit = _SCAN_CACHE[key] = (hdus, spans)
+    return [h.copy() for h in hit[0]], list(hit[1])
 
 
 def native_pixels(a):
@@ -572,7 +587,7 @@ def read_header(path, window=-1):
     if isinstance(path, (tuple, list)) and len(path) == 2:
         return Header(path[1])
     if os.path.exists(str(path)):
-        hdus = _read_all(path, with_data=False)
+        hdus = [(h, None) for h in _scan(path)[0]]
         hdr = hdus[_select(hdus, window)][0]
         if str(hdr.get("XTENSION", "")).strip() == "BINTABLE" and hdr.get("ZIMAGE") is True:
             return _image_header_of_table(hdr)

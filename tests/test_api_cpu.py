@@ -543,3 +543,25 @@ def test_write_corrected_fits_leaves_valid_checksums(tmp_path):
     assert fits_io._sum32(after[3][3], start=int(ha["DATASUM"])) == fits_io._sum32(before[3][3], start=int(hb["DATASUM"]))
     d, _ = fits_io.read_image(dst, "RICE")
     assert np.array_equal(d, fits_io.read_image(src, "RICE")[0])
+
+
+def test_header_scans_are_cached_per_file_state(tmp_path):
+    """A drop-in call asks for a file's headers several times: parsed once per (path, modification time, size); a file
+    that is rewritten is parsed again, and callers cannot alter the cached headers."""
+    from euispice_coreg_amd.utils import fits_io
+    p = str(tmp_path / "a.fits")
+    fits_io.write_images(p, [(None, {}), (np.zeros((3, 4), np.float32), {"CRVAL1": 1.0, "EXTNAME": "A"})])
+    h1 = fits_io.read_header(p, -1)
+    h1["CRVAL1"] = 99.0
+    assert fits_io.read_header(p, "A")["CRVAL1"] == 1.0 and fits_io.open_raw(p, -1).header["CRVAL1"] == 1.0
+    n = len(fits_io._SCAN_CACHE)
+    fits_io.read_header(p, -1)
+    assert len(fits_io._SCAN_CACHE) == n
+    os.utime(p, ns=(1, 1))  # (same size, other modification time)
+    fits_io.write_images(p, [(None, {}), (np.zeros((3, 4), np.float32), {"CRVAL1": 2.0, "EXTNAME": "A"})])
+    assert fits_io.read_header(p, -1)["CRVAL1"] == 2.0
+    for k in range(40):
+        q = str(tmp_path / f"f{k}.fits")
+        fits_io.write_images(q, [(None, {"K": k})])
+        assert fits_io.read_header(q, 0)["K"] == k
+    assert len(fits_io._SCAN_CACHE) <= 16
