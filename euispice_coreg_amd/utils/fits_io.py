@@ -504,30 +504,36 @@ def load_for_upload(path, window=-1):
 _SCAN_CACHE = {}  # (abs path, mtime_ns, size) -> ([header], [span]) of the last few files looked at
 
 
-def _scan(path):
+def _scan(path, with_raw=False):
     """Headers of every HDU and where each data unit lies: ([header], [(offset, nbytes, shape) or None]).  A drop-in call
     asks for the same file's headers several times (header of the reference, header of the image, the raw view of
-    either): parsed once per file state (path, modification time, size); the headers handed out are copies."""
+    either, the header blocks `write_corrected_fits` patches): parsed once per file state (path, modification time, size);
+    the headers handed out are copies.  with_raw: also the header blocks as stored and where each HDU starts."""
     st = os.stat(path)
     key = (os.path.abspath(os.fspath(path)), st.st_mtime_ns, st.st_size)
     hit = _SCAN_CACHE.get(key)
     if hit is None:
-        hdus, spans = [], []
+        hdus, spans, raws, starts = [], [], [], []
         with open(path, "rb") as f:
             while True:
-                hdr, _ = _read_header(f)
+                starts.append(f.tell())
+                hdr, raw = _read_header(f)
                 if hdr is None:
+                    starts.pop()
                     break
                 nbytes, shape = _data_size(hdr)
                 spans.append((f.tell(), nbytes, shape) if nbytes else None)
                 f.seek(((nbytes + BLOCK - 1) // BLOCK) * BLOCK, os.SEEK_CUR)
                 hdus.append(hdr)
+                raws.append(raw)
         if len(_SCAN_CACHE) >= 16:  # (threads of a jitter session share it: every step tolerates the other's)
             try:
                 _SCAN_CACHE.pop(next(iter(_SCAN_CACHE)), None)
             except (StopIteration, RuntimeError):
                 pass
-        hit = _SCAN_CACHE[key] = (hdus, spans)
+        hit = _SCAN_CACHE[key] = (hdus, spans, raws, starts)
+    if with_raw:
+        return [h.copy() for h in hit[0]], list(hit[1]), list(hit[2]), list(hit[3])
     return [h.copy() for h in hit[0]], list(hit[1])
 
 
@@ -902,17 +908,13 @@ def rewrite_with_corrected_headers(path_in, path_out, is_selected, correct):
     final = None
     if os.path.exists(path_out) and os.path.samefile(path_in, path_out):  # correcting a file in place
         final, path_out = path_out, str(path_out) + ".coreg-tmp"
+    hdus_in, _, raws_in, starts_in = _scan(path_in, with_raw=True)
     with open(path_in, "rb") as fi:
         spans = []
-        while True:
-            start = fi.tell()
-            hdr, raw_hdr = _read_header(fi)
-            if hdr is None:
-                break
+        for hdr, raw_hdr, start in zip(hdus_in, raws_in, starts_in):
             nbytes, shape = _data_size(hdr)
-            data_pos = fi.tell()
+            data_pos = start + len(raw_hdr)
             padded = ((nbytes + BLOCK - 1) // BLOCK) * BLOCK
-            fi.seek(padded, os.SEEK_CUR)
             spans.append((hdr, start, data_pos, nbytes, padded, shape, raw_hdr))
         size = os.fstat(fi.fileno()).st_size
         with open(path_out, "wb") as fo:
