@@ -19,6 +19,7 @@
 #include "fit.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include <atomic>
 #include "ricecomp.hpp"
 #include "riceenc.hpp"
 
@@ -2863,9 +2864,12 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     const Plan plan = choose_plan(h, geo, m1, d.n2, h->opt_use_lds ? lds_window_elems(h) : (1LL << 40));
 
     // ---- all slots of all (cdelt1, cdelt2, crota) combinations -> ONE launch
-    SlotList slots;
+    // Two passes.  (1) per combination, independent of every other and of the handle -- a few host threads share them
+    // when the lag set is large (cfg4: 21 combinations x 3 721 lag-points, 1.4 ms of 3 x 3 products on one core):
+    // shifted header, slots, one homography per slot, the combination's corner of the cull box.  (2) in combination
+    // order, on this thread: the lag-points decided by wcslib's rounding noise (handle caches), the bookkeeping of the
+    // odd-order pass, the concatenation.
     std::vector<long long> outidx;
-    std::vector<double> hs;  // AoS while building
     int n_batches = 0;
     double fx0 = 1e300, fx1 = -1e300, fy0 = 1e300, fy1 = -1e300;  // cull box in target pixels
     HomographyFamily fam;
@@ -2878,21 +2882,83 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     std::vector<int> tap_slot_combo, tap_slot_i1, tap_slot_i2;
     std::vector<unsigned char> tap_skip;     // padding lanes and lag-points the structured fix handles
     const int i1_lo = (int)(lag_begin / row), i1_hi = (int)((lag_end - 1) / row);
+    fam.fill_products(i1_lo, i1_hi);  // (read-only from here on: `get` is safe to call from several threads)
     const double nanv = std::numeric_limits<double>::quiet_NaN();
-    for (long long c = 0; c < d.nc; ++c) {
+    struct ComboPlan {
+        bool used = false;
+        coreg_wcs2d hc;
+        SlotList slots;
+        std::vector<double> hs;  // AoS [slot][9]
+        double box[4] = {1e300, -1e300, 1e300, -1e300};
+    };
+    std::vector<ComboPlan> cps((size_t)d.nc);
+    // which target pixels can ever be in bounds: inverse maps of the small image's corners for the lags on the
+    // boundary of the (CRVAL1, CRVAL2) rectangle, chosen BY VALUE (the reference accepts lag lists in any order):
+    // smallest, largest and the value nearest the middle of each axis (the maps vary smoothly and monotonically
+    // with the lag value, the +-3 px margin below covers the curvature in between)
+    int e1[3], e2[3];
+    extreme_lags(lags->crval1 + i1_lo, i1_hi - i1_lo + 1, e1);
+    extreme_lags(lags->crval2, d.n2, e2);
+    auto plan_combo = [&](long long c) {
+        ComboPlan& cp = cps[(size_t)c];
         const long long first = (lag_begin - c + d.nc - 1) / d.nc;
-        if (first * d.nc + c >= lag_end) continue;
+        if (first * d.nc + c >= lag_end) return;
         int i3, i4, i5;
         d.inner(c, &i3, &i4, &i5);
-        coreg_wcs2d hc;
         if (shift_header(*hdr_small, 0.0, 0.0, lags->cdelt1[i3], lags->cdelt2[i4], lags->crota[i5], cdelt_semantics,
-                         &hc))
-            continue;
-        build_slots(d, c, lag_begin, lag_end, plan.sw, plan.sh, &slots);
-        if (slots.n_batches == 0) continue;
-        const Mat3d B = HomographyFamily::combo(hc);
-        const size_t at = hs.size();
-        hs.resize(at + 9 * slots.i1.size());
+                         &cp.hc))
+            return;
+        build_slots(d, c, lag_begin, lag_end, plan.sw, plan.sh, &cp.slots);
+        if (cp.slots.n_batches == 0) return;
+        cp.used = true;
+        const Mat3d B = HomographyFamily::combo(cp.hc);
+        const size_t n = cp.slots.i1.size();
+        cp.hs.resize(9 * n);
+        for (size_t s = 0; s < n; ++s) {
+            double* hm = &cp.hs[9 * s];
+            if (cp.slots.outidx[s] < 0) {  // padding lane: NaN map -> never in bounds
+                for (int k = 0; k < 9; ++k) hm[k] = nanv;
+            } else {
+                fam.get(B, cp.slots.i1[s], cp.slots.i2[s], hm);
+            }
+        }
+        for (int a1 = 0; a1 < 3; ++a1)
+            for (int a2 = 0; a2 < 3; ++a2) {
+                coreg_wcs2d hl = cp.hc;
+                hl.crval1 = hdr_small->crval1 + lags->crval1[i1_lo + e1[a1]];
+                hl.crval2 = hdr_small->crval2 + lags->crval2[e2[a2]];
+                double hi[9];
+                homography(hl, *hdr_target, hi);
+                for (int k = 0; k < 4; ++k) {
+                    double px, py;
+                    apply_h(hi, (k & 1) ? (double)(h->sW - 1) : 0.0, (k & 2) ? (double)(h->sH - 1) : 0.0, &px, &py);
+                    cp.box[0] = std::min(cp.box[0], px);
+                    cp.box[1] = std::max(cp.box[1], px);
+                    cp.box[2] = std::min(cp.box[2], py);
+                    cp.box[3] = std::max(cp.box[3], py);
+                }
+            }
+    };
+    const unsigned plan_threads = (d.nc >= 2 && (long long)d.nc * d.n1 * d.n2 >= 16384)
+                                      ? std::min<unsigned>({8u, (unsigned)d.nc, std::max(1u, std::thread::hardware_concurrency())})
+                                      : 1u;
+    if (plan_threads <= 1) {
+        for (long long c = 0; c < d.nc; ++c) plan_combo(c);
+    } else {
+        std::atomic<long long> next(0);
+        auto worker = [&] {
+            for (long long c = next.fetch_add(1); c < d.nc; c = next.fetch_add(1)) plan_combo(c);
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < plan_threads; ++t) th.emplace_back(worker);
+        worker();
+        for (auto& x : th) x.join();
+    }
+    for (long long c = 0; c < d.nc; ++c) {
+        ComboPlan& cp = cps[(size_t)c];
+        if (!cp.used) continue;
+        const SlotList& slots = cp.slots;
+        const coreg_wcs2d& hc = cp.hc;
         if (tap_fixing) {
             tap_combo.push_back(hc);
             for (size_t s = 0; s < slots.i1.size(); ++s) {
@@ -2902,60 +2968,41 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                 tap_skip.push_back(slots.outidx[s] < 0 ? 1 : 0);
             }
         }
-        for (size_t s = 0; s < slots.i1.size(); ++s) {
-            double* hm = &hs[at + 9 * s];
-            if (slots.outidx[s] < 0) {  // padding lane: NaN map -> never in bounds
-                for (int k = 0; k < 9; ++k) hm[k] = nanv;
-            } else {
-                fam.get(B, slots.i1[s], slots.i2[s], hm);
-                if (h->opt_border_fix) {
-                    coreg_wcs2d hl = hc;
-                    hl.crval1 = hdr_small->crval1 + lags->crval1[slots.i1[s]];
-                    hl.crval2 = hdr_small->crval2 + lags->crval2[slots.i2[s]];
-                    // same tangent point as the target (sub-map path, zero CRVAL lag) and an invariant image axis:
-                    // exact invariant map on the device, border pixels decided as the reference's wcslib round trip
-                    // decides them (geometry.hpp WcslibTan, k_border_fix)
-                    const AxisInvariance inv = snap_invariant_axes(*hdr_target, hl, h->gW, h->gH, hm);
-                    if (inv.rows || inv.cols) {
-                        BorderFix::Item it;
-                        it.slot = (long long)(outidx.size() + s);
-                        it.first = (int)fix.pixels.size();
-                        wcslib_dropped_border_pixels(h, *hdr_target, hl, inv, &fix.pixels);
-                        it.n = (int)fix.pixels.size() - it.first;
-                        it.flags_off = -1;
-                        if (order & 1) {
-                            it.flags_off = (long long)flags_host.size() * h->gW * h->gH;
-                            flags_host.push_back(wcslib_tap_shift_flags(h, *hdr_target, hl, inv));  // (copy: the cache may evict)
-                        }
-                        if (it.n > 0 || it.flags_off >= 0) fix.items.push_back(it);
-                        if (tap_fixing) tap_skip[(size_t)it.slot] = 1;  // (its whole grid sits on integers: k_parity_fix)
+        if (h->opt_border_fix) {
+            for (size_t s = 0; s < slots.i1.size(); ++s) {
+                if (slots.outidx[s] < 0) continue;
+                // same tangent point as the target (sub-map path, zero CRVAL lag) and an invariant image axis: exact
+                // invariant map on the device, border pixels decided as the reference's wcslib round trip decides them
+                // (geometry.hpp WcslibTan, k_border_fix).  (The tangent points are compared first: every other
+                // lag-point is dismissed without building its header.)
+                const double v1 = hdr_small->crval1 + lags->crval1[slots.i1[s]];
+                const double v2 = hdr_small->crval2 + lags->crval2[slots.i2[s]];
+                if (v1 != hdr_target->crval1 || v2 != hdr_target->crval2) continue;
+                coreg_wcs2d hl = hc;
+                hl.crval1 = v1;
+                hl.crval2 = v2;
+                double* hm = &cp.hs[9 * s];
+                const AxisInvariance inv = snap_invariant_axes(*hdr_target, hl, h->gW, h->gH, hm);
+                if (inv.rows || inv.cols) {
+                    BorderFix::Item it;
+                    it.slot = (long long)(outidx.size() + s);
+                    it.first = (int)fix.pixels.size();
+                    wcslib_dropped_border_pixels(h, *hdr_target, hl, inv, &fix.pixels);
+                    it.n = (int)fix.pixels.size() - it.first;
+                    it.flags_off = -1;
+                    if (order & 1) {
+                        it.flags_off = (long long)flags_host.size() * h->gW * h->gH;
+                        flags_host.push_back(wcslib_tap_shift_flags(h, *hdr_target, hl, inv));  // (copy: the cache may evict)
                     }
+                    if (it.n > 0 || it.flags_off >= 0) fix.items.push_back(it);
+                    if (tap_fixing) tap_skip[(size_t)it.slot] = 1;  // (its whole grid sits on integers: k_parity_fix)
                 }
             }
         }
-        // which target pixels can ever be in bounds: inverse maps of the small image's corners for the lags on the
-        // boundary of the (CRVAL1, CRVAL2) rectangle, chosen BY VALUE (the reference accepts lag lists in any order):
-        // smallest, largest and the value nearest the middle of each axis (the maps vary smoothly and monotonically
-        // with the lag value, the +-3 px margin below covers the curvature in between)
-        int e1[3], e2[3];
-        extreme_lags(lags->crval1 + i1_lo, i1_hi - i1_lo + 1, e1);
-        extreme_lags(lags->crval2, d.n2, e2);
-        for (int a1 = 0; a1 < 3; ++a1)
-            for (int a2 = 0; a2 < 3; ++a2) {
-                coreg_wcs2d hl = hc;
-                hl.crval1 = hdr_small->crval1 + lags->crval1[i1_lo + e1[a1]];
-                hl.crval2 = hdr_small->crval2 + lags->crval2[e2[a2]];
-                double hi[9];
-                homography(hl, *hdr_target, hi);
-                for (int k = 0; k < 4; ++k) {
-                    double px, py;
-                    apply_h(hi, (k & 1) ? (double)(h->sW - 1) : 0.0, (k & 2) ? (double)(h->sH - 1) : 0.0, &px, &py);
-                    fx0 = std::min(fx0, px);
-                    fx1 = std::max(fx1, px);
-                    fy0 = std::min(fy0, py);
-                    fy1 = std::max(fy1, py);
-                }
-            }
+        fx0 = std::min(fx0, cp.box[0]);
+        fx1 = std::max(fx1, cp.box[1]);
+        fy0 = std::min(fy0, cp.box[2]);
+        fy1 = std::max(fy1, cp.box[3]);
         outidx.insert(outidx.end(), slots.outidx.begin(), slots.outidx.end());
         n_batches += slots.n_batches;
     }
@@ -2966,10 +3013,37 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     const size_t ns = outidx.size();
     std::vector<double> params(9 * ns);
     double eps_max = 0.0;  // largest |h6 x + h7 y| over the target grid and all lags
-    for (size_t s = 0; s < ns; ++s) {
-        for (int k = 0; k < 9; ++k) params[(size_t)k * ns + s] = hs[s * 9 + k];
-        const double e = std::fabs(hs[s * 9 + 6]) * (double)h->gW + std::fabs(hs[s * 9 + 7]) * (double)h->gH;
-        if (e == e) eps_max = std::max(eps_max, e);
+    {
+        // AoS per combination -> SoA [9][ns] of the launch, the same threads over the combinations
+        std::vector<size_t> off((size_t)d.nc + 1, 0);
+        for (long long c = 0; c < d.nc; ++c) off[(size_t)c + 1] = off[(size_t)c] + (cps[(size_t)c].used ? cps[(size_t)c].slots.i1.size() : 0);
+        std::vector<double> eps_of((size_t)d.nc, 0.0);
+        auto transpose = [&](long long c) {
+            const ComboPlan& cp = cps[(size_t)c];
+            if (!cp.used) return;
+            const size_t n = cp.slots.i1.size(), at = off[(size_t)c];
+            double em = 0.0;
+            for (size_t s = 0; s < n; ++s) {
+                const double* hm = &cp.hs[9 * s];
+                for (int k = 0; k < 9; ++k) params[(size_t)k * ns + at + s] = hm[k];
+                const double e = std::fabs(hm[6]) * (double)h->gW + std::fabs(hm[7]) * (double)h->gH;
+                if (e == e) em = std::max(em, e);
+            }
+            eps_of[(size_t)c] = em;
+        };
+        if (plan_threads <= 1) {
+            for (long long c = 0; c < d.nc; ++c) transpose(c);
+        } else {
+            std::atomic<long long> next(0);
+            auto worker = [&] {
+                for (long long c = next.fetch_add(1); c < d.nc; c = next.fetch_add(1)) transpose(c);
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < plan_threads; ++t) th.emplace_back(worker);
+            worker();
+            for (auto& x : th) x.join();
+        }
+        for (double e : eps_of) eps_max = std::max(eps_max, e);
     }
     // 1/(1 + eps) = 1 - eps + eps^2 is exact to float64 below ~4e-6 (eps^3 < 1e-16); wider fields divide exactly
     const int sweep_mode = (h->opt_h_series && eps_max < 4.0e-6) ? MODE_HOMOGRAPHY_SERIES : MODE_HOMOGRAPHY;

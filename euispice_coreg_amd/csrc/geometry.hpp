@@ -185,6 +185,18 @@ struct HomographyFamily {
             have_pq.assign((size_t)n1 * n2, 0);
         }
     }
+    // every product of the cache at once: afterwards `get` only reads (several threads may call it)
+    void fill_products(int i1_lo, int i1_hi) const {  // (the CRVAL1 lags of the sweep's slice, inclusive)
+        if (PQ.empty()) return;
+        for (size_t i2 = 0; i2 < P.size(); ++i2)
+            for (size_t i1 = (size_t)i1_lo; i1 <= (size_t)i1_hi && i1 < Q.size(); ++i1) {
+                const size_t k = i2 * Q.size() + i1;
+                if (!have_pq[k]) {
+                    PQ[k] = mul3(P[i2], Q[i1]);
+                    have_pq[k] = 1;
+                }
+            }
+    }
     // per (cdelt, crota) combination: B = iwc_to_pix(shifted header) * Ninv
     static Mat3d combo(const coreg_wcs2d& shifted) {
         const Mat3 Ninv = {{{0, 1, 0}, {-1, 0, 0}, {0, 0, 1}}};
