@@ -111,10 +111,45 @@ def _decode(hdr, buf, nbytes, shape):
     return arr.astype(arr.dtype.newbyteorder("="))
 
 
+_GUNZIPPED = {}   # (abs path, mtime_ns, size) of a gzip-compressed FITS file -> its decompressed copy
+_GUNZIP_DIR = None
+
+
+def _plain_path(path):
+    """`path`, or -- for a gzip-compressed file (`*.fits.gz`: astropy, hence the reference, opens them transparently) --
+    the path of a decompressed copy made once per file state in a scratch directory that is removed at exit: everything
+    downstream (memory-mapped data units, raw uploads, compressed-tile uploads) then works on it as on any file."""
+    global _GUNZIP_DIR
+    try:
+        with open(path, "rb") as f:
+            if f.read(2) != b"\x1f\x8b":
+                return path
+    except OSError:
+        return path
+    st = os.stat(path)
+    key = (os.path.abspath(os.fspath(path)), st.st_mtime_ns, st.st_size)
+    out = _GUNZIPPED.get(key)
+    if out is None or not os.path.exists(out):
+        import atexit
+        import gzip
+        import shutil
+        import tempfile
+        if _GUNZIP_DIR is None:
+            base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+            _GUNZIP_DIR = tempfile.mkdtemp(prefix="coreg_gunzip_", dir=base)
+            atexit.register(shutil.rmtree, _GUNZIP_DIR, True)
+        fd, out = tempfile.mkstemp(suffix=".fits", dir=_GUNZIP_DIR)
+        with os.fdopen(fd, "wb") as fo, gzip.open(path, "rb") as fi:
+            shutil.copyfileobj(fi, fo, 1 << 22)
+        _GUNZIPPED[key] = out
+    return out
+
+
 def _read_all(path, with_data=True, only=None):
     """[(header, data)] of every HDU.  with_data=False: headers only (data skipped with a seek); only=<window>: the pixel
     data of that HDU alone are read and decoded (an index, or an EXTNAME)."""
     hdus = []
+    path = _plain_path(path)
     with open(path, "rb") as f:
         raw = []
         while True:
@@ -210,9 +245,10 @@ def open_raw(path, window=-1):
     if not isinstance(path, (str, os.PathLike)) or not os.path.isfile(path):
         return None
     try:
+        path = _plain_path(path)
         hdus, spans = _scan(path)
         i = _select([(h, None) for h in hdus], window)
-    except (IOError, KeyError, IndexError, ValueError):
+    except (IOError, KeyError, IndexError, ValueError, EOFError):
         return None
     hdr = hdus[i]
     is_image = hdr.get("SIMPLE") is not None or str(hdr.get("XTENSION", "")).strip() == "IMAGE"
@@ -448,9 +484,10 @@ def open_compressed(path, window=-1):
     if not isinstance(path, (str, os.PathLike)) or not os.path.isfile(path):
         return None
     try:
+        path = _plain_path(path)
         hdus, spans = _scan(path)
         i = _select([(h, None) for h in hdus], window)
-    except (IOError, KeyError, IndexError, ValueError):
+    except (IOError, KeyError, IndexError, ValueError, EOFError):
         return None
     hdr = hdus[i]
     if not (str(hdr.get("XTENSION", "")).strip() == "BINTABLE" and hdr.get("ZIMAGE") is True and spans[i] is not None):
@@ -465,6 +502,7 @@ def open_cube(path, window=-1):
     for anything that is not a plain, unscaled image HDU of a local file."""
     if isinstance(path, (str, os.PathLike)) and os.path.isfile(path):
         try:
+            path = _plain_path(path)
             hdus, spans = _scan(path)
             i = _select([(h, None) for h in hdus], window)
             hdr = hdus[i]
@@ -509,6 +547,7 @@ def _scan(path, with_raw=False):
     asks for the same file's headers several times (header of the reference, header of the image, the raw view of
     either, the header blocks `write_corrected_fits` patches): parsed once per file state (path, modification time, size);
     the headers handed out are copies.  with_raw: also the header blocks as stored and where each HDU starts."""
+    path = _plain_path(path)
     st = os.stat(path)
     key = (os.path.abspath(os.fspath(path)), st.st_mtime_ns, st.st_size)
     hit = _SCAN_CACHE.get(key)
@@ -908,6 +947,10 @@ def rewrite_with_corrected_headers(path_in, path_out, is_selected, correct):
     final = None
     if os.path.exists(path_out) and os.path.samefile(path_in, path_out):  # correcting a file in place
         final, path_out = path_out, str(path_out) + ".coreg-tmp"
+    gz_out = None
+    if str(final or path_out).endswith(".gz"):  # (astropy's writeto compresses by the name: so does this)
+        gz_out, path_out = path_out, str(path_out) + ".coreg-plain"
+    path_in = _plain_path(path_in)
     hdus_in, _, raws_in, starts_in = _scan(path_in, with_raw=True)
     with open(path_in, "rb") as fi:
         spans = []
@@ -964,6 +1007,13 @@ def rewrite_with_corrected_headers(path_in, path_out, is_selected, correct):
                     blob = _patch_header(raw_hdr, changed, gone + ("BSCALE", "BZERO", "BLANK"))
                     fo.write(_refresh_checksum(blob, datasum=_sum32(raw) if b"DATASUM =" in blob or b"CHECKSUM=" in blob else None))
                     fo.write(raw)
+    if gz_out is not None:
+        import gzip
+        import shutil
+        with open(path_out, "rb") as fi, gzip.open(gz_out, "wb", compresslevel=6) as fo:
+            shutil.copyfileobj(fi, fo, 1 << 22)
+        os.remove(path_out)
+        path_out = gz_out
     if final is not None:
         os.replace(path_out, final)
     return n_corrected

@@ -565,3 +565,41 @@ def test_header_scans_are_cached_per_file_state(tmp_path):
         fits_io.write_images(q, [(None, {"K": k})])
         assert fits_io.read_header(q, 0)["K"] == k
     assert len(fits_io._SCAN_CACHE) <= 16
+
+
+def test_gzip_compressed_fits_files_are_opened_transparently(tmp_path):
+    """`*.fits.gz` (astropy, hence the reference, opens them as any file; `writeto` compresses by the name): headers,
+    pixels, the raw and compressed-tile views the uploads use, and write_corrected_fits in and out."""
+    import gzip
+    from euispice_coreg_amd.hdrshift import AlignmentResults
+    from euispice_coreg_amd.utils import fits_io
+    from tests.test_oracle_golden import REF_CORR
+    hdr = {"CRVAL1": 10.0, "CRVAL2": 20.0, "CDELT1": 0.5, "CDELT2": 0.5, "CROTA": 0.0, "CUNIT1": "arcsec", "CUNIT2": "arcsec",
+           "CRPIX1": 3.0, "CRPIX2": 3.0, "PC1_1": 1.0, "PC1_2": 0.0, "PC2_1": 0.0, "PC2_2": 1.0, "EXTNAME": "IMG"}
+    img = np.arange(30, dtype=np.float32).reshape(5, 6)
+    plain, gz = str(tmp_path / "a.fits"), str(tmp_path / "a.fits.gz")
+    fits_io.write_images(plain, [(None, {}), (img, hdr)])
+    with open(plain, "rb") as fi, gzip.open(gz, "wb") as fo:
+        fo.write(fi.read())
+    assert fits_io.read_header(gz, "IMG")["CRVAL1"] == 10.0
+    assert np.array_equal(fits_io.read_image(gz, -1)[0], img)
+    raw = fits_io.open_raw(gz, -1)
+    assert raw is not None and np.array_equal(np.asarray(raw), img)
+    up, h = fits_io.load_for_upload(gz, -1)
+    assert isinstance(up, fits_io.RawImage) and h["CRVAL2"] == 20.0
+    # a tile-compressed image inside a gzip file
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "compressed", "rice_i16.fits")
+    gz2 = str(tmp_path / "rice.fits.gz")
+    with open(src, "rb") as fi, gzip.open(gz2, "wb") as fo:
+        fo.write(fi.read())
+    ci = fits_io.open_compressed(gz2, -1)
+    assert ci is not None and ci.on_gpu and np.array_equal(np.asarray(ci), np.asarray(fits_io.open_compressed(src, -1)))
+    # corrected files: gzip in, plain out and gzip out
+    R = AlignmentResults(REF_CORR, np.arange(15, 26, 1), np.arange(5, 11, 1), None, [0], [0], "arcsec", image_to_align_path=gz)
+    out_plain, out_gz = str(tmp_path / "c.fits"), str(tmp_path / "c.fits.gz")
+    R.write_corrected_fits([-1], out_plain)
+    R.write_corrected_fits([-1], out_gz)
+    assert open(out_gz, "rb").read(2) == b"\\x1f\\x8b" and open(out_plain, "rb").read(6) == b"SIMPLE"
+    assert gzip.open(out_gz, "rb").read() == open(out_plain, "rb").read()
+    assert fits_io.read_header(out_gz, -1)["CRVAL1"] == pytest.approx(10.0 + R.shift_arcsec[0])
+    assert np.array_equal(fits_io.read_image(out_gz, -1)[0], img)
