@@ -599,7 +599,7 @@ def test_gzip_compressed_fits_files_are_opened_transparently(tmp_path):
     out_plain, out_gz = str(tmp_path / "c.fits"), str(tmp_path / "c.fits.gz")
     R.write_corrected_fits([-1], out_plain)
     R.write_corrected_fits([-1], out_gz)
-    assert open(out_gz, "rb").read(2) == b"\\x1f\\x8b" and open(out_plain, "rb").read(6) == b"SIMPLE"
+    assert open(out_gz, "rb").read(2) == bytes([0x1F, 0x8B]) and open(out_plain, "rb").read(6) == b"SIMPLE"
     assert gzip.open(out_gz, "rb").read() == open(out_plain, "rb").read()
     assert fits_io.read_header(out_gz, -1)["CRVAL1"] == pytest.approx(10.0 + R.shift_arcsec[0])
     assert np.array_equal(fits_io.read_image(out_gz, -1)[0], img)
