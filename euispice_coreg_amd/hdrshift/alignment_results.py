@@ -130,8 +130,7 @@ class AlignmentResults:
             if self.image_to_align_path is None:
                 raise ValueError("Please provide a path_to_l2_input parameter")
             path_to_l2_input = self.image_to_align_path
-        _, hdr = fits_io.read_image(path_to_l2_input, window)
-        hdr = hdr.copy()
+        hdr = fits_io.Header(fits_io.read_header(path_to_l2_input, window))  # (no pixel is decoded for a header)
         s = self.shift_arcsec
         hdrutil.correct_pointing_header(hdr, lag_crval1=s[0], lag_crval2=s[1], lag_cdelt1=s[2], lag_cdelt2=s[3],
                                         lag_crota=s[4])
@@ -212,8 +211,86 @@ class AlignmentResults:
             plt.show()
         return fig, ax
 
-    def plot_co_alignment(self, *a, **k):
-        raise NotImplementedError("plotting is outside the accelerated path (reference: plot/plot.py)")
+    def plot_co_alignment(self, path_save_figure=None, show=False, lonlims=None, latlims=None, levels_percentile=None,
+                          imin=2, imax=97, **kwargs):
+        """AlignmentResults.py:121-147 -> plot/plot.py:608-925, its "compare_plot": the reference image, and on top of it
+        the contours of the image to align before and after the pointing correction.  The image to align is put on the
+        reference image's pixel grid by the library's own resampler (the exact TAN -> TAN map of the sweep, order 2),
+        once with the header it came with and once with `return_corrected_header`; nothing else of the reference's
+        plotting module is reproduced (no sunpy frames, no SPICE cubes: 2-D image HDUs in helioprojective coordinates).
+        lonlims / latlims: (min, max) of the part of the reference image shown, in the lag unit.  Returns (fig, axes);
+        `self.co_alignment` keeps the three arrays that were drawn.  Needs matplotlib (optional dependency)."""
+        try:
+            import matplotlib
+            if not show:
+                matplotlib.use("Agg", force=False)
+            from matplotlib import pyplot as plt
+        except ImportError as e:  # pragma: no cover
+            raise NotImplementedError("plot_co_alignment needs matplotlib") from e
+        if self.image_to_align_path is None or self.reference_image_path is None:
+            raise ValueError("plot_co_alignment needs the paths of both images (AlignmentResults built by Alignment has them)")
+        if kwargs.get("type_plot", "compare_plot") != "compare_plot":
+            raise NotImplementedError("only type_plot='compare_plot'")
+        from .. import _lib
+        from ..utils import wcs_tan
+        w_small = -1 if self.image_to_align_window is None else self.image_to_align_window
+        w_ref = -1 if self.reference_image_window is None else self.reference_image_window
+        ref, href = fits_io.read_image(self.reference_image_path, w_ref)
+        small, hs = fits_io.load_for_upload(self.image_to_align_path, w_small)
+        if np.ndim(ref) != 2 or len(getattr(small, "shape", ())) != 2:
+            raise NotImplementedError("plot_co_alignment: 2-D image HDUs only")
+        href, hs = fits_io.Header(href), fits_io.Header(hs)
+        hdrutil.check_and_create_pcij_matrix(href, False)
+        hdrutil.check_and_create_pcij_matrix(hs, False)
+        hc = self.return_corrected_header(w_small)
+        hdrutil.check_and_create_pcij_matrix(hc, False)
+        h = _lib.shared_handle(-1, 0)
+        h.set_small(fits_io.native_pixels(small))
+        before = h.resample_helioprojective(href, hs, order=2, dtype=np.float64)
+        after = h.resample_helioprojective(href, hc, order=2, dtype=np.float64)
+        ref = np.asarray(ref, dtype=np.float64)
+        # what is shown: the part of the reference image either version of the image to align covers (or the limits asked
+        # for), with a margin
+        seen = np.isfinite(before) | np.isfinite(after)
+        if lonlims is not None or latlims is not None:
+            lon, lat = wcs_tan.pixel_lonlat(href)  # degrees
+            lon = (lon + 180.0) % 360.0 - 180.0
+            f = hdrutil.unit_to_deg(self.unit_lag)
+            if lonlims is not None:
+                seen &= (lon >= lonlims[0] * f) & (lon <= lonlims[1] * f)
+            if latlims is not None:
+                seen &= (lat >= latlims[0] * f) & (lat <= latlims[1] * f)
+        if not seen.any():
+            raise ValueError("plot_co_alignment: the image to align does not overlap the (selected part of the) reference image")
+        jj, ii = np.nonzero(seen)
+        m = max(4, int(0.05 * max(jj.max() - jj.min(), ii.max() - ii.min())))
+        j0, j1 = max(0, jj.min() - m), min(ref.shape[0], jj.max() + m + 1)
+        i0, i1 = max(0, ii.min() - m), min(ref.shape[1], ii.max() + m + 1)
+        ref_c, before_c, after_c = ref[j0:j1, i0:i1], before[j0:j1, i0:i1], after[j0:j1, i0:i1]
+        self.co_alignment = {"reference": ref_c, "before": before_c, "after": after_c, "window": (j0, j1, i0, i1)}
+        levels_percentile = [85] if levels_percentile is None else list(levels_percentile)
+        fin = ref_c[np.isfinite(ref_c)]
+        vmin, vmax = (np.percentile(fin, imin), np.percentile(fin, imax)) if fin.size else (None, None)
+        fig, axes = plt.subplots(1, 3, figsize=(15, 5), sharex=True, sharey=True)
+        extent = (i0 - 0.5, i1 - 0.5, j0 - 0.5, j1 - 0.5)
+        s = self.shift_arcsec
+        titles = ("reference image", "image to align: header as it came",
+                  f"corrected: dx={s[0]:.2f}'' dy={s[1]:.2f}'' drota={s[4]:.3g} deg")
+        for ax, over, title in zip(axes, (None, before_c, after_c), titles):
+            ax.imshow(ref_c, origin="lower", interpolation="none", cmap="gray", vmin=vmin, vmax=vmax, extent=extent)
+            if over is not None and np.isfinite(over).any():
+                lv = sorted(set(float(np.nanpercentile(over, q)) for q in levels_percentile))
+                ax.contour(np.arange(i0, i1), np.arange(j0, j1), np.where(np.isfinite(over), over, np.nanmin(over)),
+                           levels=lv, colors="r", linewidths=0.6)
+            ax.set_title(title, fontsize=9)
+            ax.set_xlabel("reference pixel x")
+        axes[0].set_ylabel("reference pixel y")
+        fig.tight_layout()
+        if path_save_figure is not None:
+            fig.savefig(path_save_figure)
+        if show:
+            plt.show()
+        return fig, axes
 
     def savefig(self, filename):
         raise NotImplementedError

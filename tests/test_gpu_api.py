@@ -205,3 +205,38 @@ def test_alignment_two_ranks_gloo_every_sharding_mode(tmp_path):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_readme_example_of_the_reference_runs_to_its_last_line(fits_pair, tmp_path):
+    """The reference's README example (README.md:47-87), statement for statement with the package name changed: construct,
+    align, write the corrected file, plot the correlation, plot the co-alignment.  The last figure is drawn from the
+    image to align resampled onto the reference image's grid by the library, before and after the correction: the
+    corrected version must follow the reference image better than the uncorrected one."""
+    import os
+    pytest.importorskip("matplotlib")
+    from euispice_coreg_amd.hdrshift import Alignment
+    ps, pl, small, hs, large, hl, truth = fits_pair
+    param_alignment = {"lag_crval1": np.arange(-30, 30, 2), "lag_crval2": np.arange(-30, 30, 2), "lag_crota": np.array([0]),
+                       "lag_cdelt1": np.array([0]), "lag_cdelt2": np.array([0])}
+    windows = [-1]
+    A = Alignment(large_fov_known_pointing=pl, small_fov_to_correct=ps, parallelism=True, display_progress_bar=True,
+                  counts_cpu_max=20, **param_alignment)
+    results = A.align_using_helioprojective(method="correlation")
+    path_save_fits = str(tmp_path / "fits.fits")
+    results.write_corrected_fits(windows, path_to_l3_output=path_save_fits)
+    results.plot_correlation(path_save_figure=os.path.join(str(tmp_path), "correlation_results.pdf"))
+    results.plot_co_alignment(path_save_figure=os.path.join(str(tmp_path), "co_alignment_results.pdf"))
+    for name in ("fits.fits", "correlation_results.pdf", "co_alignment_results.pdf"):
+        assert os.path.getsize(os.path.join(str(tmp_path), name)) > 1000
+    assert abs(results.shift_arcsec[0] - truth["lag_crval1"]) < 1.5 and abs(results.shift_arcsec[1] - truth["lag_crval2"]) < 1.5
+    c = results.co_alignment
+
+    def pearson(a, b):
+        m = np.isfinite(a) & np.isfinite(b)
+        return np.corrcoef(a[m], b[m])[0, 1]
+    assert pearson(c["reference"], c["after"]) > pearson(c["reference"], c["before"]) + 0.05
+    assert pearson(c["reference"], c["after"]) > 0.5
+    # limits of the shown part in the lag unit; SPICE cubes and the other plot types are refused, not mis-drawn
+    results.plot_co_alignment(lonlims=(-600, -100), latlims=(200, 600))
+    with pytest.raises(NotImplementedError):
+        results.plot_co_alignment(type_plot="sunpy")
