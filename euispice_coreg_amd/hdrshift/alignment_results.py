@@ -217,7 +217,8 @@ class AlignmentResults:
         the contours of the image to align before and after the pointing correction.  The image to align is put on the
         reference image's pixel grid by the library's own resampler (the exact TAN -> TAN map of the sweep, order 2),
         once with the header it came with and once with `return_corrected_header`; nothing else of the reference's
-        plotting module is reproduced (no sunpy frames, no SPICE cubes: 2-D image HDUs in helioprojective coordinates).
+        plotting module is reproduced (no sunpy frames; 2-D image HDUs and SPICE level-2 windows in helioprojective
+        coordinates; `wavelength_interval_to_sum` / `sub_fov_window` as the SPICE alignment took them).
         lonlims / latlims: (min, max) of the part of the reference image shown, in the lag unit.  Returns (fig, axes);
         `self.co_alignment` keeps the three arrays that were drawn.  Needs matplotlib (optional dependency)."""
         try:
@@ -236,13 +237,33 @@ class AlignmentResults:
         w_small = -1 if self.image_to_align_window is None else self.image_to_align_window
         w_ref = -1 if self.reference_image_window is None else self.reference_image_window
         ref, href = fits_io.read_image(self.reference_image_path, w_ref)
-        small, hs = fits_io.load_for_upload(self.image_to_align_path, w_small)
-        if np.ndim(ref) != 2 or len(getattr(small, "shape", ())) != 2:
-            raise NotImplementedError("plot_co_alignment: 2-D image HDUs only")
-        href, hs = fits_io.Header(href), fits_io.Header(hs)
+        if np.ndim(ref) != 2:
+            raise NotImplementedError("plot_co_alignment: the reference image must be a 2-D image HDU")
+        href = fits_io.Header(href)
         hdrutil.check_and_create_pcij_matrix(href, False)
-        hdrutil.check_and_create_pcij_matrix(hs, False)
-        hc = self.return_corrected_header(w_small)
+        naxis = int(fits_io.read_header(self.image_to_align_path, w_small).get("NAXIS", 0))
+        s = self.shift_arcsec
+        if naxis == 4:
+            # a SPICE level-2 window: the image the sweep saw -- wavelength planes added, slit edges masked, the 4-D
+            # header flattened (hdrshift/alignment_spice.py) -- and the correction applied to that 2-D header
+            from .alignment_spice import AlignmentSpice
+            S = AlignmentSpice(self.reference_image_path, self.image_to_align_path, small_fov_window=w_small,
+                               large_fov_window=w_ref,
+                               wavelength_interval_to_sum=kwargs.get("wavelength_interval_to_sum", "all"),
+                               sub_fov_window=kwargs.get("sub_fov_window", "all"))
+            S.extend_pixel_size = False
+            S._extract_spice_data_header(level=2)
+            small, hs = S.data_small, fits_io.Header(S.hdr_small)
+            hc = hs.copy()
+            hdrutil.correct_pointing_header(hc, lag_crval1=s[0], lag_crval2=s[1], lag_cdelt1=s[2], lag_cdelt2=s[3],
+                                            lag_crota=s[4])
+        elif naxis == 2:
+            small, hs = fits_io.load_for_upload(self.image_to_align_path, w_small)
+            hs = fits_io.Header(hs)
+            hdrutil.check_and_create_pcij_matrix(hs, False)
+            hc = self.return_corrected_header(w_small)
+        else:
+            raise NotImplementedError("plot_co_alignment: 2-D image HDUs and SPICE level-2 windows only")
         hdrutil.check_and_create_pcij_matrix(hc, False)
         h = _lib.shared_handle(-1, 0)
         h.set_small(fits_io.native_pixels(small))
@@ -273,7 +294,6 @@ class AlignmentResults:
         vmin, vmax = (np.percentile(fin, imin), np.percentile(fin, imax)) if fin.size else (None, None)
         fig, axes = plt.subplots(1, 3, figsize=(15, 5), sharex=True, sharey=True)
         extent = (i0 - 0.5, i1 - 0.5, j0 - 0.5, j1 - 0.5)
-        s = self.shift_arcsec
         titles = ("reference image", "image to align: header as it came",
                   f"corrected: dx={s[0]:.2f}'' dy={s[1]:.2f}'' drota={s[4]:.3g} deg")
         for ax, over, title in zip(axes, (None, before_c, after_c), titles):

@@ -240,3 +240,42 @@ def test_readme_example_of_the_reference_runs_to_its_last_line(fits_pair, tmp_pa
     results.plot_co_alignment(lonlims=(-600, -100), latlims=(200, 600))
     with pytest.raises(NotImplementedError):
         results.plot_co_alignment(type_plot="sunpy")
+
+
+def test_readme_spice_example_runs_to_its_last_line(tmp_path):
+    """The reference's SPICE example (README.md:172-212) on a synthetic level-2 raster file: AlignmentSpice from paths, a
+    window chosen by name, write_corrected_fits on a list of window names, plot_correlation, and plot_co_alignment with
+    two contour levels -- drawn from the spectrally summed, slit-masked image the sweep saw and its flattened header."""
+    import os
+    pytest.importorskip("matplotlib")
+    from euispice_coreg_amd import synthetic
+    from euispice_coreg_amd.hdrshift import AlignmentSpice
+    from euispice_coreg_amd.utils import fits_io
+    cube, h4, large, hl, truth = synthetic.make_spice_l2()
+    name = "Ly-gamma-CIII group (Merged)"
+    path_spice = str(tmp_path / "solo_L2_spice-n-ras_20220317T000032_V01.fits")
+    path_sr = str(tmp_path / "synthetic_raster.fits")
+    fits_io.write_images(path_spice, [(cube.astype(np.float32), dict(h4, EXTNAME=name))])
+    fits_io.write_images(path_sr, [(None, {}), (large.astype(np.float32), hl)])
+    param_alignment = {"lag_crval1": np.arange(-31.0, -14.0, 2.0), "lag_crval2": np.arange(28.0, 45.0, 2.0),
+                       "lag_crota": np.array([0]), "lag_cdelt1": np.array([0]), "lag_cdelt2": np.array([0])}
+    A = AlignmentSpice(large_fov_known_pointing=path_sr, small_fov_to_correct=path_spice, display_progress_bar=True,
+                       parallelism=True, counts_cpu_max=10, large_fov_window=-1, small_fov_window=name,
+                       path_save_figure=str(tmp_path), **param_alignment)
+    with pytest.warns(UserWarning):
+        results = A.align_using_helioprojective(method="correlation")
+    am = results.max_index
+    assert (param_alignment["lag_crval1"][am[0]], param_alignment["lag_crval2"][am[1]]) == (truth["lag_crval1"], truth["lag_crval2"])
+    out = str(tmp_path / "corrected.fits")
+    results.write_corrected_fits([name], path_to_l3_output=out)
+    h_out = fits_io.read_header(out, name)
+    assert h_out["NAXIS"] == 4 and h_out["CRVAL1"] != h4["CRVAL1"]
+    results.plot_correlation(path_save_figure=os.path.join(str(tmp_path), "correlation_results.pdf"))
+    results.plot_co_alignment(path_save_figure=os.path.join(str(tmp_path), "co_alignment_results.pdf"), levels_percentile=[80, 90])
+    assert os.path.getsize(os.path.join(str(tmp_path), "co_alignment_results.pdf")) > 1000
+    c = results.co_alignment
+
+    def pearson(a, b):
+        m = np.isfinite(a) & np.isfinite(b)
+        return np.corrcoef(a[m], b[m])[0, 1]
+    assert pearson(c["reference"], c["after"]) > pearson(c["reference"], c["before"])
