@@ -1607,6 +1607,7 @@ int begin_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_d
     h->pending_fin.clear();
     h->sums_slots = 0;
     h->pending_n_out = 0;
+    h->tap_last[0] = h->tap_last[1] = h->tap_last[2] = 0;  // (coreg_last_tap_fix speaks of THIS sweep)
     // A sweep that failed between upload_plan and end_sweep leaves its prologue armed and may have enqueued kernels that
     // still read its pinned plan slot: forget the prologue, and let everything it enqueued finish before that slot (it
     // was never handed on) is written again.
