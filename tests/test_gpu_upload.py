@@ -378,3 +378,22 @@ def test_corrupt_compressed_streams_are_refused_by_the_gpu_decoder(gpu_handle):
     rb = gpu_handle.resample_helioprojective(hdr, hdr, order=1, dtype=np.float64)
     m = np.isfinite(rb)
     assert np.array_equal(rb[m], np.asarray(good).astype(np.float64)[m])
+
+
+@pytest.mark.parametrize("tile", [(150, 40), (300, 200), (7, 3)])
+def test_compressed_tiles_of_any_size_decode_on_the_gpu(gpu_handle, tmp_path, tile):
+    """Tiles beyond what the kernel stages in LDS (4096 pixels, 16 KB of stream) take its direct path -- one lane decodes
+    straight from the heap into the image -- and tiny ragged tiles the staged one: same pixels as the host decoder."""
+    from euispice_coreg_amd.utils import fits_io
+    small, hs, _, _, _ = H.scene(small_n=96)
+    img = np.resize(small.astype(np.float32), (200, 300))
+    hdr = dict(hs, NAXIS1=300, NAXIS2=200, PC1_1=1.0, PC1_2=0.0, PC2_1=0.0, PC2_2=1.0, CROTA=0.0)
+    p = str(tmp_path / "t.fits")
+    fits_io.write_compressed_image(p, img, hdr, tile=tile, quantize="SUBTRACTIVE_DITHER_1", dither0=9000)
+    ci = fits_io.open_compressed(p, -1)
+    assert ci.on_gpu and ci.ztile == tile
+    host = ci.decode()
+    gpu_handle.set_small(ci)
+    rb = gpu_handle.resample_helioprojective(hdr, hdr, order=1, dtype=np.float64)
+    m = np.isfinite(rb)
+    assert m.mean() > 0.8 and np.abs(rb[m] - host.astype(np.float64)[m]).max() <= 1e-9
