@@ -16,7 +16,6 @@
 // compressed stream is bounds-checked: a truncated or corrupt tile yields an error flag, never an out-of-range access.
 #pragma once
 #include <cstdint>
-#include <cstddef>
 
 #if defined(__HIPCC__)
 #define COREG_HD __host__ __device__
@@ -144,76 +143,22 @@ struct QSink {
 // position (1 .. 8) of the highest set bit of a non-zero byte: cfitsio's nonzero_count[] table
 COREG_HD inline int top_bit(unsigned b) { return 32 - __builtin_clz(b); }
 
-// The compressed stream as a sequence of bits, most significant first.  `cnt` bits wait in the low end of `acc`; a refill
-// appends one aligned 32-bit word (one load per ~4 pixels instead of one per byte: on the GPU the decoding lane waits
-// for every load, LDS or global) or, at the unaligned head and at the tail of the stream, single bytes -- never a byte
-// outside [begin, end).  Past the end zeros are appended and counted (`phantom`): a decoder that consumes any of them
-// has run off a truncated or corrupt stream (`overrun`).
-struct BitReader {
-    const unsigned char* p;
-    const unsigned char* end;
-    uint64_t acc;
-    int cnt;      // valid bits in acc (the low `cnt` bits; what lies above them has been consumed)
-    int phantom;  // how many of them are zeros appended past the end of the stream
-    COREG_HD void init(const unsigned char* begin, const unsigned char* e) {
-        p = begin;
-        end = e;
-        acc = 0;
-        cnt = 0;
-        phantom = 0;
-    }
-    COREG_HD void refill() {  // leaves cnt > 32
-        while (cnt <= 32) {
-            if (p + 4 <= end && (((uintptr_t)p) & 3u) == 0) {
-                const uint32_t w = *(const uint32_t*)p;  // (aligned; big-endian bytes on a little-endian machine)
-                acc = (acc << 32) | (uint64_t)__builtin_bswap32(w);
-                cnt += 32;
-                p += 4;
-            } else if (p < end) {
-                acc = (acc << 8) | (uint64_t)*p++;
-                cnt += 8;
-            } else {
-                acc <<= 8;
-                cnt += 8;
-                if (phantom < (1 << 20)) phantom += 8;
-            }
-        }
-    }
-    COREG_HD bool overrun() const { return cnt < phantom; }
-    COREG_HD uint32_t get(int n) {  // the next n bits (0 <= n <= 32)
-        if (n == 0) return 0u;
-        if (cnt < n) refill();
-        cnt -= n;
-        return (uint32_t)(acc >> cnt) & (n == 32 ? 0xffffffffu : ((1u << n) - 1u));
-    }
-    // the number of zero bits before the next one-bit, which is consumed too; -1 when the stream ends first
-    COREG_HD int unary() {
-        int run = 0;
-        for (;;) {
-            if (cnt == 0) refill();
-            const uint64_t window = acc << (64 - cnt);  // the valid bits, left-aligned
-            if (window != 0) {
-                const int z = __builtin_clzll(window);
-                cnt -= z + 1;
-                return run + z;
-            }
-            run += cnt;
-            cnt = 0;
-            if (p >= end && phantom > 0) return -1;  // nothing but appended zeros from here on
-            refill();
-        }
-    }
-};
-
 // cfitsio fits_rdecomp / fits_rdecomp_short / fits_rdecomp_byte, one routine: BYTEPIX = 4 / 2 / 1.
-// Returns 0, or 1 when the stream ends early / is inconsistent (the remaining pixels of the tile are then written as the
-// last good value so that nothing stays uninitialised; the caller reports the error).
+// Returns 0, or 1 when the stream ends early / is inconsistent (the remaining pixels of the tile are then NaN-less garbage
+// free: they are written as the last good value so that nothing stays uninitialised; the caller reports the error).
 template <typename Sink>
 COREG_HD inline int rice_decode_tile(const unsigned char* c, int64_t clen, int nx, int nblock, int bytepix, Sink& sink) {
     const int fsbits = bytepix == 4 ? 5 : (bytepix == 2 ? 4 : 3);
     const int fsmax = bytepix == 4 ? 25 : (bytepix == 2 ? 14 : 6);
     const int bbits = 1 << fsbits;
     const unsigned vmask = bytepix == 4 ? 0xffffffffu : (bytepix == 2 ? 0xffffu : 0xffu);
+    const unsigned char* const cend = c + clen;
+    int err = 0;
+    auto next_byte = [&]() -> unsigned {
+        if (c < cend) return *c++;
+        err = 1;
+        return 0u;
+    };
     auto emit = [&](unsigned v) {  // the value modulo 2^(8 bytepix), as the signed / unsigned type of the image
         v &= vmask;
         int32_t q;
@@ -226,39 +171,69 @@ COREG_HD inline int rice_decode_tile(const unsigned char* c, int64_t clen, int n
         for (int i = 0; i < nx; ++i) emit(0u);
         return 1;
     }
-    BitReader br;
-    br.init(c, c + clen);
-    unsigned lastpix = br.get(bbits) & vmask;  // the first pixel verbatim (bbits = 8 bytepix)
-    int err = 0;
+    unsigned lastpix = 0;
+    for (int k = 0; k < bytepix; ++k) lastpix = (lastpix << 8) | next_byte();
+    unsigned b = next_byte();  // bit buffer
+    int nbits = 8;             // bits remaining in b
     for (int i = 0; i < nx;) {
-        const int fs = (int)br.get(fsbits) - 1;
+        nbits -= fsbits;
+        while (nbits < 0) {
+            b = (b << 8) | next_byte();
+            nbits += 8;
+        }
+        const int fs = (int)(b >> nbits) - 1;
+        b &= (1u << nbits) - 1u;
         int imax = i + nblock;
         if (imax > nx) imax = nx;
-        if (br.overrun() || fs > fsmax) {
-            err = 1;
-        } else if (fs < 0) {
+        if (fs < 0) {
             for (; i < imax; ++i) emit(lastpix);  // all differences zero
         } else if (fs == fsmax) {
             for (; i < imax; ++i) {  // differences stored verbatim, bbits bits each
-                unsigned diff = br.get(bbits);
+                int k = bbits - nbits;
+                unsigned diff = k < 32 ? (b << k) : 0u;
+                for (k -= 8; k >= 0; k -= 8) {
+                    b = next_byte();
+                    diff |= b << k;
+                }
+                if (nbits > 0) {
+                    b = next_byte();
+                    diff |= b >> (-k);
+                    b &= (1u << nbits) - 1u;
+                } else {
+                    b = 0;
+                }
                 diff = (diff & 1u) == 0 ? diff >> 1 : ~(diff >> 1);
                 lastpix = (diff + lastpix) & vmask;
                 emit(lastpix);
             }
-            if (br.overrun()) err = 1;
+        } else if (fs > fsmax) {
+            err = 1;
+            for (; i < imax; ++i) emit(lastpix);
         } else {
             for (; i < imax; ++i) {  // Rice code: unary high part, fs low bits
-                const int nzero = br.unary();
-                if (nzero < 0) {
-                    err = 1;
-                    break;
+                while (b == 0) {
+                    nbits += 8;
+                    b = next_byte();
+                    if (err) break;
                 }
-                unsigned diff = ((unsigned)nzero << fs) | br.get(fs);
+                if (err) {
+                    emit(lastpix);
+                    continue;
+                }
+                const int nzero = nbits - top_bit(b);
+                nbits -= nzero + 1;
+                b ^= 1u << nbits;  // flip the leading one-bit
+                nbits -= fs;
+                while (nbits < 0) {
+                    b = (b << 8) | next_byte();
+                    nbits += 8;
+                }
+                unsigned diff = ((unsigned)nzero << fs) | (b >> nbits);
+                b &= (1u << nbits) - 1u;
                 diff = (diff & 1u) == 0 ? diff >> 1 : ~(diff >> 1);
                 lastpix = (diff + lastpix) & vmask;
                 emit(lastpix);
             }
-            if (br.overrun()) err = 1;
         }
         if (err) {
             for (; i < nx; ++i) emit(lastpix);
