@@ -26,7 +26,11 @@ def _parse_value(s: str):
     s = s.strip()
     if not s:
         return None
-    if s.startswith("'"):
+    if s[0] == "'":
+        # a string: up to the closing quote ('' inside stands for one quote), trailing blanks insignificant
+        end = s.find("'", 1)
+        if end > 0 and (end + 1 >= len(s) or s[end + 1] != "'"):
+            return s[1:end].rstrip()  # (the common case: no quote inside)
         end = 1
         out = []
         while end < len(s):
@@ -39,11 +43,19 @@ def _parse_value(s: str):
             out.append(s[end])
             end += 1
         return "".join(out).rstrip()
-    s = s.split("/")[0].strip()
-    if s in ("T", "F"):
-        return s == "T"
+    k = s.find("/")
+    if k >= 0:
+        s = s[:k].strip()
+    if s == "T":
+        return True
+    if s == "F":
+        return False
     try:
         return int(s)
+    except ValueError:
+        pass
+    try:
+        return float(s)
     except ValueError:
         pass
     try:
@@ -64,25 +76,26 @@ def _read_header(f):
             raise IOError("truncated FITS header")
         raw += block
         done = False
+        text = block.decode("ascii", "replace")  # (one decode per block; cards are slices of it)
         for i in range(0, BLOCK, 80):
-            card = block[i:i + 80].decode("ascii", "replace")
-            key = card[:8].strip()
+            key = text[i:i + 8].strip()
             if key == "END":
                 done = True
                 break
+            if not key:
+                continue
+            if text[i + 8:i + 10] == "= " and key != "COMMENT" and key != "HISTORY":
+                hdr[key] = _parse_value(text[i + 10:i + 80])
+                last_key = key
+                continue
             if key == "CONTINUE" and last_key is not None:
                 # the long-string convention: a string value ending in '&' goes on in the next card's string
                 prev = hdr.get(last_key)
                 if isinstance(prev, str) and prev.endswith("&"):
-                    part = _parse_value(card[8:])
+                    part = _parse_value(text[i + 8:i + 80])
                     hdr[last_key] = prev[:-1] + (part if isinstance(part, str) else "")
                     continue
-            if not key or key in ("COMMENT", "HISTORY") or card[8:10] != "= ":
-                if key:
-                    last_key = None
-                continue
-            hdr[key] = _parse_value(card[10:])
-            last_key = key
+            last_key = None
         if done:
             break
     return hdr, raw
