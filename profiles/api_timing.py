@@ -62,6 +62,20 @@ def main():
     # best of a few warm calls
     warm = [call(p_small2 if i % 2 else p_small)["align_ms"] for i in range(6)]
     out["warm_calls_ms"] = warm
+    # the same with headers as long as the instrument's (about 250 cards instead of the scene's 35), on files the process
+    # has not seen: every call parses both headers once (cached per file state afterwards)
+    fat = {f"KEYF{k:03d}": 1.2345e-3 * k for k in range(120)}
+    fat.update({f"KEYS{k:03d}": f"string value number {k} / with a slash" for k in range(70)})
+    fat.update({f"KEYI{k:03d}": 1000 * k for k in range(25)})
+    p_l250 = os.path.join(d, "fsi_250.fits")
+    fits_io.write_images(p_l250, [(None, {}), (large.astype(np.float32), dict(hl, **fat))])
+    call_fat = []
+    for i in range(4):
+        p_s250 = os.path.join(d, f"hri_250_{i}.fits")
+        fits_io.write_images(p_s250, [(None, {}), ((small * (1 + 0.01 * i)).astype(np.float32), dict(hs, **fat))])
+        call_fat.append(call(p_s250)["align_ms"])
+        os.remove(p_s250)
+    out["warm_calls_ms_250_card_headers_new_image_each"] = call_fat
     # the two host stages of a warm call on their own (no profiler: cProfile inflates the many small scipy calls)
     from euispice_coreg_amd.hdrshift.alignment_results import AlignmentResults
     A = Alignment(large_fov_known_pointing=p_large, small_fov_to_correct=p_small, lag_crval1=lag, lag_crval2=lag,
