@@ -76,6 +76,13 @@ def main():
         call_fat.append(call(p_s250)["align_ms"])
         os.remove(p_s250)
     out["warm_calls_ms_250_card_headers_new_image_each"] = call_fat
+    call_new = []  # (the control: a new image each call, the scene's short headers)
+    for i in range(4):
+        p_s35 = os.path.join(d, f"hri_35_{i}.fits")
+        fits_io.write_images(p_s35, [(None, {}), ((small * (1 + 0.01 * i)).astype(np.float32), hs)])
+        call_new.append(call(p_s35)["align_ms"])
+        os.remove(p_s35)
+    out["warm_calls_ms_new_image_each"] = call_new
     # the two host stages of a warm call on their own (no profiler: cProfile inflates the many small scipy calls)
     from euispice_coreg_amd.hdrshift.alignment_results import AlignmentResults
     A = Alignment(large_fov_known_pointing=p_large, small_fov_to_correct=p_small, lag_crval1=lag, lag_crval2=lag,
