@@ -205,6 +205,11 @@ def _select(hdus, window):
     return i
 
 
+def _populate():
+    """MAP_POPULATE unless COREG_MMAP_POPULATE=0 (experiments: faults taken by the copy threads instead)."""
+    return getattr(mmap, "MAP_POPULATE", 0) if os.environ.get("COREG_MMAP_POPULATE", "1") != "0" else 0
+
+
 class RawImage:
     """The pixels of one image HDU exactly as the file stores them -- a read-only memory map of the data unit (big-endian
     elements) plus what decoding needs (BITPIX, BSCALE, BZERO).  The library uploads these bytes as they are and decodes
@@ -218,7 +223,7 @@ class RawImage:
         self.nbytes = nbytes
         gran = mmap.ALLOCATIONGRANULARITY
         start = (offset // gran) * gran
-        flags = mmap.MAP_SHARED | getattr(mmap, "MAP_POPULATE", 0)  # page tables filled now, not by 4096 faults later
+        flags = mmap.MAP_SHARED | _populate()  # page tables filled now, not by 4096 faults later
         with open(path, "rb") as f:
             self._mm = mmap.mmap(f.fileno(), nbytes + (offset - start), flags=flags, prot=mmap.PROT_READ, offset=start)
         self._bytes = np.frombuffer(self._mm, dtype=np.uint8, count=nbytes, offset=offset - start)
@@ -364,7 +369,7 @@ class CompressedImage:
         gran = mmap.ALLOCATIONGRANULARITY
         start = (data_pos // gran) * gran
         with open(path, "rb") as f:
-            self._mm = mmap.mmap(f.fileno(), total + (data_pos - start), flags=mmap.MAP_SHARED | getattr(mmap, "MAP_POPULATE", 0),
+            self._mm = mmap.mmap(f.fileno(), total + (data_pos - start), flags=mmap.MAP_SHARED | _populate(),
                                  prot=mmap.PROT_READ, offset=start)
         base = data_pos - start
         rows = np.frombuffer(self._mm, dtype=np.uint8, count=row_bytes * n_rows, offset=base).reshape(n_rows, row_bytes)
