@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What a file the process has never mapped costs on its way to the GPU: open (header parse + mmap) and upload of a
 2048^2 float32 image, for a file that was mapped before and for files written a moment ago, with the mapping's page
-tables filled at mmap time (MAP_POPULATE, the default) or by the faults of the copy threads (COREG_MMAP_POPULATE=0).
+tables filled at mmap time (MAP_POPULATE, COREG_MMAP_POPULATE=1) or by the faults of the copy threads (the default).
 usage: python profiles/fresh_file_upload.py   -> one JSON line"""
 import json
 import os
