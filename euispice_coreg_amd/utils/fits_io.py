@@ -540,7 +540,8 @@ def open_cube(path, window=-1):
             gran = mmap.ALLOCATIONGRANULARITY
             start = (pos // gran) * gran
             with open(path, "rb") as f:
-                mm = mmap.mmap(f.fileno(), nbytes + (pos - start), flags=mmap.MAP_SHARED | getattr(mmap, "MAP_POPULATE", 0),
+                mm = mmap.mmap(f.fileno(), nbytes + (pos - start),
+                               flags=mmap.MAP_SHARED | (0 if os.environ.get("COREG_MMAP_POPULATE_CUBE", "1") == "0" else getattr(mmap, "MAP_POPULATE", 0)),
                                prot=mmap.PROT_READ, offset=start)
             dt = np.dtype(_BITPIX_DTYPE[int(hdr["BITPIX"])])
             arr = np.frombuffer(mm, dtype=dt, count=nbytes // dt.itemsize, offset=pos - start).reshape(tuple(shape))
