@@ -708,6 +708,8 @@ int dispatch_resample(coreg_handle* h, int mode, int order, bool ts_f32, bool ou
         if (order == 2) RS_T(MODE_TRANSLATE, 2);
         else if (order == 1) RS_T(MODE_TRANSLATE, 1);
         else RS_T(MODE_TRANSLATE, ORDER_RT);
+    } else if (mode == MODE_CAR) {
+        RS_T(MODE_CAR, ORDER_RT);  // once per call, on small maps: the run-time-order gather serves every order
     } else {
         if (order == 2) RS_T(MODE_HOMOGRAPHY, 2);
         else if (order == 1) RS_T(MODE_HOMOGRAPHY, 1);
@@ -2171,6 +2173,8 @@ static int reference_crop(coreg_handle* h, int mode, const ResampleArgs& a0, int
     a.bbox = h->bbox_buf.as<double>();
     if (mode == MODE_TRANSLATE)
         hipLaunchKernelGGL((k_resample_bbox<MODE_TRANSLATE>), dim3(nb), dim3(256), 0, h->aux_stream, a);
+    else if (mode == MODE_CAR)
+        hipLaunchKernelGGL((k_resample_bbox<MODE_CAR>), dim3(nb), dim3(256), 0, h->aux_stream, a);
     else
         hipLaunchKernelGGL((k_resample_bbox<MODE_HOMOGRAPHY>), dim3(nb), dim3(256), 0, h->aux_stream, a);
     HIPCHK(hipGetLastError());
@@ -2324,19 +2328,46 @@ static int prepare_helioprojective(coreg_handle* h, const void* large, const Pix
     if (!large || !hdr_large || !hdr_small || ny < 1 || nx < 1)
         return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
     if (hdr_small->naxis1 < 1 || hdr_small->naxis2 < 1) return fail(h, COREG_EINVAL, "hdr_small: NAXIS1/2 missing");
-    if (hdr_large->proj != COREG_PROJ_TAN || hdr_small->proj != COREG_PROJ_TAN)
-        return fail(h, COREG_ENOTIMPL, "prepare_reference_helioprojective: TAN headers only");
+    if (hdr_large->proj != hdr_small->proj || (hdr_small->proj != COREG_PROJ_TAN && hdr_small->proj != COREG_PROJ_CAR))
+        return fail(h, COREG_ENOTIMPL, "prepare_reference_helioprojective: both headers TAN, or both CAR");
     RETCHK(check_order(h, order));
     RETCHK(bind_device(h));
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
-    homography(*hdr_small, *hdr_large, a.hom.h);  // alignment.py:993: pixels of hdr_cut -> pixels of hdr_large
+    int mode = MODE_HOMOGRAPHY;
+    if (hdr_small->proj == COREG_PROJ_CAR) {
+        // two Carrington maps (align_using_initial_carrington: both branches of alignment.py:649-651 / :765-767 build the
+        // sub-map for this frame too): pixel of hdr_small -> native angles -> sphere rotation -> native angles of hdr_large
+        // -> its pixel, the per-lag map of sweep_car with the roles of the two maps exchanged
+        mode = MODE_CAR;
+        Mat3 r_small, r_large;
+        if (car_native_to_celestial(*hdr_small, &r_small) || car_native_to_celestial(*hdr_large, &r_large))
+            return fail(h, COREG_EINVAL, "prepare_reference: no valid native pole for this CRVAL2 / LONPOLE (CAR)");
+        const Mat3 m = mat_mul(mat_T(r_large), r_small);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) a.hom.h[3 * i + j] = (double)m.m[i][j];
+        const Affine2 fwd = car_pix_to_native(*hdr_small), inv = car_native_to_pix(*hdr_large);
+        a.car_fwd.m00 = fwd.m00;
+        a.car_fwd.m01 = fwd.m01;
+        a.car_fwd.m10 = fwd.m10;
+        a.car_fwd.m11 = fwd.m11;
+        a.car_fwd.b0 = fwd.b0;
+        a.car_fwd.b1 = fwd.b1;
+        a.car_inv.m00 = inv.m00;
+        a.car_inv.m01 = inv.m01;
+        a.car_inv.m10 = inv.m10;
+        a.car_inv.m11 = inv.m11;
+        a.car_inv.b0 = inv.b0;
+        a.car_inv.b1 = inv.b1;
+    } else {
+        homography(*hdr_small, *hdr_large, a.hom.h);  // alignment.py:993: pixels of hdr_cut -> pixels of hdr_large
+    }
     a.W = nx;
     a.H = ny;
     a.gw = hdr_small->naxis1;
     a.gh = hdr_small->naxis2;
     CropRect crop = {0, 0, nx, ny};
-    if (kind == SRC_HOST) RETCHK(reference_crop(h, MODE_HOMOGRAPHY, a, order, &crop));
+    if (kind == SRC_HOST) RETCHK(reference_crop(h, mode, a, order, &crop));
     bool f32;
     const void* img_dev = nullptr;
     RETCHK(upload_reference_source(h, large, (size_t)ny * nx, fmt, &f32, kind, &img_dev, nx, &crop));
@@ -2344,7 +2375,7 @@ static int prepare_helioprojective(coreg_handle* h, const void* large, const Pix
     if (crop.w != nx || crop.h != ny) a.crop = {crop.x0, crop.y0, crop.w};
     HIPCHK(h->ref.reserve((size_t)a.gw * a.gh * sizeof(float)));
     a.out = h->ref.p;
-    RETCHK(dispatch_resample(h, MODE_HOMOGRAPHY, order, f32, true, a, 0));
+    RETCHK(dispatch_resample(h, mode, order, f32, true, a, 0));
     h->gW = a.gw;
     h->gH = a.gh;
     h->ref_dtype = COREG_F32;

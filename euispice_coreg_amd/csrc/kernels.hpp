@@ -553,6 +553,8 @@ struct ResampleArgs {
     int order_rt;  // ORDER == ORDER_RT: the spline order
     Crop crop;     // `img` holds this crop of the W x H image
     double* bbox;  // k_resample_bbox: [gridDim.x][4] partial (min x, max x, min y, max y) of the in-bounds coordinates
+    LaunchU car_fwd, car_inv;  // MODE_CAR: 0-based grid pixel -> its native (phi, theta) [rad]; native angles of the
+                               // source map -> its 0-based pixel; `hom` = rotation between the two native frames
 };
 // the 0-based source-pixel coordinate of output grid point idx -- ONE function for the resample and for the bounding box
 // that decides which pixels it can touch (bit-identical coordinates in both)
@@ -565,6 +567,10 @@ __device__ __forceinline__ bool resample_coord(const ResampleArgs& a, long long 
         ok = carr_term(a.carr, i, j, t0, t1);
         nx = a.x0 + t0;
         ny = a.y0 + t1;
+    } else if (MODE == MODE_CAR) {
+        const double phi = fma(a.car_fwd.m00, (double)i, fma(a.car_fwd.m01, (double)j, a.car_fwd.b0));
+        const double theta = fma(a.car_fwd.m10, (double)i, fma(a.car_fwd.m11, (double)j, a.car_fwd.b1));
+        apply_car(a.hom, a.car_inv, phi, theta, nx, ny);
     } else {
         apply_h(a.hom, (double)i, (double)j, nx, ny);
     }

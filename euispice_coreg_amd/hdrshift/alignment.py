@@ -203,7 +203,8 @@ class Alignment:
 
     def align_using_initial_carrington(self, method="correlation", return_type="AlignmentResults"):
         """alignment.py:344-399: both inputs are already Carrington maps (CRLN-CAR / CRLT-CAR, plate carree).  The image
-        to align is resampled, per lag, on the reference map's own pixel grid (no sub-map, no Carrington transform);
+        reference map is resampled once on the pixel grid of the map to align (the sub-map of alignment.py:987-1016, in
+        both the parallel and the serial branch), the map to align per lag on that same grid; no Carrington transform;
         both images are read as float32, lags are not wrapped (ang2pipi=False)."""
         self.lonlims = self.latlims = self.shape = self.reference_date = None
         self.method = method
@@ -396,13 +397,15 @@ class Alignment:
                     return h.sweep_carrington(self.hdr_small, g, sr, my_lags, order=self.order, method=method,
                                               cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
             elif self.coordinate_frame == "initial_carrington":
-                # the reference map on its own grid, float32 (alignment.py:372); neither the parallel nor the serial
-                # branch of the reference builds a sub-map for this frame (:649, :765)
-                h.set_reference_on_grid(np.asarray(self._large_pixels(), dtype=np.float32))
+                # BOTH branches of the reference name this frame in their sub-map condition (alignment.py:649-651 parallel,
+                # :765-767 serial): the reference map is resampled once on the grid of the map to align, float32, and
+                # every lag re-samples the map to align on its own grid (round 5: found by the reference-run fixtures;
+                # rounds 1-4 correlated on the reference map's full grid)
+                prepare("helioprojective", self.hdr_large, self.hdr_small, self.order)
 
                 def run():
                     select_combos()
-                    return h.sweep_helioprojective(self.hdr_large, self.hdr_small, my_lags, order=self.order,
+                    return h.sweep_helioprojective(self.hdr_small, self.hdr_small, my_lags, order=self.order,
                                                    method=method, cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
             else:
                 if self.parallelism:

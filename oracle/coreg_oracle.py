@@ -1080,11 +1080,12 @@ def step(st: SweepState, frame, data_small, data_large, d_crval1, d_crval2, d_cd
 
 def prepare_reference(st: SweepState, frame, d_solar_r, parallelism=True):
     """alignment.py:646-651 (parallel) / 762-767 (serial; quirk Q1: helioprojective keeps the
-    FULL large grid because the condition tests 'initial_helioprojective')."""
+    FULL large grid because the condition tests 'initial_helioprojective').  frame 'initial_carrington'
+    (align_using_initial_carrington, alignment.py:344-399) is named by BOTH conditions: always the sub-map."""
     if frame == "carrington":
         return carrington_transform_fa(st.data_large, st.hdr_large, d_solar_r, st.shape, st.lonlims,
                                        st.latlims, st.order)
-    if parallelism:
+    if parallelism or frame == "initial_carrington":
         return create_submap_of_large_data(st)
     return st.data_large
 
@@ -1113,14 +1114,18 @@ def _worker(args):
 
 
 def find_best_header_parameters(st: SweepState, frame, method="correlation", parallelism=True, counts=None,
-                                lag_subset=None, prepared_reference=None):
+                                lag_subset=None, prepared_reference=None, use_ang2pipi=True, reference_quirks=False):
     """alignment.py:613-797.  Returns the 6-D corr array [crval1, crval2, cdelt1, cdelt2, crota, solar_r].
+    `frame`: 'carrington', 'helioprojective' or 'initial_carrington' (CAR maps on both sides; sub-map always).
+    `use_ang2pipi`: False for align_using_initial_carrington (alignment.py:388).
+    `reference_quirks`: reproduce quirk Q10 -- the serial branch overwrites `self.data_large` with the prepared
+    reference (alignment.py:763-764), so a second `lag_solar_r` value re-projects the already re-projected image.
     `counts` > 1 fans the raveled lag list out over processes in `np.array_split` chunks with the images in
     POSIX shared memory (alignment.py:667-744); `counts` in (None, 1) runs in-process.
     `lag_subset` (indices into the raveled lag list) restricts the computation (bench sampling);
     other entries are NaN.  `prepared_reference`: the reference image already on the target grid (skips the
     once-only preparation, alignment.py:646-651, so that it can be kept out of a timed region)."""
-    set_initial_header_values(st)
+    set_initial_header_values(st, use_ang2pipi)
     table, shp = lag_table(st)
     nsr = len(st.lag_solar_r)
     corr = np.full((table.shape[0], nsr), np.nan)
@@ -1131,6 +1136,8 @@ def find_best_header_parameters(st: SweepState, frame, method="correlation", par
                 st.hdr_large = dict(st.hdr_small)  # alignment.py:1000
         else:
             data_large = prepare_reference(st, frame, d_solar_r, parallelism)
+            if reference_quirks and not parallelism and frame == "carrington":
+                st.data_large = data_large
         if np.isnan(st.data_small).all():
             raise ValueError("minimum or maximum value have set all small FOV to nan")
         idx = np.arange(table.shape[0]) if lag_subset is None else np.asarray(lag_subset)
