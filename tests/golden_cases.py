@@ -120,8 +120,8 @@ def product_replay(name, tmpdir, return_type="corr", **extra):
         if ctor.get(k) is not None:
             ctor[k] = np.asarray(ctor[k], dtype=np.float64)
     ck = dict(c.get("call_kwargs") or {})
-    unit = ck.pop("limits_unit", "arcsec")
-    assert unit == ctor.get("unit_lag", "arcsec")  # plain numbers are read in the input lag unit by the product
+    unit = ck.pop("limits_unit", None)  # plain numbers are read in the input lag unit by the product
+    assert unit is None or unit == ctor.get("unit_lag", "arcsec")
     ctor.update(extra)
     A = Alignment(large_fov_known_pointing=pl, small_fov_to_correct=ps, cdelt_semantics="reference", **ctor)
     return A, getattr(A, "align_using_" + c["call"])(return_type=return_type, **ck)

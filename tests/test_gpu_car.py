@@ -73,7 +73,7 @@ def test_align_using_initial_carrington_dropin(tmp_path):
     ps, pl = str(tmp_path / "small_car.fits"), str(tmp_path / "large_car.fits")
     fits_io.write_images(ps, [(None, {}), (small, hs)])
     fits_io.write_images(pl, [(None, {}), (large, hl)])
-    lag1, lag2 = np.arange(-20.0, 140.0, 20.0), np.arange(-120.0, 40.0, 20.0)  # arcsec; the maps are in degrees
+    lag1, lag2 = np.arange(-25.0, 135.0, 20.0), np.arange(-125.0, 35.0, 20.0)  # arcsec; the maps are in degrees
     A = Alignment(pl, ps, lag_crval1=lag1, lag_crval2=lag2, lag_cdelt1=None, lag_cdelt2=None, lag_crota=None,
                   parallelism=True, small_fov_value_max=2900.0)
     with pytest.warns(UserWarning):
@@ -82,8 +82,11 @@ def test_align_using_initial_carrington_dropin(tmp_path):
     sm = small.astype(np.float64)
     from oracle import coreg_oracle as O
     O.set_threshold_minmax_to_nan(sm, None, 2900.0)
-    want = H.oracle_helio(sm, hs, large.astype(np.float64), hl, (lag1 / 3600.0, lag2 / 3600.0, None, None, None),
-                          parallelism=False, unit_lag="deg")
+    # both branches of the reference build the sub-map for this frame (alignment.py:649-651, 765-767): the oracle's frame
+    # "initial_carrington"; pinned by the reference's own output in tests/test_gpu_reference_golden.py
+    st = H.oracle_state(sm, hs, large.astype(np.float64), hl, (lag1 / 3600.0, lag2 / 3600.0, None, None, None),
+                        unit_lag="deg")
+    want = O.find_best_header_parameters(st, "initial_carrington", use_ang2pipi=False)
     H.assert_corr_close(res.corr, want, 1e-7, "Alignment.align_using_initial_carrington")
     assert abs(res.shift_arcsec[0] - truth["lag_crval1"] * 3600) < 20 and abs(res.shift_arcsec[1] - truth["lag_crval2"] * 3600) < 20
     # TAN inputs are refused
