@@ -14,6 +14,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <functional>
 #include <vector>
 
 #include "fit.hpp"
@@ -173,7 +174,14 @@ struct coreg_handle {
         long long slot_off, n_slots, lag_begin;
         const long long* outidx_dev;
         int residus;
+        // what coreg_finalize_sums needs to re-evaluate the ill-conditioned lag-points of this launch once the ranks' sums
+        // are added (the flags come from the REDUCED sums): the launch's refine arguments and, when later launches of the
+        // same sweep have overwritten the compacted points, how to compute them again
+        RefineArgs refine;
+        std::function<int(coreg_handle*)> replay_precompute;
     };
+    std::function<int(coreg_handle*)> last_precompute;  // the precompute launch the next launch_sweep follows
+    DevBuf rf_flags, rf_pivots, rf_list, rf_head, rf_partial;  // work space of the re-evaluation (kernels.hpp: RefineArgs)
     std::vector<PendingFinalize> pending_fin;
     DevBuf fin_outidx;        // copy of the output indices of the pending sharded sweep
     long long pending_n_out = 0;
@@ -181,7 +189,7 @@ struct coreg_handle {
     // options
     int64_t opt_crop_reference = 1;
     int64_t opt_taper_min = 128, opt_taper_frac = -1, opt_taper_rounds = 6;  // tapered group shares (pick_taper)
-    int64_t opt_use_lds = 1, opt_clean_path = 1, opt_refine = 1, opt_refine_cond_log10 = 5, opt_refine_max = 4, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
+    int64_t opt_use_lds = 1, opt_clean_path = 1, opt_refine = 1, opt_refine_cond_log10 = 5, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
 
     coreg_stats stats;
     bool stats_pending = false;   // a device-output sweep is in flight: timings are collected on demand
@@ -1041,6 +1049,50 @@ struct BorderFix {  // lag-points of a launch whose border pixels are decided by
     TapFixArgs tap = {};
 };
 
+// work space + arguments of the re-evaluation of ill-conditioned lag-points (kernels.hpp: RefineArgs) for a launch of
+// n_slots lag slots whose parameters are at params_dev
+int fill_refine(coreg_handle* h, RefineArgs* r, int mode, int order, const double* params_dev, const LaunchU& car_inv,
+                long long n_slots) {
+    HIPCHK(h->rf_flags.reserve((size_t)n_slots * sizeof(int)));
+    HIPCHK(h->rf_pivots.reserve((size_t)n_slots * 2 * sizeof(double)));
+    HIPCHK(h->rf_list.reserve((size_t)n_slots * sizeof(int)));
+    HIPCHK(h->rf_head.reserve(2 * sizeof(int)));
+    // work items: (flagged slots) x (chunks per slot) <= max(kRefineBlocks, n_slots), see k_refine_list
+    HIPCHK(h->rf_partial.reserve((size_t)std::max<long long>(kRefineBlocks, n_slots) * kNumSums * sizeof(double)));
+    std::memset(r, 0, sizeof(*r));
+    r->cond = std::pow(10.0, (double)h->opt_refine_cond_log10);
+    r->mode = mode;
+    r->order = order;
+    r->small_f32 = h->small_f32 ? 1 : 0;
+    r->img = h->small.p;
+    r->W = h->sW;
+    r->H = h->sH;
+    r->pts = h->pts.as<Pt>();
+    r->tile_list = h->tile_list.as<int>();
+    r->tile_count = h->tile_count.as<int>();
+    r->tile_info = h->tile_info.as<long long>();
+    r->lane_params = params_dev;
+    r->pivots = h->pivots.as<double>();
+    r->car_inv = car_inv;
+    r->flags = h->rf_flags.as<int>();
+    r->slot_pivots = h->rf_pivots.as<double>();
+    r->list = h->rf_list.as<int>();
+    r->head = h->rf_head.as<int>();
+    r->partial = h->rf_partial.as<double>();
+    return COREG_OK;
+}
+
+// after a k_finalize that has written the flags: list the flagged slots, re-evaluate them, overwrite their coefficients.
+// Three launches without a host round trip; with nothing flagged (the normal case) every block leaves at once.
+int launch_refine(coreg_handle* h, const RefineArgs& r, long long n_slots, const long long* outidx_dev,
+                  long long lag_begin, double* out_dev) {
+    hipLaunchKernelGGL(k_refine_list, dim3(1), dim3(1024), 0, h->stream, r, n_slots, h->counters.as<long long>());
+    hipLaunchKernelGGL(k_refine, dim3(kRefineBlocks), dim3(kRefineThreads), 0, h->stream, r, n_slots);
+    hipLaunchKernelGGL(k_refine_final, dim3(64), dim3(256), 0, h->stream, r, n_slots, outidx_dev, lag_begin, out_dev);
+    HIPCHK(hipGetLastError());
+    return COREG_OK;
+}
+
 int launch_sweep(coreg_handle* h, int mode, int order, int method, const double* params_dev,
                  const long long* outidx_dev, int n_batches, int n_tiles, long long lag_begin, double* out_dev,
                  const LaunchU* car_inv = nullptr, const BorderFix* fix = nullptr, long long sums_off = 0,
@@ -1260,26 +1312,15 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     }
 
     FinalizeArgs f = {};
-    // ill-conditioned lag-points are re-evaluated by k_finalize itself (kernels.hpp: RefineArgs) -- not for method
-    // 'residus' (another statistic), not when the sums are shares of the grid (the other GPUs hold the rest), and not
-    // in a launch whose noise-decided border pixels were taken out of the sums by an extra slab
-    f.refine.enabled = (h->opt_refine && method != COREG_METHOD_RESIDUS && !sharded && !fixing) ? 1 : 0;
-    f.refine.cond = std::pow(10.0, (double)h->opt_refine_cond_log10);
-    f.refine.mode = mode;
-    f.refine.order = order;
-    f.refine.small_f32 = h->small_f32 ? 1 : 0;
-    f.refine.img = h->small.p;
-    f.refine.W = h->sW;
-    f.refine.H = h->sH;
-    f.refine.pts = h->pts.as<Pt>();
-    f.refine.tile_list = h->tile_list.as<int>();
-    f.refine.tile_count = h->tile_count.as<int>();
-    f.refine.tile_info = h->tile_info.as<long long>();
-    f.refine.lane_params = params_dev;
-    f.refine.pivots = h->pivots.as<double>();
-    f.refine.car_inv = a.car_inv;
+    // ill-conditioned lag-points are flagged by k_finalize and re-evaluated about their own means (kernels.hpp:
+    // RefineArgs) -- not for method 'residus' (another statistic) and not in a launch whose noise-decided border pixels
+    // were taken out of the sums by an extra slab.  Grid shares across GPUs: the flags can only come from the REDUCED
+    // sums, so the re-evaluation is run by coreg_finalize_sums, on every rank, over the whole grid.
+    const bool fix_any = fix && (!fix->items.empty() || fix->tap_segs > 0);  // (the same on every rank)
+    const bool refinable = h->opt_refine && method != COREG_METHOD_RESIDUS && !fix_any;
+    RETCHK(fill_refine(h, &f.refine, mode, order, params_dev, a.car_inv, n_slots));
+    f.refine.enabled = (refinable && !sharded) ? 1 : 0;
     f.refine_count = h->counters.as<long long>();  // (null before the first plan: no sweep without one)
-    f.refine_max = (int)h->opt_refine_max;
     f.partials = h->partials.as<double>();
     f.n_groups = g_per + (fixing ? 1 : 0);
     f.part_stride = n_slots;
@@ -1296,6 +1337,9 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
         pf.lag_begin = lag_begin;
         pf.outidx_dev = nullptr;  // set by coreg_finalize_sums from fin_outidx
         pf.residus = method == COREG_METHOD_RESIDUS ? 1 : 0;
+        pf.refine = f.refine;
+        pf.refine.enabled = refinable ? 1 : 0;
+        pf.replay_precompute = h->last_precompute;
         h->pending_fin.push_back(pf);
     }
     f.n_slots = n_slots;
@@ -1307,6 +1351,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_slots + kFinSlots - 1) / kFinSlots)), dim3(kFinSlots * kFinLanes), 0,
                        h->stream, f);
     HIPCHK(hipGetLastError());
+    if (f.refine.enabled) RETCHK(launch_refine(h, f.refine, n_slots, outidx_dev, lag_begin, out_dev));
     return COREG_OK;
 }
 
@@ -1853,8 +1898,8 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         if (value < -3 || value > 15) return fail(h, COREG_EINVAL, "refine_cond_log10 must be in [-3, 15]");
         h->opt_refine_cond_log10 = value;
     } else if (n == "refine_max") {
+        // round 4's cap on the re-evaluations per block of lag slots; there is no cap any more (accepted, ignored)
         if (value < 0 || value > 16) return fail(h, COREG_EINVAL, "refine_max must be in [0, 16]");
-        h->opt_refine_max = value;
     } else if (n == "tile_w") {
         if (value != 0 && (value < 1 || value > kTilePts || (value & (value - 1)) != 0))
             return fail(h, COREG_EINVAL, "tile_w must be 0 or a power of two <= 1024");
@@ -2667,7 +2712,13 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
             pa.dlon = grid->n_lon > 1 ? (std::fabs(grid->lon1 - grid->lon0) / (grid->n_lon - 1) * 1.001 + 1e-4) * kDeg2Rad : 0.0;
             pa.dlat = grid->n_lat > 1 ? (std::fabs(grid->lat1 - grid->lat0) / (grid->n_lat - 1) * 1.001 + 1e-4) * kDeg2Rad : 0.0;
         }
-        RETCHK(launch_precompute<MODE_TRANSLATE>(h, pa, n_tiles, pick_groups(h, L.n_batches, n_tiles), L.n_batches));
+        {
+            const int ng = pick_groups(h, L.n_batches, n_tiles), nb = L.n_batches;
+            RETCHK(launch_precompute<MODE_TRANSLATE>(h, pa, n_tiles, ng, nb));
+            h->last_precompute = [pa, n_tiles, ng, nb](coreg_handle* hh) {
+                return launch_precompute<MODE_TRANSLATE>(hh, pa, n_tiles, ng, nb);
+            };
+        }
         // SoA block of this launch starts at 2 * slot_off doubles (every earlier launch contributed 2 per slot)
         RETCHK(launch_sweep(h, MODE_TRANSLATE, order, method, h->lane_params.as<double>() + 2 * L.slot_off,
                             h->out_index.as<long long>() + L.slot_off, L.n_batches, n_tiles, lag_begin, out_dev, nullptr,
@@ -2826,6 +2877,12 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
         // the work partition (k_tile_list) depends on the group count of the launch: redo it only when that changes
         const int ng = pick_groups(h, L.n_batches, n_tiles);
         if (ng != last_groups || L.n_batches != last_batches) RETCHK(launch_precompute<MODE_CAR>(h, pa, n_tiles, ng, L.n_batches));
+        {
+            const int nb = L.n_batches;
+            h->last_precompute = [pa, n_tiles, ng, nb](coreg_handle* hh) {
+                return launch_precompute<MODE_CAR>(hh, pa, n_tiles, ng, nb);
+            };
+        }
         last_groups = ng;
         last_batches = L.n_batches;
         RETCHK(launch_sweep(h, MODE_CAR, order, method, h->lane_params.as<double>() + 9 * L.slot_off,
@@ -3105,7 +3162,13 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
             HIPCHK(hipMemcpy(h->border_flags.as<unsigned char>() + k * each, flags_host[k].data(), each,
                              hipMemcpyHostToDevice));
     }
-    RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles, pick_groups(h, n_batches, n_tiles), n_batches));
+    {
+        const int ng = pick_groups(h, n_batches, n_tiles);
+        RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pa, n_tiles, ng, n_batches));
+        h->last_precompute = [pa, n_tiles, ng, n_batches](coreg_handle* hh) {
+            return launch_precompute<MODE_HOMOGRAPHY>(hh, pa, n_tiles, ng, n_batches);
+        };
+    }
     h->tap_last[0] = h->tap_last[1] = h->tap_last[2] = 0;
     const double tap_box[4] = {pa.f0lo, pa.f0hi, pa.f1lo, pa.f1hi};
     if (tap_fixing)
@@ -3164,8 +3227,18 @@ int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device,
                            (long long)n_out, std::numeric_limits<double>::quiet_NaN());
         HIPCHK(hipGetLastError());
     }
-    for (const coreg_handle::PendingFinalize& pf : h->pending_fin) {
-        FinalizeArgs f = {};  // (refine.enabled = 0: these are sums over shares of the grid)
+    const size_t n_pending = h->pending_fin.size();
+    size_t points_of = n_pending - 1;  // the launch whose compacted points the handle holds: the sweep's last one
+    for (size_t ip = 0; ip < n_pending; ++ip) {
+        const coreg_handle::PendingFinalize& pf = h->pending_fin[ip];
+        FinalizeArgs f = {};
+        // flags from the REDUCED sums: the same on every rank.  (work-space pointers taken afresh: a later launch of the
+        // sweep may have grown the buffers)
+        RETCHK(fill_refine(h, &f.refine, pf.refine.mode, pf.refine.order, pf.refine.lane_params, pf.refine.car_inv,
+                           pf.n_slots));
+        f.refine.enabled = pf.refine.enabled;
+        const RefineArgs rf = f.refine;
+        f.refine_count = h->counters.as<long long>();
         f.partials = h->sums.as<double>() + pf.slot_off;
         f.n_groups = 1;
         f.n_slots = pf.n_slots;
@@ -3179,6 +3252,24 @@ int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device,
         f.sums_stride = f.sums_off = 0;
         hipLaunchKernelGGL(k_finalize, dim3((unsigned)((pf.n_slots + kFinSlots - 1) / kFinSlots)), dim3(kFinSlots * kFinLanes),
                            0, h->stream, f);
+        if (!rf.enabled) continue;
+        // Ill-conditioned lag-points: every rank holds both images and re-evaluates them over the WHOLE grid (not its
+        // share) with the same kernels in the same order -- identical coefficients on every rank, and equal to the
+        // single-GPU sweep's, without a second collective.  The compacted points of a launch that was not the sweep's
+        // last have been overwritten by the later launches: computed again, only when something is flagged.
+        hipLaunchKernelGGL(k_refine_list, dim3(1), dim3(1024), 0, h->stream, rf, pf.n_slots, h->counters.as<long long>());
+        HIPCHK(hipGetLastError());
+        int head[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(head, rf.head, sizeof(head), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (head[0] == 0) continue;
+        if (points_of != ip && pf.replay_precompute) {
+            RETCHK(pf.replay_precompute(h));
+            points_of = ip;
+        }
+        hipLaunchKernelGGL(k_refine, dim3(kRefineBlocks), dim3(kRefineThreads), 0, h->stream, rf, pf.n_slots);
+        hipLaunchKernelGGL(k_refine_final, dim3(64), dim3(256), 0, h->stream, rf, pf.n_slots, f.out_index, pf.lag_begin,
+                           out_dev);
     }
     HIPCHK(hipGetLastError());
     if (!out_on_device && n_out > 0) {

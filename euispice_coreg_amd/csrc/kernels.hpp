@@ -2082,10 +2082,15 @@ __global__ void __launch_bounds__(256) k_tap_fix(const TapFixArgs a) {
 // Ill-conditioned lag-points.  The coefficient comes from six sums taken about two GLOBAL pivots (the images' means); when
 // the samples of a lag-point lie far from a pivot compared with their own spread -- a handful of samples, or an overlap
 // inside a flat region -- the subtraction  sum xx - (sum x)^2 / n  cancels (relative error eps * sum xx / (n var)).
-// k_finalize notices (both quotients are at hand) and re-evaluates such a lag-point the way c_correlate.py:39-72 does:
-// means first, centred sums second, over every compacted point, with the arithmetic of the sweep's per-point path.
+// k_finalize notices (both quotients are at hand), FLAGS such a lag-point and leaves its own two means -- which the
+// one-pass sums do give accurately -- as the lag-point's private pivots.  Round 5: every flagged lag-point is then
+// re-evaluated, by kernels of their own (k_refine_list -> k_refine -> k_refine_final), with sums centred on THOSE pivots
+// and the corrected two-pass formula  cov = S_ab - S_a S_b / n  (the residual S_a, S_b of an approximate mean cancel to
+// first order: the result has the accuracy of c_correlate.py:39-72's means-first evaluation).  One pass over the
+// compacted points per flagged lag-point, spread over (lag-point x chunk of the tile list) work items in a fixed order:
+// no cap, deterministic, and the same on every GPU of a grid-sharded sweep.
 struct RefineArgs {
-    int enabled;  // 0: never (method 'residus', grid shares across GPUs, launches with noise-decided border pixels)
+    int enabled;  // 0: never (method 'residus', launches with noise-decided border pixels)
     double cond;  // sum xx / (n var) above which a lag-point is re-evaluated (kRefineCond; tests lower it)
     int mode, order, small_f32;
     const void* img;  // image to align, float / double [H][W]
@@ -2097,8 +2102,17 @@ struct RefineArgs {
     const double* lane_params;  // SoA [2 or 9][n_slots]
     const double* pivots;
     LaunchU car_inv;
+    // work space of the re-evaluation (per handle, sized for the launch)
+    int* flags;           // [n_slots] 1: flagged by k_finalize
+    double* slot_pivots;  // [2][n_slots] the lag-point's own means, relative to the global pivots
+    int* list;            // [n_slots] flagged slots in slot order (k_refine_list)
+    int* head;            // [0] number of flagged slots, [1] chunks per slot (k_refine_list)
+    double* partial;      // [kRefineItems-bounded][kNumSums] partial sums of the work items
 };
 constexpr double kRefineCond = 1e5;  // default threshold on sum xx / (n var) (one-pass error below it: < 1e-11)
+constexpr int kRefineBlocks = 2048;  // grid of k_refine; also the number of work items a sweep with few flagged lag-points is cut in
+constexpr int kRefineThreads = 256;
+constexpr int kRefineMaxChunks = 64;
 
 struct FinalizeArgs {
     const double* partials;
@@ -2117,105 +2131,16 @@ struct FinalizeArgs {
     long long part_stride;  // distance between the six sums of a slab (n_slots, or sums_stride when reading reduced sums)
     RefineArgs refine;
     long long* refine_count;  // device counters (diagnostics), or null: [0] re-evaluated lag-points, [1] lag-points that
-                              // were flagged but left with their one-pass value (refine_max)
-    int refine_max;           // at most this many re-evaluations per block of kFinSlots lag slots (0 = no limit): bounds
-                              // the run time of a sweep whose overlaps are degenerate everywhere
+                              // were flagged but kept their one-pass value (always 0 since round 5: there is no cap)
 };
 constexpr int kFinLanes = 16;  // threads per lag slot in k_finalize
 constexpr int kFinSlots = 16;  // lag slots per block: 256-thread blocks, 16 of them per 256-lag batch -- a sweep of two
                                // batches (one GPU's share of the headline at N = 8) still spreads over 32 CUs
 constexpr int kFinThreads = kFinSlots * kFinLanes;
 
-// One lag-point, two centred passes over all compacted points, by the whole block (fixed thread -> point assignment and
-// a fixed reduction tree: deterministic).  point_lag on a zeroed accumulator hands back (valid, a - pivot, sample - pivot).
-template <int MODE, int ORDER, typename TS>
-__device__ double refine_slot(const FinalizeArgs& a, long long slot, double (*sh)[kFinThreads]) {
-    constexpr bool ROUND = MODE != MODE_TRANSLATE;
-    const RefineArgs& r = a.refine;
-    double px0 = 0.0, py0 = 0.0;
-    H9 hm;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) hm.h[k] = 0.0;
-    if (MODE == MODE_TRANSLATE) {
-        px0 = r.lane_params[slot];
-        py0 = r.lane_params[a.n_slots + slot];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) hm.h[k] = r.lane_params[(long long)k * a.n_slots + slot];
-    }
-    const TS* __restrict__ img = (const TS*)r.img;
-    const double wmax = (double)(r.W - 1), hmax = (double)(r.H - 1), pivot_b = r.pivots[1];
-    const int n_list = (int)r.tile_info[0];
-    double mean_a = 0.0, mean_b = 0.0, res = __builtin_nan("");
-    for (int pass = 0; pass < 2; ++pass) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;  // pass 0: n, sum a, sum b; pass 1: sum da^2, sum db^2, sum da db
-        for (int tl = 0; tl < n_list; ++tl) {
-            const int tile = r.tile_list[tl];
-            const int cnt = r.tile_count[tile];
-            const Pt* __restrict__ pts = r.pts + (size_t)tile * kTilePts;
-            for (int p = threadIdx.x; p < cnt; p += kFinThreads) {
-                const Pt pt = pts[p];
-                Acc t = {0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                point_lag<MODE, ORDER, TS, false, ROUND, false>(t, 0u, img, 0, 0, 0, r.W, r.H, wmax, hmax, px0, py0, 0.0, 0.0,
-                                                                hm, r.car_inv, pt.b0, pt.b1, pt.a, pt.pad, pivot_b);
-                if (t.n) {
-                    if (pass == 0) {
-                        s0 += 1.0;
-                        s1 += t.a;
-                        s2 += t.b;
-                    } else {
-                        const double da = t.a - mean_a, db = t.b - mean_b;
-                        s0 = fma(da, da, s0);
-                        s1 = fma(db, db, s1);
-                        s2 = fma(da, db, s2);
-                    }
-                }
-            }
-        }
-        sh[0][threadIdx.x] = s0;
-        sh[1][threadIdx.x] = s1;
-        sh[2][threadIdx.x] = s2;
-        __syncthreads();
-        for (int o = kFinThreads / 2; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
-            }
-            __syncthreads();
-        }
-        const double t0 = sh[0][0], t1 = sh[1][0], t2 = sh[2][0];
-        __syncthreads();
-        if (pass == 0) {
-            if (!(t0 > 0.0)) break;  // (uniform)
-            mean_a = t1 / t0;
-            mean_b = t2 / t0;
-        } else {
-            res = t2 / sqrt(t0 * t1);
-        }
-    }
-    return res;
-}
-template <int MODE, typename TS>
-__device__ double refine_order(const FinalizeArgs& a, long long slot, double (*sh)[kFinThreads]) {
-    if (a.refine.order == 2) return refine_slot<MODE, 2, TS>(a, slot, sh);
-    if (a.refine.order == 1) return refine_slot<MODE, 1, TS>(a, slot, sh);
-    return refine_slot<MODE, ORDER_RT, TS>(a, slot, sh);
-}
-template <typename TS>
-__device__ double refine_mode(const FinalizeArgs& a, long long slot, double (*sh)[kFinThreads]) {
-    switch (a.refine.mode) {
-        case MODE_TRANSLATE: return refine_order<MODE_TRANSLATE, TS>(a, slot, sh);
-        case MODE_HOMOGRAPHY: return refine_order<MODE_HOMOGRAPHY, TS>(a, slot, sh);
-        case MODE_HOMOGRAPHY_SERIES: return refine_order<MODE_HOMOGRAPHY_SERIES, TS>(a, slot, sh);
-        default: return refine_order<MODE_CAR, TS>(a, slot, sh);
-    }
-}
-
 __global__ void __launch_bounds__(kFinThreads) k_finalize(const FinalizeArgs a) {
     // kFinLanes threads per slot each add every kFinLanes-th slab, then one adds them in order
     __shared__ double red[kFinLanes - 1][kNumSums][kFinSlots];
-    __shared__ int s_flag[kFinSlots];
-    __shared__ double s_ref[3][kFinThreads];
     const int ls = threadIdx.x % kFinSlots, j = threadIdx.x / kFinSlots;
     const long long slot = (long long)blockIdx.x * kFinSlots + ls;
     double s[kNumSums];
@@ -2233,12 +2158,12 @@ __global__ void __launch_bounds__(kFinThreads) k_finalize(const FinalizeArgs a) 
         for (int k = 0; k < kNumSums; ++k) red[j - 1][k][ls] = s[k];
     }
     __syncthreads();
-    int flag = 0;
     if (j == 0 && slot < a.n_slots) {
         for (int g = 0; g < kFinLanes - 1; ++g) {
 #pragma unroll
             for (int k = 0; k < kNumSums; ++k) s[k] += red[g][k][ls];
         }
+        int flag = 0;
         if (a.sums_out) {
 #pragma unroll
             for (int k = 0; k < kNumSums; ++k) a.sums_out[(size_t)k * a.sums_stride + a.sums_off + slot] = s[k];
@@ -2259,30 +2184,160 @@ __global__ void __launch_bounds__(kFinThreads) k_finalize(const FinalizeArgs a) 
                     r = cov / sqrt(va * vb);
                     // (negated comparisons: a NaN or non-positive variance is flagged too)
                     flag = !(va > 0.0) || !(vb > 0.0) || !(s[3] <= a.refine.cond * va) || !(s[4] <= a.refine.cond * vb);
+                    if (a.refine.enabled && flag) {
+                        a.refine.slot_pivots[slot] = s[1] / n;
+                        a.refine.slot_pivots[a.n_slots + slot] = s[2] / n;
+                    }
                 }
                 a.out[idx - a.lag_begin] = r;
             }
         }
+        if (a.refine.enabled) a.refine.flags[slot] = flag;
     }
-    if (!a.refine.enabled) return;  // (uniform)
-    if (j == 0) s_flag[ls] = flag;
+}
+
+// flagged slots in slot order (one block; deterministic), their number, and the number of chunks each one's walk over
+// the tile list is cut in: few flagged lag-points -> many chunks each, so that the re-evaluation still fills the chip
+__global__ void __launch_bounds__(1024) k_refine_list(const RefineArgs r, long long n_slots, long long* refine_count) {
+    __shared__ int wave_n[16];
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
     __syncthreads();
-    int n_done = 0;  // (uniform)
-    for (int q = 0; q < kFinSlots; ++q) {
-        if (!s_flag[q]) continue;  // (uniform: shared)
-        if (a.refine_max > 0 && n_done >= a.refine_max) {
-            // the first refine_max flagged slots of a block are re-evaluated, in slot order (deterministic); the others
-            // keep the one-pass coefficient
-            if (threadIdx.x == 0 && a.refine_count) atomicAdd((unsigned long long*)a.refine_count + 1, 1ull);
-            continue;
-        }
-        ++n_done;
-        const long long sq = (long long)blockIdx.x * kFinSlots + q;
-        const double r2 = a.refine.small_f32 ? refine_mode<float>(a, sq, s_ref) : refine_mode<double>(a, sq, s_ref);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long s0 = 0; s0 < n_slots; s0 += 1024) {
+        const long long slot = s0 + threadIdx.x;
+        const int f = slot < n_slots ? r.flags[slot] : 0;
+        const unsigned long long m = __ballot(f != 0);
+        if (lane == 0) wave_n[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_n[w];
+        if (f) r.list[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)slot;
+        __syncthreads();
         if (threadIdx.x == 0) {
-            a.out[a.out_index[sq] - a.lag_begin] = r2;
-            if (a.refine_count) atomicAdd((unsigned long long*)a.refine_count, 1ull);
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wave_n[w];
+            base += t;
         }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int n = base;
+        r.head[0] = n;
+        int chunks = n > 0 ? kRefineBlocks / n : 1;
+        chunks = chunks < 1 ? 1 : (chunks > kRefineMaxChunks ? kRefineMaxChunks : chunks);
+        r.head[1] = chunks;
+        if (refine_count && n > 0) atomicAdd((unsigned long long*)refine_count, (unsigned long long)n);
+    }
+}
+
+// one work item = (flagged lag-point, chunk of the tile list): six sums about the lag-point's own pivots over the chunk's
+// compacted points, with the arithmetic of the sweep's per-point path (point_lag on a zeroed accumulator hands back
+// (valid, a - pivot, sample - pivot)); fixed thread -> point assignment and reduction tree
+template <int MODE, int ORDER, typename TS>
+__device__ void refine_item(const RefineArgs& r, long long n_slots, int slot, int chunk, int n_chunks, double* out6,
+                            double (*sh)[kRefineThreads]) {
+    constexpr bool ROUND = MODE != MODE_TRANSLATE;
+    double px0 = 0.0, py0 = 0.0;
+    H9 hm;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) hm.h[k] = 0.0;
+    if (MODE == MODE_TRANSLATE) {
+        px0 = r.lane_params[slot];
+        py0 = r.lane_params[n_slots + slot];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) hm.h[k] = r.lane_params[(long long)k * n_slots + slot];
+    }
+    const TS* __restrict__ img = (const TS*)r.img;
+    const double wmax = (double)(r.W - 1), hmax = (double)(r.H - 1), pivot_b = r.pivots[1];
+    const double pa = r.slot_pivots[slot], pb = r.slot_pivots[n_slots + slot];
+    const int n_list = (int)r.tile_info[0];
+    double s[kNumSums];
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) s[k] = 0.0;
+    for (int tl = chunk; tl < n_list; tl += n_chunks) {
+        const int tile = r.tile_list[tl];
+        const int cnt = r.tile_count[tile];
+        const Pt* __restrict__ pts = r.pts + (size_t)tile * kTilePts;
+        for (int p = threadIdx.x; p < cnt; p += kRefineThreads) {
+            const Pt pt = pts[p];
+            Acc t = {0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            point_lag<MODE, ORDER, TS, false, ROUND, false>(t, 0u, img, 0, 0, 0, r.W, r.H, wmax, hmax, px0, py0, 0.0, 0.0, hm,
+                                                            r.car_inv, pt.b0, pt.b1, pt.a, pt.pad, pivot_b);
+            if (t.n) {
+                const double da = t.a - pa, db = t.b - pb;
+                s[0] += 1.0;
+                s[1] += da;
+                s[2] += db;
+                s[3] = fma(da, da, s[3]);
+                s[4] = fma(db, db, s[4]);
+                s[5] = fma(da, db, s[5]);
+            }
+        }
+    }
+    for (int k = 0; k < kNumSums; ++k) {
+        sh[0][threadIdx.x] = s[k];
+        __syncthreads();
+        for (int o = kRefineThreads / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out6[k] = sh[0][0];
+        __syncthreads();
+    }
+}
+template <int MODE, typename TS>
+__device__ void refine_order(const RefineArgs& r, long long n_slots, int slot, int chunk, int n_chunks, double* out6,
+                             double (*sh)[kRefineThreads]) {
+    if (r.order == 2) refine_item<MODE, 2, TS>(r, n_slots, slot, chunk, n_chunks, out6, sh);
+    else if (r.order == 1) refine_item<MODE, 1, TS>(r, n_slots, slot, chunk, n_chunks, out6, sh);
+    else refine_item<MODE, ORDER_RT, TS>(r, n_slots, slot, chunk, n_chunks, out6, sh);
+}
+template <typename TS>
+__device__ void refine_mode(const RefineArgs& r, long long n_slots, int slot, int chunk, int n_chunks, double* out6,
+                            double (*sh)[kRefineThreads]) {
+    switch (r.mode) {
+        case MODE_TRANSLATE: refine_order<MODE_TRANSLATE, TS>(r, n_slots, slot, chunk, n_chunks, out6, sh); break;
+        case MODE_HOMOGRAPHY: refine_order<MODE_HOMOGRAPHY, TS>(r, n_slots, slot, chunk, n_chunks, out6, sh); break;
+        case MODE_HOMOGRAPHY_SERIES: refine_order<MODE_HOMOGRAPHY_SERIES, TS>(r, n_slots, slot, chunk, n_chunks, out6, sh); break;
+        default: refine_order<MODE_CAR, TS>(r, n_slots, slot, chunk, n_chunks, out6, sh); break;
+    }
+}
+__global__ void __launch_bounds__(kRefineThreads) k_refine(const RefineArgs r, long long n_slots) {
+    __shared__ double sh[1][kRefineThreads];
+    const int n = r.head[0], n_chunks = r.head[1];  // (uniform; every wave leaves when there is nothing flagged)
+    const long long items = (long long)n * n_chunks;
+    for (long long w = blockIdx.x; w < items; w += gridDim.x) {
+        const int slot = r.list[w / n_chunks], chunk = (int)(w % n_chunks);
+        double* out6 = r.partial + (size_t)w * kNumSums;
+        if (r.small_f32) refine_mode<float>(r, n_slots, slot, chunk, n_chunks, out6, sh);
+        else refine_mode<double>(r, n_slots, slot, chunk, n_chunks, out6, sh);
+    }
+}
+// the chunks of a flagged lag-point added in chunk order, then the corrected two-pass coefficient
+__global__ void __launch_bounds__(256) k_refine_final(const RefineArgs r, long long n_slots, const long long* out_index,
+                                                      long long lag_begin, double* out) {
+    const int n = r.head[0], n_chunks = r.head[1];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        double s[kNumSums];
+#pragma unroll
+        for (int k = 0; k < kNumSums; ++k) s[k] = 0.0;
+        for (int c = 0; c < n_chunks; ++c) {
+            const double* p = r.partial + ((size_t)e * n_chunks + c) * kNumSums;
+#pragma unroll
+            for (int k = 0; k < kNumSums; ++k) s[k] += p[k];
+        }
+        const int slot = r.list[e];
+        const double cnt = s[0];
+        double res = __builtin_nan("");
+        if (cnt > 0.0) {
+            const double cov = s[5] - s[1] * s[2] / cnt;
+            const double va = s[3] - s[1] * s[1] / cnt;
+            const double vb = s[4] - s[2] * s[2] / cnt;
+            res = cov / sqrt(va * vb);
+        }
+        out[out_index[slot] - lag_begin] = res;
     }
 }
 
