@@ -158,6 +158,28 @@ def test_headline_60x60_map_against_the_oracle(gpu_handle, big_scene, small_f64)
         want = O.step(st, "carrington", st.data_small, ref, d1, d2, 0.0, 0.0, 0.0, 1.004)
         got = full[int(d1 + 30), int(d2 + 30)]
         assert abs(got - want) <= 1e-10, (small_f64, d1, d2, got, want)
+    if small_f64:
+        return
+    # 5 of 3600 lag-points was thin.  (i) 256 seeded lag-points the oracle evaluated in the build
+    # container (tests/golden/make_golden_headline.py; the fingerprint says the regenerated scene holds the same pixels)
+    import os
+    from tests.conftest import GOLDEN
+    from tests.golden.make_golden_headline import fingerprint
+    g = np.load(os.path.join(GOLDEN, "headline_sample.npz"))
+    assert np.array_equal(fingerprint(small, large), g["fingerprint"]), "the synthetic scene differs from the golden run's"
+    d = np.abs(full.ravel()[g["index"]] - g["corr"])
+    print("headline map vs 256 committed oracle lag-points: max |dcorr|", d.max())
+    assert d.max() <= 1e-10
+    # (ii) 64 more, evaluated NOW by the oracle's process pool (alignment.py:667-744 restated) on this box's cores
+    rng = np.random.default_rng(5)
+    idx = np.sort(rng.choice(np.setdiff1d(np.arange(3600), g["index"]), size=64, replace=False))
+    stp = H.oracle_state(small, hs, large, hl, (lag, lag, None, None, None), shape=list(SHAPE), lonlims=list(LON),
+                         latlims=list(LAT), solar_r=(1.004,))
+    live = O.find_best_header_parameters(stp, "carrington", counts=min(16, os.cpu_count() or 1), lag_subset=idx,
+                                         prepared_reference=ref).ravel()[idx]
+    d2 = np.abs(full.ravel()[idx] - live)
+    print("headline map vs 64 live oracle lag-points: max |dcorr|", d2.max())
+    assert d2.max() <= 1e-10
 
 
 def test_degenerate_overlaps_everywhere_stay_bounded_at_full_size(gpu_handle, big_scene):
