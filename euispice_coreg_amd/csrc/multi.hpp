@@ -306,6 +306,87 @@ void multi_drop_rccl(coreg_multi* m, const char* why) {
     (void)multi_run(m, [&](int k) { return coreg_synchronize(m->h[k]); });
 }
 
+// ---- every wait on RCCL is bounded ------------------------------------------------------------
+// A grouped collective is enqueued on the handles' own streams; what can fail to come back is the streams.  After each
+// group the streams are polled (hipStreamQuery) for at most COREG_RCCL_WAIT_SECONDS (default 20, as the creation-time
+// self-test); on expiry the communicators are aborted (ncclCommAbort releases the kernels a group holds on a stream),
+// RCCL is dropped for this handle, and the caller hands the intact per-device results over through the host.
+inline double multi_rccl_wait_limit() {
+    const char* env = std::getenv("COREG_RCCL_WAIT_SECONDS");
+    return env && std::atof(env) > 0 ? std::atof(env) : 20.0;
+}
+
+// Fault injection for the tests (COREG_RCCL_TEST_STALL=1): instead of the group's collective, every stream gets a kernel
+// that spins on a flag in page-locked host memory -- a collective that never completes, as far as the stream can tell.
+// The abort path sets the flag; the kernel also leaves by itself after ~3 s of GPU clock, so that a bug in the recovery
+// cannot hold the device.
+__global__ void k_test_stall(volatile int* release) {
+    const long long t0 = wall_clock64();
+    while (*release == 0 && wall_clock64() - t0 < 300000000LL) __builtin_amdgcn_s_sleep(64);  // 100 MHz counter: 3 s
+}
+struct StallFlag {
+    int* p = nullptr;
+    StallFlag() {
+        if (hipHostMalloc((void**)&p, sizeof(int), hipHostMallocPortable) != hipSuccess) p = nullptr;
+        if (p) *p = 0;
+    }
+    ~StallFlag() {
+        if (p) (void)hipHostFree(p);
+    }
+};
+inline bool multi_test_stall() {
+    const char* env = std::getenv("COREG_RCCL_TEST_STALL");
+    return env && std::atoi(env) == 1;
+}
+
+// true: every stream has drained.  false: at least one did not within the limit (or reported an error) -- the
+// communicators are aborted and RCCL is given up for this handle; the streams are usable again on return.
+bool multi_wait_group(coreg_multi* m, const char* what, StallFlag* stall = nullptr) {
+    const double limit = multi_rccl_wait_limit();
+    std::vector<int> state(m->n, 0);  // 1 = drained, 2 = error, 3 = timed out
+    (void)multi_run(m, [&](int k) {
+        coreg_handle* h = m->h[k];
+        RETCHK(bind_device(h));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) {
+                state[k] = 1;
+                return COREG_OK;
+            }
+            if (q != hipErrorNotReady) {
+                state[k] = 2;
+                return COREG_OK;
+            }
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dt > limit) {
+                state[k] = 3;
+                return COREG_OK;
+            }
+            if (dt < 0.005) std::this_thread::yield();  // a sweep's collective takes microseconds to milliseconds
+            else std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    });
+    bool ok = true, timed_out = false;
+    for (int k = 0; k < m->n; ++k) {
+        ok = ok && state[k] == 1;
+        timed_out = timed_out || state[k] == 3;
+    }
+    if (ok) return true;
+    // (test: the injected "collective" is what the abort releases -- before ncclCommAbort, which waits for the
+    // communicator's stream work)
+    if (stall && stall->p) *stall->p = 1;
+    RcclApi& api = RcclApi::get();
+    for (ncclComm_t c : m->comms)
+        if (c) {
+            if (api.CommAbort) (void)api.CommAbort(c);
+            else (void)api.CommDestroy(c);
+        }
+    m->comms.clear();
+    multi_drop_rccl(m, (std::string(what) + (timed_out ? " did not complete in time" : " failed on a stream")).c_str());
+    return false;
+}
+
 // one sweep on every device + the collective; `launch(k, lags_k, begin, end, out_dev)` = the per-device sweep call
 int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out, bool per_combo_launch,
                 const std::function<int(int, const coreg_lags*, int64_t, int64_t, double*)>& launch) {
@@ -377,21 +458,40 @@ int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out, bool p
         coreg_sums_size(m->h[0], &n6);
         bool reduced_on_device = false;
         if (rccl && n6 > 0) {
-            ncclResult_t e = RcclApi::get().GroupStart();
-            for (int k = 0; k < world && e == ncclSuccess; ++k)
-                e = RcclApi::get().AllReduce(m->h[k]->sums.p, m->h[k]->sums.p, (size_t)n6, ncclDouble, ncclSum, m->comms[k],
-                                             m->h[k]->stream);
-            const ncclResult_t e2 = RcclApi::get().GroupEnd();
-            if (e != ncclSuccess || e2 != ncclSuccess) {
-                // (an all-reduce that failed half-way may have touched the sums: this sweep cannot be salvaged, the
-                // next one goes through the host)
-                multi_drop_rccl(m, "RCCL all-reduce failed");
-                return mfail(m, COREG_EHIP, "RCCL all-reduce failed (later sweeps of this handle add the sums on the host)");
+            // OUT of place (into gat[k]): whatever happens to the collective, every device's own sums stay intact and
+            // the host path below can still add them
+            RETCHK(multi_run(m, [&](int k) {
+                coreg_handle* h = m->h[k];
+                RETCHK(bind_device(h));
+                HIPCHK(m->gat[k].reserve((size_t)n6 * sizeof(double)));
+                return COREG_OK;
+            }));
+            StallFlag stall;
+            ncclResult_t e = ncclSuccess, e2 = ncclSuccess;
+            if (multi_test_stall() && stall.p) {
+                (void)multi_run(m, [&](int k) {
+                    RETCHK(bind_device(m->h[k]));
+                    hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, m->h[k]->stream, (volatile int*)stall.p);
+                    return COREG_OK;
+                });
+            } else {
+                e = RcclApi::get().GroupStart();
+                for (int k = 0; k < world && e == ncclSuccess; ++k)
+                    e = RcclApi::get().AllReduce(m->h[k]->sums.p, m->gat[k].p, (size_t)n6, ncclDouble, ncclSum, m->comms[k],
+                                                 m->h[k]->stream);
+                e2 = RcclApi::get().GroupEnd();
             }
-            reduced_on_device = true;
+            if (e != ncclSuccess || e2 != ncclSuccess) {
+                multi_drop_rccl(m, "RCCL all-reduce failed");
+                m->collective = "host-copy (RCCL all-reduce failed)";
+            } else if (!multi_wait_group(m, "RCCL all-reduce", &stall) || multi_test_stall()) {
+                m->collective = "host-copy (RCCL all-reduce did not complete)";
+            } else {
+                reduced_on_device = true;
+            }
         }
         if (reduced_on_device) {
-            m->w[0]->post([&] { rc = coreg_finalize_sums(m->h[0], m->h[0]->sums.as<double>(), 1, corr_out, 0); });
+            m->w[0]->post([&] { rc = coreg_finalize_sums(m->h[0], m->gat[0].as<double>(), 1, corr_out, 0); });
             m->w[0]->wait();
             if (rc != COREG_OK) mfail(m, rc, coreg_last_error(m->h[0]));
         } else if (n6 > 0) {
@@ -472,15 +572,30 @@ int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out, bool p
     if (rccl) {
         // THE collective: one all-gather of `chunk` doubles per device, all devices in one group, each on the stream its
         // sweep was enqueued on
-        ncclResult_t e = RcclApi::get().GroupStart();
-        for (int k = 0; k < world && e == ncclSuccess; ++k)
-            e = RcclApi::get().AllGather(m->blk[k].p, m->gat[k].p, (size_t)chunk, ncclDouble, m->comms[k], m->h[k]->stream);
-        const ncclResult_t e2 = RcclApi::get().GroupEnd();
+        StallFlag stall;
+        ncclResult_t e = ncclSuccess, e2 = ncclSuccess;
+        if (multi_test_stall() && stall.p) {
+            (void)multi_run(m, [&](int k) {
+                RETCHK(bind_device(m->h[k]));
+                hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, m->h[k]->stream, (volatile int*)stall.p);
+                return COREG_OK;
+            });
+        } else {
+            e = RcclApi::get().GroupStart();
+            for (int k = 0; k < world && e == ncclSuccess; ++k)
+                e = RcclApi::get().AllGather(m->blk[k].p, m->gat[k].p, (size_t)chunk, ncclDouble, m->comms[k], m->h[k]->stream);
+            e2 = RcclApi::get().GroupEnd();
+        }
         if (e != ncclSuccess || e2 != ncclSuccess) {
             // the blocks themselves are intact on their devices: hand them over through the host instead, now and for
             // every later sweep of this handle
             multi_drop_rccl(m, "RCCL all-gather failed");
             m->collective = "host-copy (RCCL all-gather failed)";
+            rccl = false;
+            RETCHK(multi_run(m, to_host));
+        } else if (!multi_wait_group(m, "RCCL all-gather", &stall) || multi_test_stall()) {
+            // a group that did not come back within the limit: aborted; the blocks are intact on their devices
+            m->collective = "host-copy (RCCL all-gather did not complete)";
             rccl = false;
             RETCHK(multi_run(m, to_host));
         } else {
@@ -551,6 +666,7 @@ int multi_set_small_shares(coreg_multi* m, const void* src, const PixFmt& fmt, c
         multi_drop_rccl(m, "RCCL all-gather of the image failed");
         return COREG_ENOTIMPL;
     }
+    if (!multi_wait_group(m, "RCCL all-gather of the image")) return COREG_ENOTIMPL;  // (the caller stages the whole image)
     return multi_run(m, [&](int k) {
         coreg_handle* h = m->h[k];
         if (px) {
@@ -722,13 +838,49 @@ int coreg_multi_create(coreg_multi** out, int n_devices, const int* device_ids) 
     const bool want_rccl = !(coll && std::string(coll) == "host");
     m->force_collective = m->n == 1 && force && std::atoi(force) == 1;
     if (want_rccl && (m->n > 1 || m->force_collective) && distinct && RcclApi::get().ok()) {
-        m->comms.assign(m->n, nullptr);
-        if (RcclApi::get().CommInitAll(m->comms.data(), m->n, m->devices.data()) == ncclSuccess) {
-            m->use_rccl = true;
-            multi_rccl_selftest(m);  // a group that does not gather a known pattern is not used for results
+        // ncclCommInitAll on a helper thread, waited for with the self-test's limit: a bootstrap that never returns costs
+        // this handle RCCL (host copies instead), never the process.  The thread owns its arguments (shared state), so
+        // that it may outlive this function; it is detached only when it has not come back in time.
+        struct InitState {
+            std::vector<ncclComm_t> comms;
+            std::vector<int> devs;
+            std::mutex mu;
+            std::condition_variable cv;
+            bool done = false;
+            ncclResult_t rc = ncclSuccess;
+        };
+        auto st = std::make_shared<InitState>();
+        st->comms.assign(m->n, nullptr);
+        st->devs = m->devices;
+        std::thread init([st] {
+            const char* stall = std::getenv("COREG_RCCL_TEST_INIT_STALL_SECONDS");  // tests: a bootstrap that hangs
+            if (stall && std::atof(stall) > 0)
+                std::this_thread::sleep_for(std::chrono::milliseconds((long long)(std::atof(stall) * 1000)));
+            const ncclResult_t r = RcclApi::get().CommInitAll(st->comms.data(), (int)st->devs.size(), st->devs.data());
+            std::lock_guard<std::mutex> lk(st->mu);
+            st->rc = r;
+            st->done = true;
+            st->cv.notify_all();
+        });
+        const char* env = std::getenv("COREG_RCCL_SELFTEST_SECONDS");
+        const double limit = env && std::atof(env) > 0 ? std::atof(env) : 20.0;
+        bool in_time;
+        {
+            std::unique_lock<std::mutex> lk(st->mu);
+            in_time = st->cv.wait_for(lk, std::chrono::milliseconds((long long)(limit * 1000)), [&] { return st->done; });
+        }
+        if (!in_time) {
+            init.detach();  // (its communicators, if it ever gets them, are never used)
+            m->rccl_error = "ncclCommInitAll did not return in time";
         } else {
-            m->comms.clear();
-            m->rccl_error = "ncclCommInitAll failed";
+            init.join();
+            if (st->rc == ncclSuccess) {
+                m->comms = st->comms;
+                m->use_rccl = true;
+                multi_rccl_selftest(m);  // a group that does not gather a known pattern is not used for results
+            } else {
+                m->rccl_error = "ncclCommInitAll failed";
+            }
         }
     }
     m->collective = m->use_rccl ? "rccl" : (m->n > 1 ? "host-copy" : "none");

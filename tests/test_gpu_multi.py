@@ -176,6 +176,46 @@ def test_multi_rccl_calls_run_with_a_one_rank_group(gpu_handle, monkeypatch, tmp
         m.set_option("image_shares", 1)
 
 
+def test_a_collective_that_never_completes_is_aborted_and_the_map_still_comes_out_right(gpu_handle, monkeypatch):
+    """every RCCL wait of the one-process driver is bounded.  COREG_RCCL_TEST_STALL=1 puts, in place
+    of the group's all-gather, a kernel on the stream that does not end before it is told to (the stream then looks
+    exactly like one holding a collective that never completes); COREG_RCCL_WAIT_SECONDS bounds the wait.  On expiry the
+    communicator is aborted, RCCL dropped for the handle, and the intact per-device block reaches the host by a copy:
+    the right map, this sweep and the next.  Likewise a communicator bootstrap that does not return in time
+    (COREG_RCCL_TEST_INIT_STALL_SECONDS) costs the handle RCCL, not the process."""
+    import time
+    from euispice_coreg_amd import _lib
+    monkeypatch.delenv("COREG_VIRTUAL_DEVICES", raising=False)
+    monkeypatch.setenv("COREG_MULTI_FORCE_RCCL", "1")
+    small, hs, large, hl, _ = H.scene()
+    lags = (17.0 + 1.0 * (np.arange(12) - 6), -9.0 + 1.0 * (np.arange(12) - 6), None, None, None)
+    want = _single_carr(gpu_handle, small, hs, large, hl, lags)
+    with _lib.MultiHandle(device_ids=[0]) as m:
+        if m.collective != "rccl":
+            pytest.skip("no RCCL runtime could be loaded in this process")
+        monkeypatch.setenv("COREG_RCCL_TEST_STALL", "1")
+        monkeypatch.setenv("COREG_RCCL_WAIT_SECONDS", "0.4")
+        t0 = time.perf_counter()
+        got = _multi_carr(m, small, hs, large, hl, lags)
+        dt = time.perf_counter() - t0
+        assert np.array_equal(got, want, equal_nan=True)
+        assert "did not complete" in m.collective and "did not complete in time" in m.rccl_status
+        assert 0.4 <= dt < 2.5, dt  # the wait was bounded by the limit, not by the stall kernel's own 3 s
+        monkeypatch.delenv("COREG_RCCL_TEST_STALL")
+        again = _multi_carr(m, small, hs, large, hl, lags)  # RCCL is gone for this handle: host copies
+        assert np.array_equal(again, want, equal_nan=True) and m.collective == "host-copy"
+    # a bootstrap that hangs: the handle comes up without RCCL after the limit and still sweeps correctly
+    monkeypatch.setenv("COREG_RCCL_TEST_INIT_STALL_SECONDS", "1.5")
+    monkeypatch.setenv("COREG_RCCL_SELFTEST_SECONDS", "0.3")
+    t0 = time.perf_counter()
+    with _lib.MultiHandle(device_ids=[0]) as m:
+        assert time.perf_counter() - t0 < 1.4
+        assert m.rccl_status == "ncclCommInitAll did not return in time" and m.collective != "rccl"
+        got = _multi_carr(m, small, hs, large, hl, lags)
+        assert np.array_equal(got, want, equal_nan=True)
+    time.sleep(1.5)  # (let the helper thread finish its bootstrap before the environment changes under it)
+
+
 def test_alignment_uses_every_visible_gpu_from_a_plain_script(tmp_path, monkeypatch):
     """`Alignment(..., parallelism=True).align_using_carrington()` with no torch.distributed: the library drives every
     (here: virtual) GPU itself; same map as the single-device context, and an explicit device= keeps the latter."""
