@@ -448,8 +448,11 @@ class CoregHandle:
             t, keep = _fits_tiled(img)
             self._chk(self._lib.coreg_set_small_tiled(self._h, C.byref(t)))
             return
+        # (option "async_upload": the library's upload thread reads the pixels after this call has returned -- the object
+        # that owns them is kept until the next upload replaces it; the caller must not modify them meanwhile)
         if _is_raw(img):
             px = _fits_pixels(img)
+            self._small_keepalive = (img, px)
             self._chk(self._lib.coreg_set_small_fits(self._h, C.byref(px), img.shape[0], img.shape[1]))
             return
         img = np.asarray(img)
@@ -457,6 +460,7 @@ class CoregHandle:
             raise ValueError("small image must be 2-D")
         if img.dtype == np.float32:
             img = np.ascontiguousarray(img)
+            self._small_keepalive = img
             self._chk(self._lib.coreg_set_small_f32(self._h, img.ctypes.data, img.shape[0], img.shape[1]))
         else:
             img = np.ascontiguousarray(img, dtype=np.float64)

@@ -148,6 +148,29 @@ struct coreg_handle {
     PrologueArgs pending_prologue = {};  // set by upload_plan, consumed by the sweep's first k_precompute launch
     DevBuf bbox_buf;         // reference_crop: partial bounding boxes
     hipStream_t aux_stream = nullptr;  // side stream of reference_crop (created on first use)
+    // The image to align goes up on a stream of its own (round 5): the preparation of the reference image -- bounding
+    // box, crop upload, resample -- depends on headers and the reference image only and no longer queues behind the
+    // 16 MiB of the image to align; the first call that reads the image (or its pivot) joins the two streams with an event
+    // (bind_device).  float32 / byte-swap-only uploads from host memory; everything else stays on `stream`.
+    hipStream_t up_stream = nullptr;
+    hipEvent_t ev_small = nullptr, ev_main = nullptr;
+    bool small_pending = false;
+    DevBuf red_sum_up, red_cnt_up;  // device_mean's scratch on up_stream
+    int64_t opt_overlap_upload = 1;
+    // "async_upload" (opt-in: the caller's image buffer must stay valid and unchanged until the next call that reads the
+    // image returns): the staging copies + DMA of coreg_set_small_f32 / _fits run on a worker thread of the handle, so that
+    // the calling thread goes on to prepare the reference and plan the sweep meanwhile; joined before the first kernel
+    // that reads the image (join_small).  Staging and events of its own: nothing is shared with the calling thread.
+    int64_t opt_async_upload = 0;
+    std::thread up_thread;
+    std::mutex up_m;
+    std::condition_variable up_cv;
+    std::function<hipError_t()> up_job;
+    bool up_has = false, up_stop = false, up_busy = false;
+    hipError_t up_rc = hipSuccess;
+    PinBuf pin_small[2];
+    hipEvent_t ev_pin_small[2] = {nullptr, nullptr};
+    int pin_small_next = 0;
     // zero-lag border decision of the helioprojective sub-map path (geometry.hpp WcslibTan): grid pixels the
     // reference's wcslib round trip drops, cached per header
     std::map<std::vector<double>, std::vector<int>> border_cache;
@@ -226,8 +249,81 @@ int fail(coreg_handle* h, int code, const std::string& msg) {
         if (_r != COREG_OK) return _r; \
     } while (0)
 
+int bind_device_nowait(coreg_handle* h) {
+    HIPCHK(hipSetDevice(h->device));
+    return COREG_OK;
+}
+// every entry point but the reference preparation: work enqueued on the handle's stream from here on sees the image to
+// align a preceding set_small put on the upload stream
+// the image to align is on its way on the upload stream (possibly still being issued by the handle's upload thread):
+// make the handle's stream wait for it
+int join_small(coreg_handle* h) {
+    if (!h->small_pending) return COREG_OK;
+    hipError_t worker_rc = hipSuccess;
+    {
+        std::unique_lock<std::mutex> lk(h->up_m);
+        h->up_cv.wait(lk, [&] { return !h->up_busy && !h->up_has; });
+        worker_rc = h->up_rc;
+        h->up_rc = hipSuccess;
+    }
+    h->small_pending = false;
+    if (worker_rc != hipSuccess)
+        return fail(h, COREG_EHIP, std::string("asynchronous upload of the image to align: ") + hipGetErrorString(worker_rc));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_small, 0));
+    return COREG_OK;
+}
 int bind_device(coreg_handle* h) {
     HIPCHK(hipSetDevice(h->device));
+    return join_small(h);
+}
+void upload_thread_main(coreg_handle* h) {
+    for (;;) {
+        std::function<hipError_t()> job;
+        {
+            std::unique_lock<std::mutex> lk(h->up_m);
+            h->up_cv.wait(lk, [&] { return h->up_stop || h->up_has; });
+            if (h->up_stop) return;
+            job = std::move(h->up_job);
+            h->up_has = false;
+            h->up_busy = true;
+        }
+        const hipError_t rc = job();
+        {
+            std::lock_guard<std::mutex> lk(h->up_m);
+            h->up_rc = rc;
+            h->up_busy = false;
+        }
+        h->up_cv.notify_all();
+    }
+}
+void post_upload(coreg_handle* h, std::function<hipError_t()> job) {
+    if (!h->up_thread.joinable()) h->up_thread = std::thread(upload_thread_main, h);
+    {
+        std::lock_guard<std::mutex> lk(h->up_m);
+        h->up_job = std::move(job);
+        h->up_has = true;
+    }
+    h->up_cv.notify_all();
+}
+// the stream an upload of the image to align runs on: the upload stream, made to wait for what the handle's stream has
+// been given so far (an earlier sweep may still be reading the old image), or the handle's stream itself
+int begin_small_upload(coreg_handle* h, hipStream_t* s) {
+    *s = h->stream;
+    if (!h->opt_overlap_upload) return COREG_OK;
+    if (!h->up_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_small, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(h->ev_main, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->up_stream, h->ev_main, 0));
+    *s = h->up_stream;
+    return COREG_OK;
+}
+int end_small_upload(coreg_handle* h, hipStream_t s) {
+    if (s == h->stream) return COREG_OK;
+    HIPCHK(hipEventRecord(h->ev_small, s));
+    h->small_pending = true;
     return COREG_OK;
 }
 
@@ -241,14 +337,16 @@ EventPair* next_event(coreg_handle* h, std::vector<EventPair>& v, size_t& used) 
 }
 
 template <typename T>
-int device_mean(coreg_handle* h, const T* v, long long n, double* mean_dev) {
+int device_mean(coreg_handle* h, const T* v, long long n, double* mean_dev, hipStream_t s = nullptr) {
     const int nb = 256;
-    HIPCHK(h->red_sum.reserve(nb * sizeof(double)));
-    HIPCHK(h->red_cnt.reserve(nb * sizeof(long long)));
-    hipLaunchKernelGGL((k_sum_finite<T>), dim3(nb), dim3(256), 0, h->stream, v, n, h->red_sum.as<double>(),
-                       h->red_cnt.as<long long>());
-    hipLaunchKernelGGL(k_mean_final, dim3(1), dim3(64), 0, h->stream, h->red_sum.as<double>(),
-                       h->red_cnt.as<long long>(), nb, mean_dev);
+    const bool up = s && s != h->stream;  // (the upload stream has scratch of its own)
+    if (!s) s = h->stream;
+    DevBuf& sum = up ? h->red_sum_up : h->red_sum;
+    DevBuf& cnt = up ? h->red_cnt_up : h->red_cnt;
+    HIPCHK(sum.reserve(nb * sizeof(double)));
+    HIPCHK(cnt.reserve(nb * sizeof(long long)));
+    hipLaunchKernelGGL((k_sum_finite<T>), dim3(nb), dim3(256), 0, s, v, n, sum.as<double>(), cnt.as<long long>());
+    hipLaunchKernelGGL(k_mean_final, dim3(1), dim3(64), 0, s, sum.as<double>(), cnt.as<long long>(), nb, mean_dev);
     HIPCHK(hipGetLastError());
     return COREG_OK;
 }
@@ -263,7 +361,11 @@ public:
         return p;
     }
     void copy(void* dst, const void* src, size_t bytes) {
-        const size_t min_per_thread = (size_t)512 << 10;
+        static const size_t min_per_thread = [] {
+            const char* e = std::getenv("COREG_UPLOAD_MIN_KIB");
+            const int v = e ? std::atoi(e) : 0;
+            return (size_t)(v > 0 ? v : 512) << 10;
+        }();
         const unsigned nt = (unsigned)std::min<size_t>(workers_.size() + 1, std::max<size_t>(1, bytes / min_per_thread));
         if (nt <= 1) {
             std::memcpy(dst, src, bytes);
@@ -284,7 +386,7 @@ public:
             ++epoch_;
         }
         cv_.notify_all();
-        std::memcpy(dst, src, std::min(per, bytes));
+        copy_stream((char*)dst, (const char*)src, std::min(per, bytes));
         std::unique_lock<std::mutex> lk(m_);
         done_.wait(lk, [&] { return pending_ == 0; });
     }
@@ -353,13 +455,43 @@ private:
             }
         }
     }
+    // The destination is page-locked staging the CPU never reads back: non-temporal stores spare the read-for-ownership
+    // of every destination line (glibc's memcpy only switches to them far above the 100-500 KB a worker copies).
+    // COREG_UPLOAD_NT=0 keeps memcpy.
+    static void copy_stream(char* dst, const char* src, size_t n) {
+        typedef long long v4 __attribute__((vector_size(32), aligned(32)));
+        static const bool nt = [] {
+            const char* e = std::getenv("COREG_UPLOAD_NT");
+            return !(e && std::atoi(e) == 0);
+        }();
+        if (!nt || n < 4096) {
+            std::memcpy(dst, src, n);
+            return;
+        }
+        const size_t head = (32 - ((uintptr_t)dst & 31)) & 31;
+        if (head) std::memcpy(dst, src, head);
+        size_t i = head;
+        for (; i + 128 <= n; i += 128) {
+            v4 a, b, c, d;
+            std::memcpy(&a, src + i, 32);
+            std::memcpy(&b, src + i + 32, 32);
+            std::memcpy(&c, src + i + 64, 32);
+            std::memcpy(&d, src + i + 96, 32);
+            __builtin_nontemporal_store(a, (v4*)(dst + i));
+            __builtin_nontemporal_store(b, (v4*)(dst + i + 32));
+            __builtin_nontemporal_store(c, (v4*)(dst + i + 64));
+            __builtin_nontemporal_store(d, (v4*)(dst + i + 96));
+        }
+        if (i < n) std::memcpy(dst + i, src + i, n - i);
+        std::atomic_thread_fence(std::memory_order_seq_cst);  // the DMA that follows must see the streamed lines
+    }
     void part(unsigned p) {
         if (rows_ > 0) {
             const size_t lo = std::min(rows_, (size_t)p * per_), hi = std::min(rows_, lo + per_);
             for (size_t r = lo; r < hi; ++r) std::memcpy(dst_ + r * row_bytes_, src_ + r * src_pitch_, row_bytes_);
         } else {
             const size_t lo = std::min(bytes_, (size_t)p * per_), hi = std::min(bytes_, lo + per_);
-            if (hi > lo) std::memcpy(dst_ + lo, src_ + lo, hi - lo);
+            if (hi > lo) copy_stream(dst_ + lo, src_ + lo, hi - lo);
         }
     }
     std::vector<std::thread> workers_;
@@ -377,7 +509,8 @@ void parallel_copy_rows(void* dst, const void* src, size_t rows, size_t row_byte
     CopyPool::get().copy_rows(dst, src, rows, row_bytes, src_pitch);
 }
 
-int staged_upload(coreg_handle* h, void* dev, const void* host, size_t bytes) {
+int staged_upload(coreg_handle* h, void* dev, const void* host, size_t bytes, hipStream_t stream = nullptr) {
+    if (!stream) stream = h->stream;
     // two staging buffers used alternately, each guarded by an event recorded behind its last copy: filling the
     // buffer for this upload overlaps the DMA (and whatever else the stream is doing) of the previous one
     const int k = h->pin_img_next;
@@ -396,10 +529,42 @@ int staged_upload(coreg_handle* h, void* dev, const void* host, size_t bytes) {
     for (size_t off = 0; off < bytes; off += seg, seg = std::min(seg * 2, seg_max)) {
         const size_t len = std::min(seg, bytes - off);
         parallel_memcpy(pin + off, (const char*)host + off, len);
-        HIPCHK(hipMemcpyAsync((char*)dev + off, pin + off, len, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync((char*)dev + off, pin + off, len, hipMemcpyHostToDevice, stream));
     }
-    HIPCHK(hipEventRecord(h->ev_img[k], h->stream));
+    HIPCHK(hipEventRecord(h->ev_img[k], stream));
     return COREG_OK;
+}
+
+// the same on the handle's upload thread: staging and events of its own, plain HIP error codes (h->err belongs to the
+// calling thread), then the byte swap of a BITPIX = -32 data unit and the pivot of the image, all on stream `s`
+hipError_t upload_small_worker(coreg_handle* h, void* dev, const void* host, size_t n_elem, bool swap32, hipStream_t s) {
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return e;
+    const size_t bytes = n_elem * 4;
+    const int k = h->pin_small_next;
+    h->pin_small_next ^= 1;
+    if (!h->ev_pin_small[k]) e = hipEventCreateWithFlags(&h->ev_pin_small[k], hipEventDisableTiming);
+    else e = hipEventSynchronize(h->ev_pin_small[k]);
+    if (e != hipSuccess) return e;
+    if ((e = h->pin_small[k].reserve(bytes)) != hipSuccess) return e;
+    char* pin = (char*)h->pin_small[k].p;
+    size_t seg = (size_t)2 << 20;
+    for (size_t off = 0; off < bytes; off += seg, seg = std::min(seg * 2, (size_t)6 << 20)) {
+        const size_t len = std::min(seg, bytes - off);
+        parallel_memcpy(pin + off, (const char*)host + off, len);
+        if ((e = hipMemcpyAsync((char*)dev + off, pin + off, len, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+    }
+    if ((e = hipEventRecord(h->ev_pin_small[k], s)) != hipSuccess) return e;
+    const int nb = (int)std::min<size_t>((n_elem + 255) / 256, 4096);
+    if (swap32) hipLaunchKernelGGL(k_fits_swap32, dim3(nb), dim3(256), 0, s, (unsigned int*)dev, (long long)n_elem);
+    if ((e = h->red_sum_up.reserve(256 * sizeof(double))) != hipSuccess) return e;
+    if ((e = h->red_cnt_up.reserve(256 * sizeof(long long))) != hipSuccess) return e;
+    hipLaunchKernelGGL((k_sum_finite<float>), dim3(256), dim3(256), 0, s, (const float*)dev, (long long)n_elem,
+                       h->red_sum_up.as<double>(), h->red_cnt_up.as<long long>());
+    hipLaunchKernelGGL(k_mean_final, dim3(1), dim3(64), 0, s, h->red_sum_up.as<double>(), h->red_cnt_up.as<long long>(), 256,
+                       h->pivots.as<double>() + 1);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return hipEventRecord(h->ev_small, s);
 }
 
 // A float64 image (host: staged upload; device: the caller's buffer) is kept as float32 on the device when every finite
@@ -1135,6 +1300,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     a.car_inv.order_rt = order;
 
     const dim3 grid((unsigned)((long long)g_per * n_batches)), block(kSweepThreads);
+    RETCHK(join_small(h));  // the first kernel of the call that reads the image to align
     EventPair* ev = next_event(h, h->ev_sweep, h->ev_sweep_used);
     if (!ev) return fail(h, COREG_EHIP, "hipEventCreate failed");
 #define SWP(M, O, TS, R, Q, P)                                                                                       \
@@ -1835,8 +2001,22 @@ int coreg_create(coreg_handle** out, int device) {
 void coreg_destroy(coreg_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->up_thread.joinable()) {
+        {
+            std::unique_lock<std::mutex> lk(h->up_m);
+            h->up_cv.wait(lk, [&] { return !h->up_busy && !h->up_has; });
+            h->up_stop = true;
+        }
+        h->up_cv.notify_all();
+        h->up_thread.join();
+    }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->small, &h->ref, &h->pivots, &h->red_sum, &h->red_cnt, &h->t_sin_lon, &h->t_cos_lon,
+    if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
+    for (int k = 0; k < 2; ++k) {
+        h->pin_small[k].release();
+        if (h->ev_pin_small[k]) (void)hipEventDestroy(h->ev_pin_small[k]);
+    }
+    DevBuf* bufs[] = {&h->rf_flags, &h->rf_pivots, &h->rf_list, &h->rf_head, &h->rf_partial, &h->small, &h->ref, &h->pivots, &h->red_sum, &h->red_cnt, &h->t_sin_lon, &h->t_cos_lon,
                       &h->t_cos_lat, &h->t_sin_lat, &h->pts, &h->tile_count, &h->tile_list, &h->tile_cum, &h->group_first,
                       &h->tile_info, &h->tile_bbox, &h->counters, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
                       &h->tmp_img, &h->up_f64, &h->up_flag, &h->up_raw, &h->rice_blob, &h->rice_rand, &h->dec_img, &h->border_dev, &h->sums, &h->fin_outidx, &h->border_flags, &h->fix_partial};
@@ -1861,6 +2041,11 @@ void coreg_destroy(coreg_handle* h) {
     h->pin_border.release();
     h->bbox_buf.release();
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+    if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
+    if (h->ev_small) (void)hipEventDestroy(h->ev_small);
+    if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+    h->red_sum_up.release();
+    h->red_cnt_up.release();
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1892,6 +2077,10 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         h->opt_use_lds = value ? 1 : 0;
     } else if (n == "clean_path") {
         h->opt_clean_path = value ? 1 : 0;
+    } else if (n == "overlap_upload") {
+        h->opt_overlap_upload = value ? 1 : 0;
+    } else if (n == "async_upload") {
+        h->opt_async_upload = value ? 1 : 0;
     } else if (n == "refine") {
         h->opt_refine = value ? 1 : 0;
     } else if (n == "refine_cond_log10") {
@@ -1980,12 +2169,25 @@ int coreg_set_small_f32(coreg_handle* h, const float* img, int32_t ny, int32_t n
     RETCHK(bind_device(h));
     const size_t n = (size_t)ny * nx;
     HIPCHK(h->small.reserve(n * sizeof(float)));
-    // through pinned staging: the caller's buffer is free again on return, the copy itself is asynchronous
-    RETCHK(staged_upload(h, h->small.p, img, n * sizeof(float)));
+    // through pinned staging: the caller's buffer is free again on return, the copy itself is asynchronous -- and on the
+    // upload stream, so that a reference preparation called next does not wait for it
+    hipStream_t s;
+    RETCHK(begin_small_upload(h, &s));
+    if (h->opt_async_upload && s != h->stream) {
+        h->small_f32 = true;
+        h->sW = nx;
+        h->sH = ny;
+        void* dev = h->small.p;
+        post_upload(h, [h, dev, img, n, s] { return upload_small_worker(h, dev, img, n, false, s); });
+        h->small_pending = true;  // (join_small: waits for the worker to have issued everything, then for ev_small)
+        return COREG_OK;
+    }
+    RETCHK(staged_upload(h, h->small.p, img, n * sizeof(float), s));
     h->small_f32 = true;
     h->sW = nx;
     h->sH = ny;
-    return device_mean<float>(h, h->small.as<float>(), (long long)n, h->pivots.as<double>() + 1);
+    RETCHK(device_mean<float>(h, h->small.as<float>(), (long long)n, h->pivots.as<double>() + 1, s));
+    return end_small_upload(h, s);
 }
 
 // image to align from pinned host memory or from this GPU's memory (one asynchronous copy, no staging)
@@ -2023,6 +2225,30 @@ static int set_small_fits(coreg_handle* h, const coreg_fits_pixels* px, int32_t 
     const size_t n = (size_t)ny * nx, eb = fmt.elem();
     DevBuf& dst = fmt.swap_only() ? h->small : h->up_raw;
     HIPCHK(dst.reserve(n * eb));
+    if (fmt.swap_only() && kind == SRC_HOST) {
+        // BITPIX = -32 from host memory (what an EUI level-2 file without tile compression holds): upload stream
+        hipStream_t s;
+        RETCHK(begin_small_upload(h, &s));
+        if (h->opt_async_upload && s != h->stream) {
+            h->small_f32 = true;
+            h->sW = nx;
+            h->sH = ny;
+            void* dev = dst.p;
+            const void* src = px->data;
+            post_upload(h, [h, dev, src, n, s] { return upload_small_worker(h, dev, src, n, true, s); });
+            h->small_pending = true;
+            return COREG_OK;
+        }
+        RETCHK(staged_upload(h, dst.p, px->data, n * eb, s));
+        const int nb = (int)std::min<size_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_fits_swap32, dim3(nb), dim3(256), 0, s, (unsigned int*)dst.p, (long long)n);
+        HIPCHK(hipGetLastError());
+        h->small_f32 = true;
+        h->sW = nx;
+        h->sH = ny;
+        RETCHK(device_mean<float>(h, h->small.as<float>(), (long long)n, h->pivots.as<double>() + 1, s));
+        return end_small_upload(h, s);
+    }
     if (kind == SRC_PINNED) HIPCHK(hipMemcpyAsync(dst.p, px->data, n * eb, hipMemcpyHostToDevice, h->stream));
     else if (kind == SRC_DEVICE) HIPCHK(hipMemcpyAsync(dst.p, px->data, n * eb, hipMemcpyDeviceToDevice, h->stream));
     else RETCHK(staged_upload(h, dst.p, px->data, n * eb));
@@ -2327,7 +2553,7 @@ static int prepare_carrington(coreg_handle* h, const void* large, const PixFmt& 
     if (!h) return COREG_EINVAL;
     if (!large || !hdr || !grid || ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
     RETCHK(check_order(h, order));
-    RETCHK(bind_device(h));
+    RETCHK(bind_device_nowait(h));  // (touches neither the image to align nor its pivot: no join with the upload stream)
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
     RETCHK(upload_carr_tables(h, *grid, *hdr, &a.carr));
@@ -2376,7 +2602,7 @@ static int prepare_helioprojective(coreg_handle* h, const void* large, const Pix
     if (hdr_large->proj != hdr_small->proj || (hdr_small->proj != COREG_PROJ_TAN && hdr_small->proj != COREG_PROJ_CAR))
         return fail(h, COREG_ENOTIMPL, "prepare_reference_helioprojective: both headers TAN, or both CAR");
     RETCHK(check_order(h, order));
-    RETCHK(bind_device(h));
+    RETCHK(bind_device_nowait(h));
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
     int mode = MODE_HOMOGRAPHY;
@@ -2576,7 +2802,7 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
     RETCHK(check_order(h, order));
     LagDims d;
     RETCHK(check_lags(h, lags, &d, lag_begin, lag_end));
-    RETCHK(bind_device(h));
+    RETCHK(bind_device_nowait(h));  // (the image to align is joined right before k_sweep: launch_sweep)
     if (h->ref.p && (h->gW != grid->n_lon || h->gH != grid->n_lat))
         return fail(h, COREG_EINVAL, "reference-on-grid shape differs from the Carrington grid");
     const long long n_out = lag_end - lag_begin;
@@ -2904,7 +3130,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     RETCHK(check_order(h, order));
     LagDims d;
     RETCHK(check_lags(h, lags, &d, lag_begin, lag_end));
-    RETCHK(bind_device(h));
+    RETCHK(bind_device_nowait(h));
     if (h->ref.p && (h->gW != hdr_target->naxis1 || h->gH != hdr_target->naxis2))
         return fail(h, COREG_EINVAL, "reference-on-grid shape differs from hdr_target NAXIS1/NAXIS2");
     const long long n_out = lag_end - lag_begin;

@@ -330,10 +330,19 @@ class Alignment:
 
         # alignment.py:844-861: thresholds, then the box to remove, then the sub-FOV re-grid
         on_device = (remove_fov_limits is None) and (fov_limits is None)
+        n_finite = None
         if on_device:
-            # thresholds applied to the resident copy (self.data_small is left as loaded)
-            upload_small(self.data_small)
-            n_finite = h.threshold_small(self.small_fov_value_min, self.small_fov_value_max)
+            # thresholds applied to the resident copy (self.data_small is left as loaded).  The upload is handed to the
+            # library's upload thread (option "async_upload": staging copies + DMA on a stream of their own) and this
+            # thread goes on to prepare the reference image; the threshold pass -- the first reader of the pixels -- is
+            # issued after that (`finite_pixels`, below).  self.data_small is not modified until then.
+            if not use_all and not spread:
+                h.set_option("async_upload", 1)
+            try:
+                upload_small(self.data_small)
+            finally:
+                if not use_all and not spread:
+                    h.set_option("async_upload", 0)
         else:
             self.data_small = np.array(self.data_small, dtype=np.float64)
             hdrutil.set_threshold_minmax_to_nan(self.data_small, self.small_fov_value_min, self.small_fov_value_max)
@@ -344,8 +353,17 @@ class Alignment:
             n_finite = int(np.isfinite(self.data_small).sum())
             upload_small(self.data_small)
         self._set_initial_header_values(ang2pipi)
-        if n_finite == 0:
-            raise ValueError("minimum or maximum value have set all small FOV to nan")  # alignment.py:655-656
+
+        def finite_pixels():
+            """alignment.py:654-656, after the first reference preparation (the check itself reads the uploaded pixels)."""
+            nonlocal n_finite
+            if n_finite is None:
+                n_finite = h.threshold_small(self.small_fov_value_min, self.small_fov_value_max)
+            if n_finite == 0:
+                raise ValueError("minimum or maximum value have set all small FOV to nan")
+
+        if n_finite is not None:
+            finite_pixels()
         if self.unit_lag != self.hdr_small["CUNIT1"]:
             raise ValueError("lag.unit and cUNIT are not the same")  # alignment.py:406
 
@@ -419,6 +437,7 @@ class Alignment:
                     select_combos()
                     return h.sweep_helioprojective(t, self.hdr_small, my_lags, order=self.order, method=method,
                                                    cdelt_semantics=sem, lag_begin=lo, lag_end=hi)
+            finite_pixels()
             if mode == "points":
                 part = parallel.point_sharded_sweep(h, run, lags.size)
             elif mode in ("blocks", "combos"):
