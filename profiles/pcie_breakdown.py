@@ -58,3 +58,7 @@ print("whole call, reference first      %.3f ms" % t(whole_ref_first, 12))
 import ctypes
 buf = np.empty(36 << 20, dtype=np.uint8); src = np.random.default_rng(0).integers(0, 255, 36 << 20, dtype=np.uint8)
 t0 = time.perf_counter(); np.copyto(buf, src); print("numpy memcpy 36 MiB 1 thread     %.3f ms" % (1e3 * (time.perf_counter() - t0)))
+whole_async()
+st = h.last_stats()
+print("inside the async whole call: sweep_kernel_ms %.3f precompute_ms %.3f total_gpu_ms %.3f" % (
+    st["sweep_kernel_ms"], st.get("precompute_ms", float("nan")), st["total_gpu_ms"]))
