@@ -483,6 +483,232 @@ class WcslibTan:
                     [float(hdr.get("PC2_1", 0.0)), float(hdr.get("PC2_2", 1.0))]], float(hdr.get("LONPOLE", 180.0)))
 
 
+class WcslibCar(WcslibTan):
+    """The same chain for a plate-carree header (CTYPE -CAR: align_using_initial_carrington, alignment.py:344-399):
+    wcslib's cel.c celset() for a cylindrical projection (fiducial native point (phi0, theta0) = (0, 0)) in plain double,
+    operation by operation; prj.c carx2s / cars2x (with the default r0 the scale factors are exactly 1: phi = x,
+    theta = y); sph.c sphx2s / sphs2x INCLUDING their "simple change in origin of longitude" branch, which an
+    equatorial map (CRVAL2 = 0: the native pole is the celestial pole) takes.  PINNED bit for bit by
+    tests/golden/border_car_golden.npz (astropy 4.3.1 / wcslib 7.6, seven headers)."""
+
+    def __init__(self, crpix, cdelt_deg, crval_deg, pc, lonpole=None, latpole=None):
+        super().__init__(crpix, cdelt_deg, crval_deg, pc, 0.0)
+        tol = 1.0e-10
+        lng0, lat0 = crval_deg
+        phi0 = theta0 = 0.0
+        latp = 90.0 if latpole is None or latpole != latpole else float(latpole)
+        if lonpole is None or lonpole != lonpole or lonpole == 999.0:
+            phip = 180.0 if lat0 < theta0 else 0.0
+            phip += phi0
+            if phip < -180.0: phip += 360.0
+            elif phip > 180.0: phip -= 360.0
+        else:
+            phip = float(lonpole)
+        slat0, clat0 = sincosd(lat0)
+        sthe0, cthe0 = sincosd(theta0)
+        latpreq = 0
+        if phip == phi0:
+            sphip, cphip = 0.0, 1.0
+            u = theta0
+            v = 90.0 - lat0
+        else:
+            # (measured against astropy 4.3.1 / wcslib 7.6 on southern maps, LONPOLE = 180: the sine that enters the
+            # longitude of the native pole is libm's sin(pi) = 1.22e-16, not wcstrig's exact 0 -- lngp comes out one ulp
+            # below CRVAL1; pinned by three southern headers of border_car_golden.npz)
+            sphip, cphip = _sincos((phip - phi0) * math.pi / 180.0)
+            x = cthe0 * cphip
+            y = sthe0
+            z = math.sqrt(x * x + y * y)
+            if z == 0.0:
+                if slat0 != 0.0:
+                    raise InvalidTransformError("Invalid coordinate transformation parameters")
+                latpreq = 2
+                if latp > 90.0: latp = 90.0
+                elif latp < -90.0: latp = -90.0
+            else:
+                slz = slat0 / z
+                if abs(slz) > 1.0:
+                    if (abs(slz) - 1.0) < tol:
+                        slz = 1.0 if slz > 0.0 else -1.0
+                    else:
+                        raise InvalidTransformError("Invalid coordinate transformation parameters")
+                u = atan2d(y, x)
+                v = acosd(slz)
+        if latpreq == 0:
+            latp1 = u + v
+            if latp1 > 180.0: latp1 -= 360.0
+            elif latp1 < -180.0: latp1 += 360.0
+            latp2 = u - v
+            if latp2 > 180.0: latp2 -= 360.0
+            elif latp2 < -180.0: latp2 += 360.0
+            if abs(latp - latp1) < abs(latp - latp2):
+                latp = latp1 if abs(latp1) < 90.0 + tol else latp2
+            else:
+                latp = latp2 if abs(latp2) < 90.0 + tol else latp1
+            if abs(latp) < 90.0 + tol:
+                if latp > 90.0: latp = 90.0
+                elif latp < -90.0: latp = -90.0
+            else:
+                raise InvalidTransformError("Invalid coordinate transformation parameters: no valid solution for latp")
+        z = cosd(latp) * clat0
+        if abs(z) < tol:
+            if abs(clat0) < tol:
+                lngp = lng0
+            elif latp > 0.0:
+                lngp = lng0 + phip - phi0 - 180.0
+            else:
+                lngp = lng0 - phip + phi0
+        else:
+            x = (sthe0 - sind(latp) * slat0) / z
+            y = sphip * cthe0 / clat0
+            if x == 0.0 and y == 0.0:
+                raise InvalidTransformError("Invalid coordinate transformation parameters")
+            lngp = lng0 - atan2d(y, x)
+        if lng0 >= 0.0:
+            if lngp < 0.0: lngp += 360.0
+            elif lngp > 360.0: lngp -= 360.0
+        else:
+            if lngp > 0.0: lngp -= 360.0
+            elif lngp < -360.0: lngp += 360.0
+        self.e0 = lngp
+        self.e1 = 90.0 - latp
+        self.e2 = phip
+        self.e4, self.e3 = sincosd(self.e1)
+        self.latpole = latp
+
+    def _lin_p2x(self, px0, py0):
+        t0 = (px0 + 1.0) - self.crpix[0]
+        t1 = (py0 + 1.0) - self.crpix[1]
+        if self.unity:
+            return self.cdelt[0] * t0, self.cdelt[1] * t1
+        x = 0.0; y = 0.0
+        x += self.piximg[0][0] * t0
+        y += self.piximg[1][0] * t0
+        x += self.piximg[0][1] * t1
+        y += self.piximg[1][1] * t1
+        return x, y
+
+    def p2s(self, px0, py0):
+        x, y = self._lin_p2x(px0, py0)
+        # carx2s: s = w[1] * (x + x0) with w[1] = 1, x0 = 0
+        phi = 1.0 * (x + 0.0)
+        theta = 1.0 * (y + 0.0)
+        # sphx2s
+        if self.e4 == 0.0:
+            if self.e1 == 0.0:
+                dlng = math.fmod(self.e0 + 180.0 - self.e2, 360.0)
+                lng = phi + dlng
+                lat = theta
+            else:
+                dlng = math.fmod(self.e0 + self.e2, 360.0)
+                lng = dlng - phi
+                lat = -theta
+            if self.e0 >= 0.0:
+                if lng < 0.0: lng += 360.0
+            else:
+                if lng > 0.0: lng -= 360.0
+            if lng > 360.0: lng -= 360.0
+            elif lng < -360.0: lng += 360.0
+            return lng, lat
+        dphi = phi - self.e2
+        sinthe, costhe = sincosd(theta)
+        costhe3 = costhe * self.e3; costhe4 = costhe * self.e4
+        sinthe3 = sinthe * self.e3; sinthe4 = sinthe * self.e4
+        sinphi, cosphi = sincosd(dphi)
+        xx = sinthe4 - costhe3 * cosphi
+        if abs(xx) < 1e-5:
+            xx = -cosd(theta + self.e1) + costhe3 * (1.0 - cosphi)
+        yy = -costhe * sinphi
+        if xx != 0.0 or yy != 0.0:
+            dlng = atan2d(yy, xx)
+        else:
+            dlng = dphi + 180.0
+        lng = self.e0 + dlng
+        if self.e0 >= 0.0:
+            if lng < 0.0: lng += 360.0
+        else:
+            if lng > 0.0: lng -= 360.0
+        if lng > 360.0: lng -= 360.0
+        elif lng < -360.0: lng += 360.0
+        if math.fmod(dphi, 180.0) == 0.0:
+            lat = theta + cosphi * self.e1
+            if lat > 90.0: lat = 180.0 - lat
+            if lat < -90.0: lat = -180.0 - lat
+        else:
+            z = sinthe3 + costhe4 * cosphi
+            if abs(z) > 0.99:
+                lat = math.copysign(acosd(math.sqrt(xx * xx + yy * yy)), z)
+            else:
+                lat = asind(z)
+        return lng, lat
+
+    def s2p(self, lng, lat):
+        if self.e4 == 0.0:
+            if self.e1 == 0.0:
+                dphi = math.fmod(self.e2 - 180.0 - self.e0, 360.0)
+                phi = math.fmod(lng + dphi, 360.0)
+                theta = lat
+            else:
+                dphi = math.fmod(self.e2 + self.e0, 360.0)
+                phi = math.fmod(dphi - lng, 360.0)
+                theta = -lat
+            if phi > 180.0: phi -= 360.0
+            elif phi < -180.0: phi += 360.0
+        else:
+            dlng = lng - self.e0
+            sinlat, coslat = sincosd(lat)
+            coslat3 = coslat * self.e3; coslat4 = coslat * self.e4
+            sinlat3 = sinlat * self.e3; sinlat4 = sinlat * self.e4
+            sinlng, coslng = sincosd(dlng)
+            xx = sinlat4 - coslat3 * coslng
+            if abs(xx) < 1e-5:
+                xx = -cosd(lat + self.e1) + coslat3 * (1.0 - coslng)
+            yy = -coslat * sinlng
+            if xx != 0.0 or yy != 0.0:
+                dphi = atan2d(yy, xx)
+            else:
+                dphi = dlng - 180.0
+            phi = math.fmod(self.e2 + dphi, 360.0)
+            if phi > 180.0: phi -= 360.0
+            elif phi < -180.0: phi += 360.0
+            if math.fmod(dlng, 180.0) == 0.0:
+                theta = lat + coslng * self.e1
+                if theta > 90.0: theta = 180.0 - theta
+                if theta < -90.0: theta = -180.0 - theta
+            else:
+                z = sinlat3 + coslat4 * coslng
+                if abs(z) > 0.99:
+                    theta = math.copysign(acosd(math.sqrt(xx * xx + yy * yy)), z)
+                else:
+                    theta = asind(z)
+        # cars2x: x = w[0] * phi - x0 with w[0] = 1, x0 = 0
+        x = 1.0 * phi - 0.0
+        y = 1.0 * theta - 0.0
+        if self.unity:
+            p0 = x / self.cdelt[0] + self.crpix[0]
+            p1 = y / self.cdelt[1] + self.crpix[1]
+        else:
+            p0 = 0.0
+            p0 += self.imgpix[0][0] * x
+            p0 += self.imgpix[0][1] * y
+            p0 += self.crpix[0]
+            p1 = 0.0
+            p1 += self.imgpix[1][0] * x
+            p1 += self.imgpix[1][1] * y
+            p1 += self.crpix[1]
+        return p0 - 1.0, p1 - 1.0
+
+    @classmethod
+    def from_header(cls, hdr):
+        u1 = unit_to_deg(hdr.get("CUNIT1", "deg"))
+        u2 = unit_to_deg(hdr.get("CUNIT2", "deg"))
+        return cls([float(hdr["CRPIX1"]), float(hdr["CRPIX2"])], [float(hdr["CDELT1"]) * u1, float(hdr["CDELT2"]) * u2],
+                   [float(hdr["CRVAL1"]) * u1, float(hdr["CRVAL2"]) * u2],
+                   [[float(hdr.get("PC1_1", 1.0)), float(hdr.get("PC1_2", 0.0))],
+                    [float(hdr.get("PC2_1", 0.0)), float(hdr.get("PC2_2", 1.0))]],
+                   hdr.get("LONPOLE"), hdr.get("LATPOLE"))
+
+
 # The same chain in plain C (oracle/csrc/wcslib_tan.c, built by oracle/Makefile): identical arithmetic on the same libm,
 # checked bit for bit against the Python class above and against the astropy / wcslib golden vectors
 # (tests/test_oracle_golden.py).  It exists so that EVERY pixel of a 2048 x 2048 grid can be re-evaluated (odd spline
@@ -519,6 +745,13 @@ def wcslib_pixel_to_pixel(hdr_from, hdr_to, px, py, force_python=False):
     px = np.ascontiguousarray(px, dtype=np.float64).ravel()
     py = np.ascontiguousarray(py, dtype=np.float64).ravel()
     ox, oy, lng, lat = (np.empty_like(px) for _ in range(4))
+    if str(hdr_from.get("CTYPE1", "")).strip().upper().endswith("-CAR"):
+        # two Carrington maps (alignment.py:1061-1065 with lon_ctype "CRLN-CAR": the raw wcslib values, no ang2pipi)
+        wf, wt = WcslibCar.from_header(hdr_from), WcslibCar.from_header(hdr_to)
+        for k in range(px.size):
+            lng[k], lat[k] = wf.p2s(float(px[k]), float(py[k]))
+            ox[k], oy[k] = wt.s2p(float(lng[k]), float(lat[k]))
+        return ox, oy, lng, lat
     lib = None if force_python else _wcstan_lib()
     if lib is not None:
         pf, pt = _wcstan_params(hdr_from), _wcstan_params(hdr_to)
@@ -747,7 +980,7 @@ def extract_coordinates_pixels(header_initial_to_project, header_target_projecti
     w_to = make_wcs(header_target_projection)
     lon, lat = extract_EUI_coordinates(header_initial_to_project)
     x, y = w_to.world_to_pixel(lon, lat)
-    if isinstance(w_to, TanWCS) and "NAXIS1" in header_target_projection:
+    if isinstance(w_to, (TanWCS, CarWCS)) and "NAXIS1" in header_target_projection:
         # coordinates ON the bounds rule are decided by wcslib's rounding noise (see WcslibTan)
         x, y = np.array(x, dtype=np.float64), np.array(y, dtype=np.float64)
         wcslib_refine_near_bounds(header_initial_to_project, header_target_projection, x, y)

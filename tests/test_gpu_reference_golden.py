@@ -9,7 +9,6 @@ import numpy as np
 import pytest
 
 from tests import golden_cases as G
-from tests.test_reference_golden_cpu import CAR_IDENTITY_TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -35,11 +34,6 @@ def test_hip_path_reproduces_the_reference_map(name, fits_dir):
     if not np.isfinite(want).any():
         return  # method='residus' (quirk Q8): NaN everywhere in the reference and here
     d = np.abs(got - want)
-    if c["call"] == "initial_carrington":
-        # the identity lag of two CAR maps: every border pixel is decided by wcslib's rounding noise
-        i0 = (c["ctor"]["lag_crval1"].index(0.0), c["ctor"]["lag_crval2"].index(0.0))
-        assert d[i0][0, 0, 0, 0] <= CAR_IDENTITY_TOL
-        d[i0] = 0.0
     assert np.nanmax(d) <= _tol(c), f"max |HIP - reference| = {np.nanmax(d):.3e}"
     am = np.nanargmax(got)
     assert am == np.nanargmax(want) or want.ravel()[am] >= np.nanmax(want) - _tol(c)
