@@ -157,6 +157,7 @@ struct coreg_handle {
     bool small_pending = false;
     DevBuf red_sum_up, red_cnt_up;  // device_mean's scratch on up_stream
     int64_t opt_overlap_upload = 1;
+    int64_t opt_tap_nan_filter = 1;  // odd orders: list only the near-integer samples that can change the result (k_tap_scan)
     // "async_upload" (opt-in: the caller's image buffer must stay valid and unchanged until the next call that reads the
     // image returns): the staging copies + DMA of coreg_set_small_f32 / _fits run on a worker thread of the handle, so that
     // the calling thread goes on to prepare the reference and plan the sweep meanwhile; joined before the first kernel
@@ -1557,17 +1558,19 @@ AxisInvariance snap_invariant_axes(const coreg_wcs2d& target, const coreg_wcs2d&
 
 // Pixels of the invariant border rows / columns that the reference's round trip pixel -> sky (target header) ->
 // ang2pipi -> pixel (shifted header) sends outside [0, W-1] x [0, H-1] of the image to align.  Appended to `out`.
-void wcslib_dropped_border_pixels(coreg_handle* h, const coreg_wcs2d& target, const coreg_wcs2d& shifted,
-                                  AxisInvariance inv, std::vector<int>* out) {
+template <typename Chain>
+void wcslib_dropped_border_pixels_t(coreg_handle* h, const coreg_wcs2d& target, const coreg_wcs2d& shifted,
+                                    AxisInvariance inv, std::vector<int>* out) {
     const int gw = h->gW, gh = h->gH;
-    std::vector<double> key = {target.crpix1, target.crpix2, target.crval1, target.crval2, target.cdelt1, target.cdelt2,
-                               target.pc1_1, target.pc1_2, target.pc2_1, target.pc2_2, target.unit_to_deg, target.lonpole,
+    std::vector<double> key = {(double)target.proj, target.latpole == target.latpole ? target.latpole : -999.0, target.crpix1, target.crpix2, target.crval1, target.crval2, target.cdelt1, target.cdelt2,
+                               target.pc1_1, target.pc1_2, target.pc2_1, target.pc2_2, target.unit_to_deg,
+                               target.lonpole == target.lonpole ? target.lonpole : -999.0,
                                shifted.crpix1, shifted.crpix2, shifted.cdelt1, shifted.cdelt2, shifted.pc1_1,
                                shifted.pc1_2, shifted.pc2_1, shifted.pc2_2, (double)gw, (double)gh, (double)h->sW,
                                (double)h->sH, inv.rows ? 1.0 : 0.0, inv.cols ? 1.0 : 0.0};
     auto hit = h->border_cache.find(key);
     if (hit == h->border_cache.end()) {
-        WcslibTan wf, wt;
+        Chain wf, wt;
         wf.init(target);
         wt.init(shifted);
         std::vector<int> cand;  // row-major, each pixel once
@@ -1612,21 +1615,29 @@ void wcslib_dropped_border_pixels(coreg_handle* h, const coreg_wcs2d& target, co
     out->insert(out->end(), hit->second.begin(), hit->second.end());
 }
 
+void wcslib_dropped_border_pixels(coreg_handle* h, const coreg_wcs2d& target, const coreg_wcs2d& shifted,
+                                  AxisInvariance inv, std::vector<int>* out) {
+    if (target.proj == COREG_PROJ_CAR) wcslib_dropped_border_pixels_t<WcslibCar>(h, target, shifted, inv, out);
+    else wcslib_dropped_border_pixels_t<WcslibTan>(h, target, shifted, inv, out);
+}
+
 // Odd spline orders: for every grid pixel, does the reference's round trip come back BELOW the integer along an
 // invariant axis (bit 0: rows / y, bit 1: columns / x)?  Then floor(c) -- the first tap of an odd-order spline -- is one
 // less than at the exact integer the sweep used (k_parity_fix).  W x H evaluations of the wcslib chain, in threads;
 // cached per header pair.
-const std::vector<unsigned char>& wcslib_tap_shift_flags(coreg_handle* h, const coreg_wcs2d& target,
-                                                         const coreg_wcs2d& shifted, AxisInvariance inv) {
+template <typename Chain>
+const std::vector<unsigned char>& wcslib_tap_shift_flags_t(coreg_handle* h, const coreg_wcs2d& target,
+                                                           const coreg_wcs2d& shifted, AxisInvariance inv) {
     const int gw = h->gW, gh = h->gH;
-    std::vector<double> key = {target.crpix1, target.crpix2, target.crval1, target.crval2, target.cdelt1, target.cdelt2,
-                               target.pc1_1, target.pc1_2, target.pc2_1, target.pc2_2, target.unit_to_deg, target.lonpole,
+    std::vector<double> key = {(double)target.proj, target.latpole == target.latpole ? target.latpole : -999.0, target.crpix1, target.crpix2, target.crval1, target.crval2, target.cdelt1, target.cdelt2,
+                               target.pc1_1, target.pc1_2, target.pc2_1, target.pc2_2, target.unit_to_deg,
+                               target.lonpole == target.lonpole ? target.lonpole : -999.0,
                                shifted.crpix1, shifted.crpix2, shifted.cdelt1, shifted.cdelt2, shifted.pc1_1,
                                shifted.pc1_2, shifted.pc2_1, shifted.pc2_2, (double)gw, (double)gh, (double)h->sW,
                                (double)h->sH, inv.rows ? 1.0 : 0.0, inv.cols ? 1.0 : 0.0};
     auto hit = h->flags_cache.find(key);
     if (hit != h->flags_cache.end()) return hit->second;
-    WcslibTan wf, wt;
+    Chain wf, wt;
     wf.init(target);
     wt.init(shifted);
     std::vector<unsigned char> flags((size_t)gw * gh, 0);
@@ -1661,6 +1672,12 @@ const std::vector<unsigned char>& wcslib_tap_shift_flags(coreg_handle* h, const 
     return h->flags_cache.emplace(std::move(key), std::move(flags)).first->second;
 }
 
+const std::vector<unsigned char>& wcslib_tap_shift_flags(coreg_handle* h, const coreg_wcs2d& target,
+                                                         const coreg_wcs2d& shifted, AxisInvariance inv) {
+    if (target.proj == COREG_PROJ_CAR) return wcslib_tap_shift_flags_t<WcslibCar>(h, target, shifted, inv);
+    return wcslib_tap_shift_flags_t<WcslibTan>(h, target, shifted, inv);
+}
+
 int upload_border_pixels(coreg_handle* h, const std::vector<int>& pixels) {
     const size_t bytes = std::max<size_t>(1, pixels.size()) * sizeof(int);
     HIPCHK(h->border_dev.reserve(bytes));
@@ -1680,7 +1697,7 @@ int upload_border_pixels(coreg_handle* h, const std::vector<int>& pixels) {
 // workgroup per slot adds its entries in a fixed order.  A list beyond "tap_cap" entries (a pure CRVAL1 / CRVAL2 lag set
 // under an unrotated header at full size) is not applied at all -- recorded in tap_last, coreg_last_tap_fix.
 template <typename ShiftedOf>
-int prepare_tap_fix(coreg_handle* h, int sweep_mode, const coreg_wcs2d& target, long long n_slots,
+int prepare_tap_fix(coreg_handle* h, int sweep_mode, int order, const coreg_wcs2d& target, long long n_slots,
                     const std::vector<unsigned char>& skip, const double box[4], ShiftedOf shifted_of, BorderFix* fix) {
     // the list starts small (64 K entries, or what an earlier sweep needed) and is grown -- and the scan repeated --
     // only when a sweep lists more, up to "tap_cap"
@@ -1701,6 +1718,13 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, const coreg_wcs2d& target, 
     a.wmax = (double)(h->sW - 1);
     a.hmax = (double)(h->sH - 1);
     a.tol = 1e-8;  // wcslib's round-trip noise stays below 1e-9 px, the homography's below 1e-11
+    a.img = h->small.p;
+    a.img_f32 = h->small_f32 ? 1 : 0;
+    a.W = h->sW;
+    a.H = h->sH;
+    a.order = order;
+    a.nan_filter = h->opt_tap_nan_filter ? 1 : 0;
+    if (a.nan_filter) RETCHK(join_small(h));  // (the scan reads the image to align)
     a.count = h->tap_count.as<unsigned>();
     a.list = h->tap_list.as<uint2>();
     a.cap = cap;
@@ -2077,6 +2101,8 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         h->opt_use_lds = value ? 1 : 0;
     } else if (n == "clean_path") {
         h->opt_clean_path = value ? 1 : 0;
+    } else if (n == "tap_nan_filter") {
+        h->opt_tap_nan_filter = value ? 1 : 0;
     } else if (n == "overlap_upload") {
         h->opt_overlap_upload = value ? 1 : 0;
     } else if (n == "async_upload") {
@@ -3031,11 +3057,29 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
         size_t slot_off;
         int n_batches;
         LaunchU inv;
+        bool identity;  // the one-slot launch of the identity lag-point (below)
     };
     std::vector<Launch> launches;
     std::vector<double> params;  // per launch: SoA [9][slots of the launch]
     std::vector<long long> outidx;
     SlotList slots;
+    // The identity lag-point (shifted header == target header: the zero lag of the sub-map semantics, where the target IS
+    // the header of the map to align).  The reference's pixel -> world -> pixel round trip (alignment.py:1038-1069) returns
+    // i + eps there and the sign of wcslib's rounding noise decides the bounds rule on every border pixel (and, for odd
+    // spline orders, the tap set of every pixel).  The sphere rotation of this path cannot even return exact integers, so
+    // that lag-point is taken out of the CAR launch and swept on its own with the EXACT identity map by the
+    // helioprojective kernels, whose zero-lag machinery (k_border_fix / k_parity_fix) then applies what wcslib's chain
+    // (geometry.hpp WcslibCar, bit-exact) decides.  "border_fix" 0: rotation path for that lag-point too.
+    long long identity_out = -1;
+    BorderFix id_fix;
+    std::vector<unsigned char> id_flags;
+    auto same_header = [](const coreg_wcs2d& a, const coreg_wcs2d& b) {
+        auto eq = [](double x, double y) { return x == y || (x != x && y != y); };
+        return a.proj == b.proj && a.crpix1 == b.crpix1 && a.crpix2 == b.crpix2 && a.crval1 == b.crval1 &&
+               a.crval2 == b.crval2 && a.cdelt1 == b.cdelt1 && a.cdelt2 == b.cdelt2 && a.pc1_1 == b.pc1_1 &&
+               a.pc1_2 == b.pc1_2 && a.pc2_1 == b.pc2_1 && a.pc2_2 == b.pc2_2 && a.unit_to_deg == b.unit_to_deg &&
+               eq(a.lonpole, b.lonpole) && eq(a.latpole, b.latpole) && a.naxis1 == b.naxis1 && a.naxis2 == b.naxis2;
+    };
     for (long long c = 0; c < d.nc; ++c) {
         const long long first = (lag_begin - c + d.nc - 1) / d.nc;
         if (first * d.nc + c >= lag_end) continue;
@@ -3061,16 +3105,56 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
         L.inv.b1 = inv.b1;
         L.inv.box_c = car_box_c(*hdr_target, hc, plan.tile_w);
         L.inv.pole_sep = 0.0;  // largest over the lags of this launch (below)
+        L.identity = false;
         const size_t pbase = params.size();
         params.resize(pbase + 9 * ns);
         for (size_t s = 0; s < ns; ++s) {
-            const bool pad = slots.outidx[s] < 0;
+            bool pad = slots.outidx[s] < 0;
+            if (!pad && h->opt_border_fix && identity_out < 0 && h->gW == h->sW && h->gH == h->sH) {
+                const coreg_wcs2d hl = shifted(hc, slots.i1[s], slots.i2[s]);
+                if (same_header(hl, *hdr_target)) {
+                    identity_out = slots.outidx[s];
+                    slots.outidx[s] = -1;  // not this launch's: padding lane (NaN map, nothing written)
+                    pad = true;
+                }
+            }
             const double* r = &rot[((size_t)(slots.i1[s] - i1_lo) * d.n2 + slots.i2[s]) * 9];
             for (int k = 0; k < 9; ++k) params[pbase + (size_t)k * ns + s] = pad ? nanv : r[k];
             if (!pad && r[8] == r[8]) L.inv.pole_sep = std::max(L.inv.pole_sep, car_pole_sep(r));
         }
         outidx.insert(outidx.end(), slots.outidx.begin(), slots.outidx.end());
         launches.push_back(L);
+    }
+    if (identity_out >= 0) {
+        // one batch, one live slot: the identity homography (every sample ON its pixel); the others are padding
+        Launch L;
+        std::memset(&L.inv, 0, sizeof(L.inv));
+        L.slot_off = outidx.size();
+        L.n_batches = 1;
+        L.identity = true;
+        const size_t ns = kBlock, pbase = params.size();
+        params.resize(pbase + 9 * ns, nanv);
+        const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int k = 0; k < 9; ++k) params[pbase + (size_t)k * ns] = ident[k];
+        outidx.push_back(identity_out);
+        outidx.insert(outidx.end(), ns - 1, -1);
+        launches.push_back(L);
+        {   // (on every rank of a grid-sharded sweep: launch_sweep applies it on rank 0 only, but all must agree that this
+            // launch carries a correction)
+            AxisInvariance inv;
+            inv.rows = inv.cols = true;
+            BorderFix::Item it;
+            it.slot = 0;
+            it.first = 0;
+            wcslib_dropped_border_pixels(h, *hdr_target, *hdr_target, inv, &id_fix.pixels);
+            it.n = (int)id_fix.pixels.size();
+            it.flags_off = -1;
+            if (order & 1) {
+                it.flags_off = 0;
+                id_flags = wcslib_tap_shift_flags(h, *hdr_target, *hdr_target, inv);
+            }
+            if (it.n > 0 || it.flags_off >= 0) id_fix.items.push_back(it);
+        }
     }
     if (launches.empty()) {
         RETCHK(fill_nan(h, out_dev, n_out));
@@ -3098,8 +3182,29 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
     const double inf = std::numeric_limits<double>::infinity();
     pa.f0lo = pa.f1lo = -inf;  // no culling by position: only non-finite reference values drop out
     pa.f0hi = pa.f1hi = inf;
+    if (!id_fix.items.empty()) RETCHK(upload_border_pixels(h, id_fix.pixels));
+    if (!id_flags.empty()) {
+        HIPCHK(h->border_flags.reserve(id_flags.size()));
+        HIPCHK(hipStreamSynchronize(h->stream));  // (pageable source, rare path)
+        HIPCHK(hipMemcpy(h->border_flags.p, id_flags.data(), id_flags.size(), hipMemcpyHostToDevice));
+    }
     int last_groups = -1, last_batches = -1;
     for (const Launch& L : launches) {
+        if (L.identity) {
+            // target pixel -> the same pixel of the map to align: base coordinates = pixel indices, no culling by position
+            PrecomputeArgs pi = pa;
+            std::memset(&pi.car_fwd, 0, sizeof(pi.car_fwd));
+            const int ng = pick_groups(h, 1, n_tiles);
+            RETCHK(launch_precompute<MODE_HOMOGRAPHY>(h, pi, n_tiles, ng, 1));
+            h->last_precompute = [pi, n_tiles, ng](coreg_handle* hh) {
+                return launch_precompute<MODE_HOMOGRAPHY>(hh, pi, n_tiles, ng, 1);
+            };
+            last_groups = last_batches = -1;  // (the compacted points now hold pixel indices, not unit vectors)
+            RETCHK(launch_sweep(h, MODE_HOMOGRAPHY, order, method, h->lane_params.as<double>() + 9 * L.slot_off,
+                                h->out_index.as<long long>() + L.slot_off, 1, n_tiles, lag_begin, out_dev, nullptr, &id_fix,
+                                (long long)L.slot_off));
+            continue;
+        }
         // the work partition (k_tile_list) depends on the group count of the launch: redo it only when that changes
         const int ng = pick_groups(h, L.n_batches, n_tiles);
         if (ng != last_groups || L.n_batches != last_batches) RETCHK(launch_precompute<MODE_CAR>(h, pa, n_tiles, ng, L.n_batches));
@@ -3399,7 +3504,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     const double tap_box[4] = {pa.f0lo, pa.f0hi, pa.f1lo, pa.f1hi};
     if (tap_fixing)
         RETCHK(prepare_tap_fix(
-            h, sweep_mode, *hdr_target, (long long)ns, tap_skip, tap_box,
+            h, sweep_mode, order, *hdr_target, (long long)ns, tap_skip, tap_box,
             [&](int slot) {
                 coreg_wcs2d hl = tap_combo[(size_t)tap_slot_combo[(size_t)slot]];
                 hl.crval1 = hdr_small->crval1 + lags->crval1[tap_slot_i1[(size_t)slot]];
@@ -3606,6 +3711,20 @@ int coreg_lag_homography(const coreg_wcs2d* hdr_target, const coreg_wcs2d* hdr_s
 int coreg_wcslib_pixel_to_pixel(const coreg_wcs2d* from, const coreg_wcs2d* to, int64_t n, const double* px,
                                 const double* py, double* ox, double* oy, double* lng, double* lat) {
     if (!from || !to || n < 0 || (n > 0 && (!px || !py || !ox || !oy))) return COREG_EINVAL;
+    if (from->proj == COREG_PROJ_CAR && to->proj == COREG_PROJ_CAR) {
+        WcslibCar a, b;
+        a.init(*from);
+        b.init(*to);
+        if (!a.valid || !b.valid) return COREG_EINVAL;
+        for (int64_t i = 0; i < n; ++i) {
+            double l, t;
+            a.p2s(px[i], py[i], &l, &t);
+            if (lng) lng[i] = l;
+            if (lat) lat[i] = t;
+            b.s2p(l, t, &ox[i], &oy[i]);
+        }
+        return COREG_OK;
+    }
     if (from->proj != COREG_PROJ_TAN || to->proj != COREG_PROJ_TAN) return COREG_ENOTIMPL;
     WcslibTan a, b;
     a.init(*from);

@@ -487,6 +487,228 @@ inline void wcslib_pixel_to_pixel(const WcslibTan& from, const WcslibTan& to, do
     to.s2p(ang2pipi_deg(lng), ang2pipi_deg(lat), ox, oy);
 }
 
+// The same chain for a plate-carree header (CTYPE -CAR; two Carrington maps, align_using_initial_carrington,
+// alignment.py:344-399 -- there the reference applies NO ang2pipi: lon_ctype "CRLN-CAR", utils/Util.py:302-304):
+// wcslib's cel.c celset() for a cylindrical projection (fiducial native point (0, 0)) in plain double, operation by
+// operation; prj.c carx2s / cars2x (default r0: both scale factors exactly 1); sph.c sphx2s / sphs2x INCLUDING the
+// "simple change in origin of longitude" branch an equatorial map takes.  One measured oddity (southern maps, LONPOLE =
+// 180): the sine entering the longitude of the native pole is libm's sin(pi) = 1.22e-16, not wcstrig's exact 0.  Pinned bit
+// for bit by tests/golden/border_car_golden.npz (astropy 4.3.1 / wcslib 7.6, nine headers, every border pixel).
+struct WcslibCar : WcslibTan {
+    bool valid = true;
+    void init(const coreg_wcs2d& w) {
+#pragma clang fp contract(off)
+        WcslibTan::init(w);
+        const double tol = 1.0e-10;
+        const double lng0 = w.crval1 * w.unit_to_deg, lat0 = w.crval2 * w.unit_to_deg;
+        const double phi0 = 0.0, theta0 = 0.0;
+        double latp = (w.latpole == w.latpole) ? w.latpole : 90.0;
+        double phip;
+        if (!(w.lonpole == w.lonpole) || w.lonpole == 999.0) {
+            phip = (lat0 < theta0) ? 180.0 : 0.0;
+            phip += phi0;
+            if (phip < -180.0) phip += 360.0;
+            else if (phip > 180.0) phip -= 360.0;
+        } else {
+            phip = w.lonpole;
+        }
+        double slat0, clat0, sthe0, cthe0, sphip, cphip, u = 0.0, v = 0.0;
+        sincosd(lat0, &slat0, &clat0);
+        sincosd(theta0, &sthe0, &cthe0);
+        int latpreq = 0;
+        valid = true;
+        if (phip == phi0) {
+            sphip = 0.0;
+            cphip = 1.0;
+            u = theta0;
+            v = 90.0 - lat0;
+        } else {
+            ::sincos((phip - phi0) * kPi / 180.0, &sphip, &cphip);
+            const double x = cthe0 * cphip, y = sthe0, z = std::sqrt(x * x + y * y);
+            if (z == 0.0) {
+                if (slat0 != 0.0) valid = false;
+                latpreq = 2;
+                if (latp > 90.0) latp = 90.0;
+                else if (latp < -90.0) latp = -90.0;
+            } else {
+                double slz = slat0 / z;
+                if (std::fabs(slz) > 1.0) {
+                    if ((std::fabs(slz) - 1.0) < tol) slz = (slz > 0.0) ? 1.0 : -1.0;
+                    else valid = false;
+                }
+                u = atan2d(y, x);
+                v = acosd(slz);
+            }
+        }
+        if (latpreq == 0) {
+            double latp1 = u + v;
+            if (latp1 > 180.0) latp1 -= 360.0;
+            else if (latp1 < -180.0) latp1 += 360.0;
+            double latp2 = u - v;
+            if (latp2 > 180.0) latp2 -= 360.0;
+            else if (latp2 < -180.0) latp2 += 360.0;
+            if (std::fabs(latp - latp1) < std::fabs(latp - latp2)) latp = (std::fabs(latp1) < 90.0 + tol) ? latp1 : latp2;
+            else latp = (std::fabs(latp2) < 90.0 + tol) ? latp2 : latp1;
+            if (std::fabs(latp) < 90.0 + tol) {
+                if (latp > 90.0) latp = 90.0;
+                else if (latp < -90.0) latp = -90.0;
+            } else {
+                valid = false;
+            }
+        }
+        double lngp;
+        const double z = cosd(latp) * clat0;
+        if (std::fabs(z) < tol) {
+            if (std::fabs(clat0) < tol) lngp = lng0;
+            else if (latp > 0.0) lngp = lng0 + phip - phi0 - 180.0;
+            else lngp = lng0 - phip + phi0;
+        } else {
+            const double x = (sthe0 - sind(latp) * slat0) / z, y = sphip * cthe0 / clat0;
+            if (x == 0.0 && y == 0.0) valid = false;
+            lngp = lng0 - atan2d(y, x);
+        }
+        if (lng0 >= 0.0) {
+            if (lngp < 0.0) lngp += 360.0;
+            else if (lngp > 360.0) lngp -= 360.0;
+        } else {
+            if (lngp > 0.0) lngp -= 360.0;
+            else if (lngp < -360.0) lngp += 360.0;
+        }
+        e0 = lngp;
+        e1 = 90.0 - latp;
+        e2 = phip;
+        sincosd(e1, &e4, &e3);
+    }
+    void p2s(double px0, double py0, double* lng_out, double* lat_out) const {
+#pragma clang fp contract(off)
+        const double t0 = (px0 + 1.0) - crpix[0], t1 = (py0 + 1.0) - crpix[1];
+        double x, y;
+        if (unity) {
+            x = cdelt[0] * t0;
+            y = cdelt[1] * t1;
+        } else {
+            x = 0.0;
+            y = 0.0;
+            x += piximg[0][0] * t0;
+            y += piximg[1][0] * t0;
+            x += piximg[0][1] * t1;
+            y += piximg[1][1] * t1;
+        }
+        const double phi = 1.0 * (x + 0.0), theta = 1.0 * (y + 0.0);  // carx2s
+        double lng, lat;
+        if (e4 == 0.0) {
+            if (e1 == 0.0) {
+                const double dlng = std::fmod(e0 + 180.0 - e2, 360.0);
+                lng = phi + dlng;
+                lat = theta;
+            } else {
+                const double dlng = std::fmod(e0 + e2, 360.0);
+                lng = dlng - phi;
+                lat = -theta;
+            }
+            if (e0 >= 0.0) {
+                if (lng < 0.0) lng += 360.0;
+            } else {
+                if (lng > 0.0) lng -= 360.0;
+            }
+            if (lng > 360.0) lng -= 360.0;
+            else if (lng < -360.0) lng += 360.0;
+            *lng_out = lng;
+            *lat_out = lat;
+            return;
+        }
+        const double dphi = phi - e2;
+        double sinthe, costhe, sinphi, cosphi;
+        sincosd(theta, &sinthe, &costhe);
+        const double costhe3 = costhe * e3, costhe4 = costhe * e4, sinthe3 = sinthe * e3, sinthe4 = sinthe * e4;
+        sincosd(dphi, &sinphi, &cosphi);
+        double xx = sinthe4 - costhe3 * cosphi;
+        if (std::fabs(xx) < 1.0e-5) xx = -cosd(theta + e1) + costhe3 * (1.0 - cosphi);
+        const double yy = -costhe * sinphi;
+        const double dlng = (xx != 0.0 || yy != 0.0) ? atan2d(yy, xx) : dphi + 180.0;
+        lng = e0 + dlng;
+        if (e0 >= 0.0) {
+            if (lng < 0.0) lng += 360.0;
+        } else {
+            if (lng > 0.0) lng -= 360.0;
+        }
+        if (lng > 360.0) lng -= 360.0;
+        else if (lng < -360.0) lng += 360.0;
+        if (std::fmod(dphi, 180.0) == 0.0) {
+            lat = theta + cosphi * e1;
+            if (lat > 90.0) lat = 180.0 - lat;
+            if (lat < -90.0) lat = -180.0 - lat;
+        } else {
+            const double z = sinthe3 + costhe4 * cosphi;
+            if (std::fabs(z) > 0.99) lat = std::copysign(acosd(std::sqrt(xx * xx + yy * yy)), z);
+            else lat = asind(z);
+        }
+        *lng_out = lng;
+        *lat_out = lat;
+    }
+    void s2p(double lng, double lat, double* px_out, double* py_out) const {
+#pragma clang fp contract(off)
+        double phi, theta;
+        if (e4 == 0.0) {
+            if (e1 == 0.0) {
+                const double dphi = std::fmod(e2 - 180.0 - e0, 360.0);
+                phi = std::fmod(lng + dphi, 360.0);
+                theta = lat;
+            } else {
+                const double dphi = std::fmod(e2 + e0, 360.0);
+                phi = std::fmod(dphi - lng, 360.0);
+                theta = -lat;
+            }
+            if (phi > 180.0) phi -= 360.0;
+            else if (phi < -180.0) phi += 360.0;
+        } else {
+            const double dlng = lng - e0;
+            double sinlat, coslat, sinlng, coslng;
+            sincosd(lat, &sinlat, &coslat);
+            const double coslat3 = coslat * e3, coslat4 = coslat * e4, sinlat3 = sinlat * e3, sinlat4 = sinlat * e4;
+            sincosd(dlng, &sinlng, &coslng);
+            double xx = sinlat4 - coslat3 * coslng;
+            if (std::fabs(xx) < 1.0e-5) xx = -cosd(lat + e1) + coslat3 * (1.0 - coslng);
+            const double yy = -coslat * sinlng;
+            const double dphi = (xx != 0.0 || yy != 0.0) ? atan2d(yy, xx) : dlng - 180.0;
+            phi = std::fmod(e2 + dphi, 360.0);
+            if (phi > 180.0) phi -= 360.0;
+            else if (phi < -180.0) phi += 360.0;
+            if (std::fmod(dlng, 180.0) == 0.0) {
+                theta = lat + coslng * e1;
+                if (theta > 90.0) theta = 180.0 - theta;
+                if (theta < -90.0) theta = -180.0 - theta;
+            } else {
+                const double z = sinlat3 + coslat4 * coslng;
+                if (std::fabs(z) > 0.99) theta = std::copysign(acosd(std::sqrt(xx * xx + yy * yy)), z);
+                else theta = asind(z);
+            }
+        }
+        const double x = 1.0 * phi - 0.0, y = 1.0 * theta - 0.0;  // cars2x
+        double p0, p1;
+        if (unity) {
+            p0 = x / cdelt[0] + crpix[0];
+            p1 = y / cdelt[1] + crpix[1];
+        } else {
+            p0 = 0.0;
+            p0 += imgpix[0][0] * x;
+            p0 += imgpix[0][1] * y;
+            p0 += crpix[0];
+            p1 = 0.0;
+            p1 += imgpix[1][0] * x;
+            p1 += imgpix[1][1] * y;
+            p1 += crpix[1];
+        }
+        *px_out = p0 - 1.0;
+        *py_out = p1 - 1.0;
+    }
+};
+inline void wcslib_pixel_to_pixel(const WcslibCar& from, const WcslibCar& to, double px, double py, double* ox, double* oy) {
+    double lng, lat;
+    from.p2s(px, py, &lng, &lat);
+    to.s2p(lng, lat, ox, oy);  // (no ang2pipi on this path)
+}
+
 // ---- plate carree (CAR) inputs: align_using_initial_carrington, alignment.py:344-399 --------------------
 // wcslib celset (cel.c) for a cylindrical projection, fiducial native point (phi0, theta0) = (0, 0): celestial
 // longitude / latitude of the native pole and LONPOLE, in degrees.  A CRVAL2 lag makes the projection oblique; an

@@ -1942,7 +1942,29 @@ struct TapScanArgs {
     unsigned int cap;
     int rows_per_block;
     int i_lo, i_hi, j_lo, j_hi;  // (inclusive) the cull box of the sweep: no pixel outside it maps into the image
+    // Round 5: a near-integer coordinate only matters where it can change the RESULT.  The tap that enters or leaves an
+    // odd-order footprint when the coordinate crosses the integer carries a weight of order (1e-9)^order: the value moves
+    // by 1e-12 of a pixel difference -- unless that tap is NaN (it then poisons the sample: 0 * NaN) or the coordinate
+    // sits ON the bounds rule.  So only samples on the bounds, or with a non-finite pixel in the union of the two
+    // footprints ((order + 2)^2 pixels around the nearest pixel, edges mirrored), are listed for wcslib's chain.
+    const void* img;
+    int img_f32, W, H, order, nan_filter;
 };
+template <typename TS>
+__device__ __forceinline__ bool tap_union_has_nonfinite(const TS* __restrict__ img, int W, int H, int mx, int my, int hw) {
+    for (int dy = -hw; dy <= hw; ++dy) {
+        int yy = my + dy;
+        yy = yy < 0 ? -yy : (yy > H - 1 ? 2 * (H - 1) - yy : yy);
+        yy = min(max(yy, 0), H - 1);
+        for (int dx = -hw; dx <= hw; ++dx) {
+            int xx = mx + dx;
+            xx = xx < 0 ? -xx : (xx > W - 1 ? 2 * (W - 1) - xx : xx);
+            xx = min(max(xx, 0), W - 1);
+            if (!isfinite((double)img[(size_t)yy * W + xx])) return true;
+        }
+    }
+    return false;
+}
 // One thread per (lag slot, grid row).  Along a row the mapped coordinate is x(i) = (a i + b) / (c i + d): the offsets
 // x - i and y - j are evaluated at the ends of 64-pixel segments and bounded in between by the chord plus
 // max|f''| L^2 / 8 (f'' = 2 c (b c - a d) / (c i + d)^3, bounded over the row); only segments whose bound comes within
@@ -1996,6 +2018,17 @@ __global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
                     const int inr = (int)(x >= -a.tol) & (int)(x <= a.wmax + a.tol) & (int)(y >= -a.tol) & (int)(y <= a.hmax + a.tol);
                     const int near = (int)(fabs(x - rint(x)) < a.tol) | (int)(fabs(y - rint(y)) < a.tol);
                     if (inr & near) {
+                        if (a.nan_filter) {
+                            const bool on_bound = fabs(x) < a.tol || fabs(x - a.wmax) < a.tol || fabs(y) < a.tol ||
+                                                  fabs(y - a.hmax) < a.tol;
+                            if (!on_bound) {
+                                const int mx = (int)rint(x), my = (int)rint(y), hw = (a.order + 1) / 2;
+                                const bool nonfinite =
+                                    a.img_f32 ? tap_union_has_nonfinite((const float*)a.img, a.W, a.H, mx, my, hw)
+                                              : tap_union_has_nonfinite((const double*)a.img, a.W, a.H, mx, my, hw);
+                                if (!nonfinite) continue;
+                            }
+                        }
                         const unsigned k = atomicAdd(a.count, 1u);
                         if (k < a.cap) a.list[k] = make_uint2((unsigned)slot, (unsigned)idx);
                     }

@@ -45,6 +45,16 @@ def main():
                     d = np.abs(out[1] - out[0])
                     res["lag_points_changed"] = int((d > 0).sum())
                     res["largest_change"] = float(np.nanmax(d))
+                    # round 5: only the samples that can change the result are listed (on the bounds rule, or with a
+                    # non-finite pixel in the union of the two tap sets); the unfiltered list gives the same map
+                    h.set_option("tap_nan_filter", 0)
+                    h.sweep_helioprojective(hdr, hdr, lags, order=order)
+                    t0 = time.perf_counter()
+                    full = h.sweep_helioprojective(hdr, hdr, lags, order=order)
+                    res["unfiltered_sweep_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+                    res["unfiltered_samples"] = h.last_tap_fix()["samples"] if "samples" in h.last_tap_fix() else h.last_tap_fix()
+                    res["filtered_vs_unfiltered_max"] = float(np.nanmax(np.abs(full - out[1])))
+                    h.set_option("tap_nan_filter", 1)
                 print(json.dumps(res), flush=True)
     # serial semantics (parallelism=False: the target is the reference's own, coarser grid -- every 64-pixel segment of
     # the scan spans many integers and is tested pixel by pixel)

@@ -347,8 +347,8 @@ def test_zero_lag_order1_full_size_follows_wcslib_taps(gpu_handle, big_scene):
     got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=1)[..., 0, 0, 0, 0]
     gpu_handle.set_option("border_fix", 0)  # exact identity map for the zero lag ...
     try:
-        # ... which the general pass of odd orders ("tap_fix": every sample within 1e-8 px of an integer re-evaluated with
-        # wcslib's chain, here all 4 194 304 of the zero lag) then decides by itself, to the same coefficient
+        # ... which the general pass of odd orders ("tap_fix": the samples within 1e-8 px of an integer that can change
+        # the result re-evaluated with wcslib's chain) then decides by itself, to the same coefficient
         general = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=1, prepare=False)[..., 0, 0, 0, 0]
         tf = gpu_handle.last_tap_fix()
         gpu_handle.set_option("tap_fix", 0)  # no wcslib decision at all
@@ -356,7 +356,8 @@ def test_zero_lag_order1_full_size_follows_wcslib_taps(gpu_handle, big_scene):
     finally:
         gpu_handle.set_option("border_fix", 1)
         gpu_handle.set_option("tap_fix", 1)
-    assert not tf["overflow"] and tf["samples"] > 4_000_000 and abs(general[0, 1] - got[0, 1]) < 1e-9
+    # (round 5: of the 4 194 304 near-integer samples only those on the bounds rule or beside a NaN pixel are listed)
+    assert not tf["overflow"] and 8188 <= tf["samples"] < 1_000_000 and abs(general[0, 1] - got[0, 1]) < 1e-9
     assert np.array_equal(np.delete(general.ravel(), 1), np.delete(got.ravel(), 1))
     st = H.oracle_state(small, hs, large, hl, lags, order=1)
     O.set_initial_header_values(st)

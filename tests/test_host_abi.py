@@ -186,6 +186,25 @@ def test_library_wcslib_chain_is_bit_exact_on_border_pixels(name):
     assert np.array_equal(drop, g[name + "/dropped"])
 
 
+def test_library_wcslib_car_chain_is_bit_exact():
+    """csrc/geometry.hpp WcslibCar (the host code that decides the border pixels of the identity lag of two Carrington
+    maps) against astropy 4.3.1 / wcslib 7.6: nine CAR headers, every border pixel + two diagonals, world coordinates and
+    the pixel -> world -> pixel round trip, bit for bit (tests/golden/make_golden_border_car.py)."""
+    import os
+    from tests.conftest import GOLDEN
+    from euispice_coreg_amd import _lib
+    g = np.load(os.path.join(GOLDEN, "border_car_golden.npz"))
+    names = sorted(set(k.split("/")[0] for k in g.files))
+    assert len(names) == 9
+    for name in names:
+        h = dict(zip([str(k) for k in g[name + "/keys"]], [float(v) for v in g[name + "/vals"]]))
+        h.update(CUNIT1=str(g[name + "/unit"]), CUNIT2=str(g[name + "/unit"]), CTYPE1="CRLN-CAR", CTYPE2="CRLT-CAR",
+                 NAXIS1=int(h["NAXIS1"]), NAXIS2=int(h["NAXIS2"]))
+        x, y, lon, lat = _lib.wcslib_pixel_to_pixel(h, h, g[name + "/bx"], g[name + "/by"])
+        assert np.array_equal(lon, g[name + "/lon"]) and np.array_equal(lat, g[name + "/lat"]), name
+        assert np.array_equal(x, g[name + "/rx"]) and np.array_equal(y, g[name + "/ry"]), name
+
+
 def test_hand_issued_lds_reads_are_not_touched_before_their_wait():
     """kernels.hpp Taps<N>: reads and s_waitcnt sit in separate inline-asm statements; the disassembly of the built
     library must show no use of a tap register in between (csrc/check_isa.py, also run by build())."""
