@@ -183,7 +183,7 @@ struct coreg_handle {
     // odd spline orders, general case: samples whose coordinate comes back within opt_tap_tol of an integer are
     // re-evaluated with wcslib's own arithmetic (k_tap_scan / k_tap_fix)
     int64_t opt_tap_fix = 1, opt_tap_cap = 1 << 24;
-    DevBuf tap_count, tap_list, tap_skip, tap_seg_slot, tap_seg_begin, tap_pixel, tap_xw, tap_yw;
+    DevBuf tap_count, tap_segq, tap_list, tap_skip, tap_seg_slot, tap_seg_begin, tap_pixel, tap_xw, tap_yw;
     long long tap_last[3] = {0, 0, 0};  // last sweep: samples listed, lag-points concerned, 1 = list overflowed (no fix)
     // multi-GPU point sharding (coreg_set_option "shard_world" / "shard_rank"): a sweep covers this rank's share of the
     // tile groups and leaves the six sums per lag slot in `sums`; coreg_finalize_sums turns the all-reduced sums into
@@ -1703,7 +1703,9 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, int order, const coreg_wcs2
     // only when a sweep lists more, up to "tap_cap"
     const unsigned cap_max = (unsigned)h->opt_tap_cap;
     unsigned cap = (unsigned)std::min<size_t>(cap_max, std::max<size_t>((size_t)1 << 16, h->tap_list.cap / sizeof(uint2)));
-    HIPCHK(h->tap_count.reserve(sizeof(unsigned)));
+    HIPCHK(h->tap_count.reserve(2 * sizeof(unsigned)));  // [0] listed samples, [1] queued segments
+    const unsigned seg_cap = 1u << 20;                   // 16 MiB of (slot, row, first, end); beyond: tested in-thread
+    HIPCHK(h->tap_segq.reserve((size_t)seg_cap * sizeof(uint4)));
     HIPCHK(h->tap_list.reserve((size_t)cap * sizeof(uint2)));
     HIPCHK(h->tap_skip.reserve((size_t)n_slots));
     HIPCHK(hipMemcpyAsync(h->tap_skip.p, skip.data(), (size_t)n_slots, hipMemcpyHostToDevice, h->stream));
@@ -1724,6 +1726,9 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, int order, const coreg_wcs2
     a.H = h->sH;
     a.order = order;
     a.nan_filter = h->opt_tap_nan_filter ? 1 : 0;
+    a.seg_list = h->tap_segq.as<uint4>();
+    a.seg_count = h->tap_count.as<unsigned>() + 1;
+    a.seg_cap = seg_cap;
     if (a.nan_filter) RETCHK(join_small(h));  // (the scan reads the image to align)
     a.count = h->tap_count.as<unsigned>();
     a.list = h->tap_list.as<uint2>();
@@ -1744,11 +1749,14 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, int order, const coreg_wcs2
     for (int pass = 0; pass < 2; ++pass) {
         a.list = h->tap_list.as<uint2>();
         a.cap = cap;
-        HIPCHK(hipMemsetAsync(h->tap_count.p, 0, sizeof(unsigned), h->stream));
-        if (sweep_mode == MODE_HOMOGRAPHY_SERIES)
+        HIPCHK(hipMemsetAsync(h->tap_count.p, 0, 2 * sizeof(unsigned), h->stream));
+        if (sweep_mode == MODE_HOMOGRAPHY_SERIES) {
             hipLaunchKernelGGL((k_tap_scan<MODE_HOMOGRAPHY_SERIES>), grid, dim3(256), 0, h->stream, a);
-        else
+            hipLaunchKernelGGL((k_tap_scan_segments<MODE_HOMOGRAPHY_SERIES>), dim3(2048), dim3(256), 0, h->stream, a);
+        } else {
             hipLaunchKernelGGL((k_tap_scan<MODE_HOMOGRAPHY>), grid, dim3(256), 0, h->stream, a);
+            hipLaunchKernelGGL((k_tap_scan_segments<MODE_HOMOGRAPHY>), dim3(2048), dim3(256), 0, h->stream, a);
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&count, h->tap_count.p, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));

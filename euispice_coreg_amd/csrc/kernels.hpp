@@ -1949,6 +1949,13 @@ struct TapScanArgs {
     // footprints ((order + 2)^2 pixels around the nearest pixel, edges mirrored), are listed for wcslib's chain.
     const void* img;
     int img_f32, W, H, order, nan_filter;
+    // Round 5: a thread of k_tap_scan owns (lag slot, rows) and used to test the pixels of every segment it could not
+    // dismiss by itself -- for the pure CRVAL1 / CRVAL2 lags of an unrotated header that is whole columns of pixels walked
+    // by a handful of lanes.  Such segments are now queued (slot, row, first pixel) and tested by k_tap_scan_segments, one
+    // wavefront per segment, one lane per pixel; a full queue falls back to the in-thread test.
+    uint4* seg_list;
+    unsigned int* seg_count;
+    unsigned int seg_cap;
 };
 template <typename TS>
 __device__ __forceinline__ bool tap_union_has_nonfinite(const TS* __restrict__ img, int W, int H, int mx, int my, int hw) {
@@ -1971,6 +1978,47 @@ __device__ __forceinline__ bool tap_union_has_nonfinite(const TS* __restrict__ i
 // `tol` of an integer are tested pixel by pixel with the sweep's own arithmetic.  In the sub-map semantics the target
 // grid IS the image's grid, the offsets are the lag in pixels plus 1e-5 .. 1e-3 px of field distortion, and all but a
 // few segments in ten thousand are dismissed by their end points (cfg2: 0.3 ms where the pixel-by-pixel scan took 11).
+// one grid pixel of one lag slot: is its sample within `tol` of an integer coordinate, in range, and able to change the
+// result?  Then it is listed.
+template <int MODE>
+__device__ __forceinline__ void tap_scan_pixel(const TapScanArgs& a, const H9& hm, long long slot, int i, int j) {
+    const LaunchU cu = {};
+    const long long idx = (long long)j * a.gw + i;
+    const double araw = a.ref_f32 ? (double)((const float*)a.ref)[idx] : ((const double*)a.ref)[idx];
+    if (!isfinite(araw)) return;
+    double x, y;
+    apply_map<MODE>(hm, cu, (double)i, (double)j, x, y);  // the coordinates k_sweep uses
+    const int inr = (int)(x >= -a.tol) & (int)(x <= a.wmax + a.tol) & (int)(y >= -a.tol) & (int)(y <= a.hmax + a.tol);
+    const int near = (int)(fabs(x - rint(x)) < a.tol) | (int)(fabs(y - rint(y)) < a.tol);
+    if (!(inr & near)) return;
+    if (a.nan_filter) {
+        const bool on_bound = fabs(x) < a.tol || fabs(x - a.wmax) < a.tol || fabs(y) < a.tol || fabs(y - a.hmax) < a.tol;
+        if (!on_bound) {
+            const int mx = (int)rint(x), my = (int)rint(y), hw = (a.order + 1) / 2;
+            const bool nonfinite = a.img_f32 ? tap_union_has_nonfinite((const float*)a.img, a.W, a.H, mx, my, hw)
+                                             : tap_union_has_nonfinite((const double*)a.img, a.W, a.H, mx, my, hw);
+            if (!nonfinite) return;
+        }
+    }
+    const unsigned k = atomicAdd(a.count, 1u);
+    if (k < a.cap) a.list[k] = make_uint2((unsigned)slot, (unsigned)idx);
+}
+// the queued segments: one wavefront each, one lane per pixel
+template <int MODE>
+__global__ void __launch_bounds__(256) k_tap_scan_segments(const TapScanArgs a) {
+    const unsigned n = min(*a.seg_count, a.seg_cap);
+    const int lane = threadIdx.x & 63;
+    for (unsigned sg = blockIdx.x * 4 + (threadIdx.x >> 6); sg < n; sg += gridDim.x * 4) {
+        const uint4 e = a.seg_list[sg];  // (slot, row, first pixel, one past the last pixel)
+        const long long slot = e.x;
+        const int i = (int)e.z + lane;
+        if (i >= (int)e.w) continue;
+        H9 hm;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) hm.h[k] = a.hom[(long long)k * a.n_slots + slot];
+        tap_scan_pixel<MODE>(a, hm, slot, i, (int)e.y);
+    }
+}
 template <int MODE>
 __global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
     constexpr int L = 64;
@@ -2009,29 +2057,11 @@ __global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
             const bool hit = !sane || !(ceil(xlo) > xhi) || !(ceil(ylo) > yhi);
             if (hit) {
                 const int iend = (i0 + L > a.i_hi) ? a.i_hi + 1 : i1;  // (the shared end point belongs to the next segment)
-                for (int i = i0; i < iend; ++i) {
-                    const long long idx = (long long)j * a.gw + i;
-                    const double araw = a.ref_f32 ? (double)((const float*)a.ref)[idx] : ((const double*)a.ref)[idx];
-                    if (!isfinite(araw)) continue;
-                    double x, y;
-                    apply_map<MODE>(hm, cu, (double)i, dj, x, y);  // the coordinates k_sweep uses
-                    const int inr = (int)(x >= -a.tol) & (int)(x <= a.wmax + a.tol) & (int)(y >= -a.tol) & (int)(y <= a.hmax + a.tol);
-                    const int near = (int)(fabs(x - rint(x)) < a.tol) | (int)(fabs(y - rint(y)) < a.tol);
-                    if (inr & near) {
-                        if (a.nan_filter) {
-                            const bool on_bound = fabs(x) < a.tol || fabs(x - a.wmax) < a.tol || fabs(y) < a.tol ||
-                                                  fabs(y - a.hmax) < a.tol;
-                            if (!on_bound) {
-                                const int mx = (int)rint(x), my = (int)rint(y), hw = (a.order + 1) / 2;
-                                const bool nonfinite =
-                                    a.img_f32 ? tap_union_has_nonfinite((const float*)a.img, a.W, a.H, mx, my, hw)
-                                              : tap_union_has_nonfinite((const double*)a.img, a.W, a.H, mx, my, hw);
-                                if (!nonfinite) continue;
-                            }
-                        }
-                        const unsigned k = atomicAdd(a.count, 1u);
-                        if (k < a.cap) a.list[k] = make_uint2((unsigned)slot, (unsigned)idx);
-                    }
+                const unsigned q = a.seg_list ? atomicAdd(a.seg_count, 1u) : a.seg_cap;
+                if (q < a.seg_cap) {
+                    a.seg_list[q] = make_uint4((unsigned)slot, (unsigned)j, (unsigned)i0, (unsigned)iend);
+                } else {
+                    for (int i = i0; i < iend; ++i) tap_scan_pixel<MODE>(a, hm, slot, i, j);
                 }
             }
             x0 = x1;
