@@ -917,7 +917,20 @@ struct LagDims {
     }
 };
 
-int check_lags(coreg_handle* h, const coreg_lags* l, LagDims* d, int64_t begin, int64_t end) {
+// The one-shot combination range ("combo_begin" / "combo_end") belongs to THE NEXT sweep call, whatever becomes of it: the
+// entry points take it off the handle before any validation (a call that failed early used to leave it armed
+// for an unrelated later sweep) and hand it to check_lags.
+struct ComboRange {
+    long long begin = 0, end = 0;
+};
+ComboRange take_combo_range(coreg_handle* h) {
+    ComboRange r;
+    r.begin = h->opt_combo_begin;
+    r.end = h->opt_combo_end;
+    h->opt_combo_begin = h->opt_combo_end = 0;
+    return r;
+}
+int check_lags(coreg_handle* h, const coreg_lags* l, LagDims* d, int64_t begin, int64_t end, ComboRange combo = ComboRange()) {
     if (!l || !l->crval1 || !l->crval2 || !l->cdelt1 || !l->cdelt2 || !l->crota)
         return fail(h, COREG_EINVAL, "lags: null array");
     if (l->n_crval1 < 1 || l->n_crval2 < 1 || l->n_cdelt1 < 1 || l->n_cdelt2 < 1 || l->n_crota < 1)
@@ -930,9 +943,8 @@ int check_lags(coreg_handle* h, const coreg_lags* l, LagDims* d, int64_t begin, 
     d->nc = (long long)d->n3 * d->n4 * d->n5;
     d->c0 = 0;
     {
-        // one-shot combination range of a multi-GPU sweep: consumed here, whatever happens next
-        const long long cb = h->opt_combo_begin, ce = h->opt_combo_end;
-        h->opt_combo_begin = h->opt_combo_end = 0;
+        // one-shot combination range of a multi-GPU sweep (taken off the handle by the entry point)
+        const long long cb = combo.begin, ce = combo.end;
         if (cb != 0 || ce != 0) {
             if (cb < 0 || ce <= cb || ce > d->nc)
                 return fail(h, COREG_EINVAL, "combo_begin/combo_end outside [0, n_cdelt1 * n_cdelt2 * n_crota]");
@@ -2830,12 +2842,13 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
                            const coreg_lags* lags, int order, int method, int cdelt_semantics, int64_t lag_begin,
                            int64_t lag_end, double* corr_out, int out_on_device) {
     if (!h) return COREG_EINVAL;
+    const ComboRange combo = take_combo_range(h);
     if (!hdr_small || !grid) return fail(h, COREG_EINVAL, "sweep_carrington: null header/grid");
     if (method != COREG_METHOD_CORRELATION && method != COREG_METHOD_RESIDUS)
         return fail(h, COREG_ENOTIMPL, "method must be COREG_METHOD_CORRELATION or COREG_METHOD_RESIDUS");
     RETCHK(check_order(h, order));
     LagDims d;
-    RETCHK(check_lags(h, lags, &d, lag_begin, lag_end));
+    RETCHK(check_lags(h, lags, &d, lag_begin, lag_end, combo));
     RETCHK(bind_device_nowait(h));  // (the image to align is joined right before k_sweep: launch_sweep)
     if (h->ref.p && (h->gW != grid->n_lon || h->gH != grid->n_lat))
         return fail(h, COREG_EINVAL, "reference-on-grid shape differs from the Carrington grid");
@@ -3235,6 +3248,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                                 const coreg_lags* lags, int order, int method, int cdelt_semantics, int64_t lag_begin,
                                 int64_t lag_end, double* corr_out, int out_on_device) {
     if (!h) return COREG_EINVAL;
+    const ComboRange combo = take_combo_range(h);
     if (!hdr_target || !hdr_small) return fail(h, COREG_EINVAL, "sweep_helioprojective: null header");
     if (hdr_target->proj != hdr_small->proj || (hdr_small->proj != COREG_PROJ_TAN && hdr_small->proj != COREG_PROJ_CAR))
         return fail(h, COREG_ENOTIMPL, "both headers must be TAN (helioprojective) or both CAR (Carrington maps)");
@@ -3242,7 +3256,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
         return fail(h, COREG_ENOTIMPL, "method must be COREG_METHOD_CORRELATION or COREG_METHOD_RESIDUS");
     RETCHK(check_order(h, order));
     LagDims d;
-    RETCHK(check_lags(h, lags, &d, lag_begin, lag_end));
+    RETCHK(check_lags(h, lags, &d, lag_begin, lag_end, combo));
     RETCHK(bind_device_nowait(h));
     if (h->ref.p && (h->gW != hdr_target->naxis1 || h->gH != hdr_target->naxis2))
         return fail(h, COREG_EINVAL, "reference-on-grid shape differs from hdr_target NAXIS1/NAXIS2");

@@ -421,6 +421,10 @@ class CompressedImage:
             self.has_blank, self.blank = True, int(th["BLANK"])
         else:
             self.has_blank, self.blank = False, 0
+        if self.zbitpix > 0 and self.bscale == 1 and self.bzero == 0:
+            #  astropy -- hence the reference -- turns BLANK into NaN only where BSCALE / BZERO make the image
+            # floating point; unscaled integers keep the stored value, compressed or not (`_decode` of a plain image)
+            self.has_blank = False
 
     # ---- what the library needs
     @property

@@ -114,6 +114,14 @@ def test_combo_range_option_is_one_shot_and_selects_the_combinations(gpu_handle)
         gpu_handle.sweep_carrington(hs, grid, 1.004, ls, lag_end=10)
     again = gpu_handle.sweep_carrington(hs, grid, 1.004, ls).reshape(7, 6, inner)
     assert np.array_equal(again, full, equal_nan=True)
+    #  a sweep that fails BEFORE the lag set is looked at -- a spline order the library refuses -- consumes the
+    # range all the same: the next, ordinary sweep on this context covers everything
+    gpu_handle.set_option("combo_begin", 2)
+    gpu_handle.set_option("combo_end", 4)
+    with pytest.raises(_lib.CoregError):
+        gpu_handle.sweep_carrington(hs, grid, 1.004, ls, order=9)
+    again = gpu_handle.sweep_carrington(hs, grid, 1.004, ls).reshape(7, 6, inner)
+    assert np.array_equal(again, full, equal_nan=True)
     # helioprojective sub-map semantics, a slice of the restricted index
     gpu_handle.prepare_reference_helioprojective(large, hl, hs, 2)
     fullh = gpu_handle.sweep_helioprojective(hs, hs, ls).reshape(7, 6, inner)
