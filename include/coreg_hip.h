@@ -215,7 +215,9 @@ int coreg_set_reference_on_grid(coreg_handle* h, const void* ref, int dtype, int
  *
  * Once-per-sweep reference preparation on the GPU.
  * carrington:      alignment.py:646-648 -> :889-901  (large image -> Carrington grid, float64)
- * helioprojective: alignment.py:649-651 -> :987-1000 (large image -> small header's pixel grid, float32) */
+ * helioprojective: alignment.py:649-651 -> :987-1000 (large image -> small header's pixel grid, float32).  Both headers
+ *                  TAN, or both CAR: two Carrington maps, align_using_initial_carrington -- BOTH branches of the
+ *                  reference build this sub-map for that frame (alignment.py:649-651 and :765-767). */
 int coreg_prepare_reference_carrington(coreg_handle* h, const double* large, int32_t ny, int32_t nx,
                                        const coreg_wcs2d* hdr_large, const coreg_carr_grid* grid, double solar_r,
                                        int order);
@@ -305,9 +307,9 @@ int coreg_last_stats(coreg_handle* h, coreg_stats* out);
 /* Diagnostics.  counts6[0..3]: (tile, lag batch) visits of the sweep kernel's workgroups in the LAST launch of the last
  * sweep -- all; gathered from an LDS window; of those, "interior" (every sample inside the image: no bounds rule); of
  * those, all-finite windows (no sample mask either).  counts6[4]: lag-points of the WHOLE last sweep whose six sums
- * were too ill-conditioned for the one-pass Pearson formula and were re-evaluated with centred sums ("refine");
- * counts6[5]: lag-points that were flagged likewise but kept their one-pass value because their block of 16 lag slots
- * had used up its "refine_max" re-evaluations.  Waits for the stream. */
+ * were too ill-conditioned for the one-pass Pearson formula and were re-evaluated about their own means ("refine");
+ * counts6[5]: lag-points that were flagged but kept their one-pass value -- always 0 since round 5 (there is no cap on
+ * the re-evaluations any more; the field stays for ABI stability).  Waits for the stream. */
 int coreg_last_visit_counts(coreg_handle* h, int64_t* counts6);
 /* Odd spline orders in the helioprojective frame ("tap_fix", below): counts3[0] samples of the last sweep whose mapped
  * coordinate lay within 1e-8 px of an integer and were re-evaluated with wcslib's own arithmetic, counts3[1] lag-points
@@ -319,14 +321,21 @@ int coreg_last_tap_fix(coreg_handle* h, int64_t* counts3);
  *   "clean_path"   1 (default) interior visits whose LDS window holds only finite values skip the per-sample mask and
  *                  take the count and the reference moments from per-chunk sums; 0: always the masked arithmetic
  *   "refine"       1 (default) lag-points whose sums are ill-conditioned (sum xx / (n var) > 1e5: a handful of samples, an
- *                  overlap inside a flat region) are re-evaluated with means first and centred sums second, as
- *                  c_correlate.py:39-72 does; 0: the one-pass formula everywhere
+ *                  overlap inside a flat region) are re-evaluated with sums centred on the lag-point's own means and the
+ *                  corrected two-pass formula -- the accuracy of c_correlate.py:39-72's means-first evaluation -- by
+ *                  kernels of their own, EVERY flagged lag-point, also in grid-sharded multi-GPU sweeps
+ *                  (coreg_finalize_sums flags from the reduced sums); 0: the one-pass formula everywhere
  *   "refine_cond_log10"  5 (default): log10 of that threshold; -1 re-evaluates every lag-point (tests)
- *   "refine_max"   4 (default): re-evaluations per block of 16 consecutive lag slots (a re-evaluation walks every active
- *                  grid point twice with ONE workgroup, ~1.5 ms at headline size: the cap bounds a sweep whose overlaps
- *                  are degenerate everywhere -- flat images, a handful of samples per lag-point -- to a few tens of ms;
- *                  the flagged lag-points beyond it keep the one-pass value and are counted, coreg_last_visit_counts);
- *                  0 = no limit
+ *   "refine_max"   accepted and ignored (round 4 capped the re-evaluations per block of lag slots; no cap any more)
+ *   "overlap_upload"  1 (default) coreg_set_small_f32 / coreg_set_small_fits (BITPIX -32) put the image to align on an
+ *                  upload stream of the handle's own: a coreg_prepare_reference_* called next does not queue behind the
+ *                  image's DMA; the first call that reads the image joins the streams.  0: everything on one stream
+ *   "async_upload" 0 (default).  1: those two calls return as soon as the upload is QUEUED on the handle's upload thread
+ *                  (staging copies + DMA run there while the caller prepares the reference and plans the sweep).  The
+ *                  caller's pixel buffer must then stay valid and unchanged until the next call on this handle that reads
+ *                  the image (a sweep, coreg_threshold_small, coreg_synchronize, ...) has returned
+ *   "tap_nan_filter"  1 (default) the odd-order pass ("tap_fix") lists only the near-integer samples that can change the
+ *                  result: on the bounds rule, or with a non-finite pixel in the union of the two tap sets; 0: all of them
  *   "tap_fix"      1 (default): helioprojective sweeps with an odd spline order re-evaluate, with wcslib's own arithmetic
  *                  on the host, every sample whose mapped coordinate comes back within 1e-8 px of an integer -- there
  *                  the sign of the rounding noise of the reference's round trip (alignment.py:1038-1069) picks the
@@ -348,7 +357,8 @@ int coreg_last_tap_fix(coreg_handle* h, int64_t* counts3);
  *   "combo_begin", "combo_end"  multi-GPU sharding by (cdelt1, cdelt2, crota) combination: the NEXT sweep call covers
  *                  only the combinations [begin, end) of the inner C-order index (i_cdelt1 * n_cdelt2 + i_cdelt2) * n_crota
  *                  + i_crota; its output (and lag_begin / lag_end) is the C-order array [n_crval1][n_crval2][end - begin].
- *                  One-shot: consumed by that call, which leaves "all combinations" behind whether it succeeds or not.
+ *                  One-shot: taken off the handle at the very top of that call, before any validation -- it leaves
+ *                  "all combinations" behind whether it succeeds, fails late or fails at once.
  * Returns COREG_EINVAL for unknown names. */
 int coreg_set_option(coreg_handle* h, const char* name, int64_t value);
 
