@@ -487,13 +487,10 @@ def main():
             with torch.cuda.stream(streams[0]):
                 ts = parallel.replicate_image(small_h) if use_dist else None
                 if ts is None:
-                    # (round 5: staging copies + DMA of the image to align on the library's upload thread / stream while
-                    # this thread prepares the reference and plans the sweep; small_h is not touched meanwhile)
-                    h.set_option("async_upload", 1)
-                    try:
-                        h.set_small(small_h)
-                    finally:
-                        h.set_option("async_upload", 0)
+                    # (round 5: the image to align goes up on the handle's upload stream, staged with non-temporal
+                    # copies; the reference preparation below does not queue behind it.  The opt-in upload THREAD
+                    # -- option "async_upload" -- measured +-0.03 ms here and is not used: profiles/r05_pcie_breakdown.log)
+                    h.set_small(small_h)
                 else:  # (the handle runs on streams[0] = torch's current stream here: stream-ordered, no sync needed)
                     h.set_small_from_device(ts.data_ptr(), ts.shape, small_h.dtype)
                 # the reference: every rank sends the rectangle its grid can touch (the library crops: ~2 % of 36 MiB)

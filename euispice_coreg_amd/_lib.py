@@ -466,6 +466,11 @@ class CoregHandle:
             img = np.ascontiguousarray(img, dtype=np.float64)
             self._chk(self._lib.coreg_set_small(self._h, img.ctypes.data, img.shape[0], img.shape[1]))
 
+    def drop_small_keepalive(self):
+        """The caller knows that the image has been read (a sweep has returned): let go of the pixel buffer held for the
+        upload thread, so that it is freed where the caller frees it and not inside the next upload."""
+        self._small_keepalive = None
+
     def threshold_small(self, vmin=None, vmax=None) -> int:
         """|v| < vmin or |v| > vmax -> NaN on the resident image to align (alignment.py:876-887); returns the number of
         finite pixels left."""

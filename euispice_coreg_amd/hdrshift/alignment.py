@@ -336,12 +336,21 @@ class Alignment:
             # library's upload thread (option "async_upload": staging copies + DMA on a stream of their own) and this
             # thread goes on to prepare the reference image; the threshold pass -- the first reader of the pixels -- is
             # issued after that (`finite_pixels`, below).  self.data_small is not modified until then.
-            if not use_all and not spread:
+            # (only when a reference preparation follows -- nothing to overlap with when the prepared reference is still
+            # resident, and the hand-over to the thread then costs more than it saves: profiles/r05_api_timing*.json)
+            will_prepare = True
+            if self.coordinate_frame == "final_carrington":
+                sr0 = 1.004 if self.lag_solar_r is None else float(np.atleast_1d(self.lag_solar_r)[0])
+                tag0 = self._reference_tag("carrington", self.lonlims, self.latlims, self.shape, sr0)
+                will_prepare = tag0 is None or tag0 != getattr(h, "reference_tag", None)
+            use_async = (will_prepare and not use_all and not spread
+                         and os.environ.get("COREG_ASYNC_UPLOAD", "1") != "0")
+            if use_async:
                 h.set_option("async_upload", 1)
             try:
                 upload_small(self.data_small)
             finally:
-                if not use_all and not spread:
+                if use_async:
                     h.set_option("async_upload", 0)
         else:
             self.data_small = np.array(self.data_small, dtype=np.float64)
@@ -448,6 +457,8 @@ class Alignment:
                 part = run()
             out[..., kk] = np.asarray(part).reshape(lags.shape)
         self.last_stats = h.last_stats()
+        if hasattr(h, "drop_small_keepalive"):
+            h.drop_small_keepalive()  # (every sweep has returned: the upload thread is done with the pixels)
         if use_all:
             self.last_sharding = h.last_mode
         elif int(self.order) % 2 == 1 and self.coordinate_frame != "final_carrington" and hasattr(h, "last_tap_fix"):
