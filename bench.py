@@ -496,9 +496,15 @@ def main():
                 # the reference: every rank sends the rectangle its grid can touch (the library crops: ~2 % of 36 MiB)
                 h.prepare_reference_carrington(large_h, hl, grid, SOLAR_R, ORDER)
                 same_pivots(h)
-            step_no[0] = 0
-            step(1)  # sweep of this rank's block (+ the one collective) on stream / handle 0
-            out_host = result[0].cpu().numpy()  # the map on the host: waits for everything above
+            if not use_dist and have_lags:
+                # one rank: the call `hdrshift.Alignment` makes -- the library's sweep with the map written straight to
+                # host memory (its own pinned read-back + stream sync; no tensor round trip in between)
+                with torch.cuda.stream(streams[0]):
+                    out_host = h.sweep_carrington(hs, grid, SOLAR_R, my_lags, order=ORDER)
+            else:
+                step_no[0] = 0
+                step(1)  # sweep of this rank's block (+ the one collective) on stream / handle 0
+                out_host = result[0].cpu().numpy()  # the map on the host: waits for everything above
             el = time.perf_counter() - t0
             if use_dist:
                 t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")

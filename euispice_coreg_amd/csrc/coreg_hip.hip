@@ -1234,9 +1234,12 @@ int fill_refine(coreg_handle* h, RefineArgs* r, int mode, int order, const doubl
     HIPCHK(h->rf_flags.reserve((size_t)n_slots * sizeof(int)));
     HIPCHK(h->rf_pivots.reserve((size_t)n_slots * 2 * sizeof(double)));
     HIPCHK(h->rf_list.reserve((size_t)n_slots * sizeof(int)));
-    HIPCHK(h->rf_head.reserve(2 * sizeof(int)));
-    // work items: (flagged slots) x (chunks per slot) <= max(kRefineBlocks, n_slots), see k_refine_list
-    HIPCHK(h->rf_partial.reserve((size_t)std::max<long long>(kRefineBlocks, n_slots) * kNumSums * sizeof(double)));
+    if (!h->rf_head.p) {
+        HIPCHK(h->rf_head.reserve(4 * sizeof(int)));
+        HIPCHK(hipMemsetAsync(h->rf_head.p, 0, 4 * sizeof(int), h->stream));  // (the two tickets start at zero)
+    }
+    // work items: (flagged slots) x (chunks per slot) <= max(kRefineItems, n_slots), see refine_list_block
+    HIPCHK(h->rf_partial.reserve((size_t)std::max<long long>(kRefineItems, n_slots) * kNumSums * sizeof(double)));
     std::memset(r, 0, sizeof(*r));
     r->cond = std::pow(10.0, (double)h->opt_refine_cond_log10);
     r->mode = mode;
@@ -1260,13 +1263,16 @@ int fill_refine(coreg_handle* h, RefineArgs* r, int mode, int order, const doubl
     return COREG_OK;
 }
 
-// after a k_finalize that has written the flags: list the flagged slots, re-evaluate them, overwrite their coefficients.
-// Three launches without a host round trip; with nothing flagged (the normal case) every block leaves at once.
-int launch_refine(coreg_handle* h, const RefineArgs& r, long long n_slots, const long long* outidx_dev,
+// after a k_finalize that has written the flags and (its last block) listed the flagged slots: re-evaluate them and
+// overwrite their coefficients (the last block of k_refine).  ONE launch, no host round trip; with nothing flagged (the
+// normal case) every block leaves at once.
+int launch_refine(coreg_handle* h, const RefineArgs& r0, long long n_slots, const long long* outidx_dev,
                   long long lag_begin, double* out_dev) {
-    hipLaunchKernelGGL(k_refine_list, dim3(1), dim3(1024), 0, h->stream, r, n_slots, h->counters.as<long long>());
+    RefineArgs r = r0;
+    r.out_index = outidx_dev;
+    r.lag_begin = lag_begin;
+    r.out = out_dev;
     hipLaunchKernelGGL(k_refine, dim3(kRefineBlocks), dim3(kRefineThreads), 0, h->stream, r, n_slots);
-    hipLaunchKernelGGL(k_refine_final, dim3(64), dim3(256), 0, h->stream, r, n_slots, outidx_dev, lag_begin, out_dev);
     HIPCHK(hipGetLastError());
     return COREG_OK;
 }
@@ -3610,9 +3616,8 @@ int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device,
         // share) with the same kernels in the same order -- identical coefficients on every rank, and equal to the
         // single-GPU sweep's, without a second collective.  The compacted points of a launch that was not the sweep's
         // last have been overwritten by the later launches: computed again, only when something is flagged.
-        hipLaunchKernelGGL(k_refine_list, dim3(1), dim3(1024), 0, h->stream, rf, pf.n_slots, h->counters.as<long long>());
         HIPCHK(hipGetLastError());
-        int head[2] = {0, 0};
+        int head[2] = {0, 0};  // (listed by k_finalize's last block)
         HIPCHK(hipMemcpyAsync(head, rf.head, sizeof(head), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         if (head[0] == 0) continue;
@@ -3620,9 +3625,7 @@ int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device,
             RETCHK(pf.replay_precompute(h));
             points_of = ip;
         }
-        hipLaunchKernelGGL(k_refine, dim3(kRefineBlocks), dim3(kRefineThreads), 0, h->stream, rf, pf.n_slots);
-        hipLaunchKernelGGL(k_refine_final, dim3(64), dim3(256), 0, h->stream, rf, pf.n_slots, f.out_index, pf.lag_begin,
-                           out_dev);
+        RETCHK(launch_refine(h, rf, pf.n_slots, f.out_index, pf.lag_begin, out_dev));
     }
     HIPCHK(hipGetLastError());
     if (!out_on_device && n_out > 0) {

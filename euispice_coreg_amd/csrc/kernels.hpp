@@ -2169,12 +2169,18 @@ struct RefineArgs {
     int* flags;           // [n_slots] 1: flagged by k_finalize
     double* slot_pivots;  // [2][n_slots] the lag-point's own means, relative to the global pivots
     int* list;            // [n_slots] flagged slots in slot order (k_refine_list)
-    int* head;            // [0] number of flagged slots, [1] chunks per slot (k_refine_list)
-    double* partial;      // [kRefineItems-bounded][kNumSums] partial sums of the work items
+    int* head;            // [0] number of flagged slots, [1] chunks per slot; [2], [3]: tickets of the two
+                          // "last block finishes the job" steps (k_finalize lists, k_refine finalises), zero between launches
+    double* partial;      // [max(kRefineItems, n_slots)][kNumSums] partial sums of the work items
+    const long long* out_index;  // (k_refine's last block writes the coefficients)
+    long long lag_begin;
+    double* out;
+    long long* refine_count;
 };
 constexpr double kRefineCond = 1e5;  // default threshold on sum xx / (n var) (one-pass error below it: < 1e-11)
-constexpr int kRefineBlocks = 2048;  // grid of k_refine; also the number of work items a sweep with few flagged lag-points is cut in
-constexpr int kRefineThreads = 256;
+constexpr int kRefineBlocks = 512;    // grid of k_refine (an empty launch -- the normal case -- costs its dispatch: ~5 us)
+constexpr int kRefineThreads = 1024;
+constexpr int kRefineItems = 1024;    // a sweep with few flagged lag-points is cut in about this many work items
 constexpr int kRefineMaxChunks = 64;
 
 struct FinalizeArgs {
@@ -2200,6 +2206,43 @@ constexpr int kFinLanes = 16;  // threads per lag slot in k_finalize
 constexpr int kFinSlots = 16;  // lag slots per block: 256-thread blocks, 16 of them per 256-lag batch -- a sweep of two
                                // batches (one GPU's share of the headline at N = 8) still spreads over 32 CUs
 constexpr int kFinThreads = kFinSlots * kFinLanes;
+
+// flagged slots in slot order (ONE block of kFinThreads threads: deterministic), their number, and the number of chunks each
+// one's walk over the tile list is cut in: few flagged lag-points -> many chunks each, so that the re-evaluation still
+// fills the chip
+__device__ void refine_list_block(const RefineArgs& r, long long n_slots, long long* refine_count) {
+    __shared__ int wave_n[kFinThreads / 64];
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long s0 = 0; s0 < n_slots; s0 += kFinThreads) {
+        const long long slot = s0 + threadIdx.x;
+        const int f = slot < n_slots ? ((volatile const int*)r.flags)[slot] : 0;
+        const unsigned long long m = __ballot(f != 0);
+        if (lane == 0) wave_n[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_n[w];
+        if (f) r.list[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)slot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < kFinThreads / 64; ++w) t += wave_n[w];
+            base += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int n = base;
+        r.head[0] = n;
+        int chunks = n > 0 ? kRefineItems / n : 1;
+        chunks = chunks < 1 ? 1 : (chunks > kRefineMaxChunks ? kRefineMaxChunks : chunks);
+        r.head[1] = chunks;
+        r.head[2] = 0;  // the ticket, for the next launch
+        if (refine_count && n > 0) atomicAdd((unsigned long long*)refine_count, (unsigned long long)n);
+    }
+}
 
 __global__ void __launch_bounds__(kFinThreads) k_finalize(const FinalizeArgs a) {
     // kFinLanes threads per slot each add every kFinLanes-th slab, then one adds them in order
@@ -2257,41 +2300,17 @@ __global__ void __launch_bounds__(kFinThreads) k_finalize(const FinalizeArgs a) 
         }
         if (a.refine.enabled) a.refine.flags[slot] = flag;
     }
-}
-
-// flagged slots in slot order (one block; deterministic), their number, and the number of chunks each one's walk over
-// the tile list is cut in: few flagged lag-points -> many chunks each, so that the re-evaluation still fills the chip
-__global__ void __launch_bounds__(1024) k_refine_list(const RefineArgs r, long long n_slots, long long* refine_count) {
-    __shared__ int wave_n[16];
-    __shared__ int base;
-    if (threadIdx.x == 0) base = 0;
+    if (!a.refine.enabled) return;  // (uniform)
+    // the block that finishes last lists the flagged slots (no launch of its own: nothing is flagged in an ordinary sweep
+    // and this costs a few microseconds inside one block)
+    __shared__ int s_last;
+    __threadfence();
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (long long s0 = 0; s0 < n_slots; s0 += 1024) {
-        const long long slot = s0 + threadIdx.x;
-        const int f = slot < n_slots ? r.flags[slot] : 0;
-        const unsigned long long m = __ballot(f != 0);
-        if (lane == 0) wave_n[wave] = __popcll(m);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += wave_n[w];
-        if (f) r.list[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)slot;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int t = 0;
-            for (int w = 0; w < 16; ++w) t += wave_n[w];
-            base += t;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const int n = base;
-        r.head[0] = n;
-        int chunks = n > 0 ? kRefineBlocks / n : 1;
-        chunks = chunks < 1 ? 1 : (chunks > kRefineMaxChunks ? kRefineMaxChunks : chunks);
-        r.head[1] = chunks;
-        if (refine_count && n > 0) atomicAdd((unsigned long long*)refine_count, (unsigned long long)n);
-    }
+    if (threadIdx.x == 0) s_last = atomicAdd((unsigned int*)a.refine.head + 2, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    refine_list_block(a.refine, a.n_slots, a.refine_count);
 }
 
 // one work item = (flagged lag-point, chunk of the tile list): six sums about the lag-point's own pivots over the chunk's
@@ -2369,7 +2388,9 @@ __device__ void refine_mode(const RefineArgs& r, long long n_slots, int slot, in
 }
 __global__ void __launch_bounds__(kRefineThreads) k_refine(const RefineArgs r, long long n_slots) {
     __shared__ double sh[1][kRefineThreads];
+    __shared__ int s_last;
     const int n = r.head[0], n_chunks = r.head[1];  // (uniform; every wave leaves when there is nothing flagged)
+    if (n == 0) return;
     const long long items = (long long)n * n_chunks;
     for (long long w = blockIdx.x; w < items; w += gridDim.x) {
         const int slot = r.list[w / n_chunks], chunk = (int)(w % n_chunks);
@@ -2377,17 +2398,20 @@ __global__ void __launch_bounds__(kRefineThreads) k_refine(const RefineArgs r, l
         if (r.small_f32) refine_mode<float>(r, n_slots, slot, chunk, n_chunks, out6, sh);
         else refine_mode<double>(r, n_slots, slot, chunk, n_chunks, out6, sh);
     }
-}
-// the chunks of a flagged lag-point added in chunk order, then the corrected two-pass coefficient
-__global__ void __launch_bounds__(256) k_refine_final(const RefineArgs r, long long n_slots, const long long* out_index,
-                                                      long long lag_begin, double* out) {
-    const int n = r.head[0], n_chunks = r.head[1];
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    // the block that finishes last adds the chunks of every flagged lag-point in chunk order and writes the corrected
+    // two-pass coefficient
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd((unsigned int*)r.head + 3, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int e = threadIdx.x; e < n; e += kRefineThreads) {
         double s[kNumSums];
 #pragma unroll
         for (int k = 0; k < kNumSums; ++k) s[k] = 0.0;
         for (int c = 0; c < n_chunks; ++c) {
-            const double* p = r.partial + ((size_t)e * n_chunks + c) * kNumSums;
+            const volatile double* p = r.partial + ((size_t)e * n_chunks + c) * kNumSums;
 #pragma unroll
             for (int k = 0; k < kNumSums; ++k) s[k] += p[k];
         }
@@ -2400,8 +2424,9 @@ __global__ void __launch_bounds__(256) k_refine_final(const RefineArgs r, long l
             const double vb = s[4] - s[2] * s[2] / cnt;
             res = cov / sqrt(va * vb);
         }
-        out[out_index[slot] - lag_begin] = res;
+        r.out[r.out_index[slot] - r.lag_begin] = res;
     }
+    if (threadIdx.x == 0) r.head[3] = 0;  // the ticket, for the next launch
 }
 
 }  // namespace coreg
