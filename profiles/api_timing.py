@@ -138,9 +138,8 @@ def main():
         t.append(1e3 * (time.perf_counter() - t0))
     out["align_without_fit_ms"] = min(t)
     print(json.dumps(out))
-    for p in (p_small, p_small2, p_large):
-        os.remove(p)
-    os.rmdir(d)
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -27,21 +27,29 @@ def raster(tmp_path_factory):
     return p_spice, paths, frames, h4, d
 
 
+def _reference_run():
+    """What the REFERENCE's own SPICEComposedMapBuilder.process did with the same raster geometry and imager sequence
+    (tests/golden/make_golden_callers.py -> callers_golden.json): the imager frame it took for every raster column and
+    the 2-D header it composed.  (the expectation below used to be built from this package's own
+    `spice_header.column_times` / `celestial_header`.)"""
+    from tests.test_reference_callers_cpu import load
+    _, m = load()
+    c = m["synras"]["cases"]["process"]
+    return c["frame_of_column"], c["header"]
+
+
 def _expected(h4, frames, target):
-    """Literal per-column construction (map_builder.py:95-131) on the CPU."""
-    from euispice_coreg_amd.utils import spice_header as S
+    """Literal per-column construction (map_builder.py:95-131) on the CPU: the oracle's TAN WCS + scipy, the column ->
+    frame choice and the target header taken from the reference's own run."""
     from oracle import coreg_oracle as O
-    col_s, t_ref = S.column_times(h4)
-    dates = [S.parse_date(h["DATE-AVG"]) for _, h in frames]
+    frame_of_column, _ = _reference_run()
     ny, nx = target["NAXIS2"], target["NAXIS1"]
-    if len(col_s) != nx:
-        col_s = np.interp(np.arange(0, h4["NAXIS1"], h4["NAXIS1"] / nx)[:nx], np.arange(h4["NAXIS1"]), col_s)
+    assert len(frame_of_column) == nx
     wt = O.TanWCS(target)
     out = np.empty((ny, nx))
     chosen = []
     for ii in range(nx):
-        t = t_ref + dt.timedelta(seconds=float(col_s[ii]))
-        k = int(np.argmin([abs((t - d).total_seconds()) for d in dates]))
+        k = int(frame_of_column[ii])
         chosen.append(k)
         img, hi = frames[k]
         hi = dict(hi)
@@ -63,7 +71,12 @@ def test_spice_composed_map_matches_column_by_column_construction(raster, tmp_pa
                      return_synras_name=True)
     assert name == os.path.join(str(tmp_path), "synras.fits") == C.get_path_to_composed_map()
     data, hdr = fits_io.read_image(name, 0)
-    target = dict(S.celestial_header(h4), NAXIS1=h4["NAXIS1"], NAXIS2=h4["NAXIS2"])
+    # the target WCS: the cards the reference composed for the same raster (CRVAL / CDELT / PC / CRPIX in degrees)
+    ref_hdr = _reference_run()[1]
+    target = {k: ref_hdr[k] for k in ("CRPIX1", "CRPIX2", "CRVAL1", "CRVAL2", "CDELT1", "CDELT2", "PC1_1", "PC1_2", "PC2_1",
+                                      "PC2_2", "CUNIT1", "CUNIT2", "CTYPE1", "CTYPE2")}
+    target.update(NAXIS1=h4["NAXIS1"], NAXIS2=h4["NAXIS2"], LONPOLE=ref_hdr.get("LONPOLE", 180.0))
+    assert target == {**dict(S.celestial_header(h4)), **target}  # (and this package's flattening agrees with it)
     want, chosen = _expected(h4, frames, target)
     assert len(set(chosen)) >= 4  # the raster spans several imager frames
     assert data.shape == want.shape
