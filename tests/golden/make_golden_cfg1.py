@@ -35,7 +35,25 @@ def lags_baseline():
     return (np.arange(-5, 6, 1.0), np.arange(-5, 6, 1.0), None, None, None)
 
 
+def fingerprint(small32, large32):
+    return np.array([np.nansum(small32.astype(np.float64)), np.nansum(large32.astype(np.float64)),
+                     float(np.isnan(small32).sum()), float(small32[200, 300]), float(large32[700, 500])])
+
+
+def dump_scene(path):
+    """The scene as a BITPIX = -32 FITS pair holds it, for make_golden_cfg1_reference.py (the reference's own run)."""
+    import json
+    small, hs, large, hl, truth = scene()
+    s32, l32 = small.astype(np.float32), large.astype(np.float32)
+    np.savez(path, small=s32, large=l32, hdr_small=np.array(json.dumps(hs)), hdr_large=np.array(json.dumps(hl)),
+             fingerprint=fingerprint(s32, l32))
+    print("wrote", path)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--dump-scene":
+        dump_scene(sys.argv[2])
+        sys.exit(0)
     small, hs, large, hl, truth = scene()
     lg = lags(truth)
     serial = H.oracle_helio(small, hs, large, hl, lg, parallelism=False, counts=os.cpu_count())

@@ -113,3 +113,26 @@ def test_alignment_results_end_to_end(name, fits_dir, tmp_path):
     data, h2 = fits_io.read_image(out, -1)
     assert np.array_equal(data, G.scene(c["scene"])[0], equal_nan=True)
     assert h2["CRVAL1"] == hdr["CRVAL1"] and h2["PC1_2"] == hdr["PC1_2"]
+
+
+def test_cfg1_at_its_stated_size_against_the_references_own_run(gpu_handle):
+    """BASELINE.json configs[0] -- 512^2 small-FOV image against a 1024^2 large-FOV image, helioprojective, lag_crval1/2 in
+    [-5, 5] step 1, parallelism=False -- as the reference itself ran it (tests/golden/make_golden_cfg1_reference.py), the
+    same window through its parallel branch (the zero lag included: 2044 border pixels decided by wcslib's noise), the
+    window centred on the injected shift, and the Carrington frame: the HIP path against all six reference maps."""
+    import os
+    from tests import helpers as H
+    from tests.conftest import GOLDEN
+    from tests.golden import make_golden_cfg1 as C
+    ref = np.load(os.path.join(GOLDEN, "cfg1_reference.npz"))
+    small, hs, large, hl, truth = C.scene()
+    assert np.array_equal(C.fingerprint(small.astype(np.float32), large.astype(np.float32)), ref["fingerprint"])
+    for suffix, lags in (("0", C.lags_baseline()), ("", C.lags(truth))):
+        got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, serial_semantics=True)
+        H.assert_corr_close(got, ref["serial" + suffix], 1e-7, "cfg1 serial branch vs the reference" + suffix)
+        got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags)
+        H.assert_corr_close(got, ref["parallel" + suffix], 1e-7, "cfg1 parallel branch vs the reference" + suffix)
+        got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, (512, 512), (228.0, 262.0), (-12.0, 22.0))
+        H.assert_corr_close(got, ref["carrington" + suffix], 1e-10, "cfg1 Carrington frame vs the reference" + suffix)
+    am = np.unravel_index(np.nanargmax(ref["serial"]), ref["serial"].shape)
+    assert (C.lags(truth)[0][am[0]], C.lags(truth)[1][am[1]]) == (17.0, -9.0)  # the reference finds the injected shift

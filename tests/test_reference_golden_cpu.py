@@ -169,3 +169,23 @@ def test_wcslib_car_restatement_is_bit_exact():
             assert (lon, lat, rx, ry) == (g[n + "/lon"][k], g[n + "/lat"][k], g[n + "/rx"][k], g[n + "/ry"][k]), (n, k)
         n_dropped += int(((g[n + "/rx"] < 0) | (g[n + "/ry"] < 0)).sum())
     assert n_dropped > 300  # the noise does decide: hundreds of border pixels come back below 0
+
+
+def test_cfg1_oracle_golden_equals_the_references_own_run():
+    """BASELINE.json configs[0] (512^2 against 1024^2, helioprojective, lags [-5, 5], parallelism=False) as the REFERENCE
+    ran it in the build container (tests/golden/make_golden_cfg1_reference.py -> cfg1_reference.npz), next to the
+    committed oracle output for the same seeded scene (cfg1_corr.npz): Carrington maps bit-equal, helioprojective maps to
+    the float32-rounding level (5 700 overlapping samples in the serial semantics: one flipped rounding is worth 2e-10),
+    same argmax -- all six maps (both lag windows, serial / parallel branch, Carrington frame)."""
+    import os
+    from tests.conftest import GOLDEN
+    from tests.golden import make_golden_cfg1 as C
+    ora = np.load(os.path.join(GOLDEN, "cfg1_corr.npz"))
+    ref = np.load(os.path.join(GOLDEN, "cfg1_reference.npz"))
+    small, hs, large, hl, _ = C.scene()
+    assert np.array_equal(C.fingerprint(small.astype(np.float32), large.astype(np.float32)), ref["fingerprint"])
+    for k, tol in (("carrington0", 0.0), ("carrington", 0.0), ("serial0", 5e-10), ("serial", 5e-10), ("parallel0", 1e-10),
+                   ("parallel", 1e-10)):
+        assert np.array_equal(np.isnan(ora[k]), np.isnan(ref[k])), k
+        assert np.nanmax(np.abs(ora[k] - ref[k])) <= tol, (k, np.nanmax(np.abs(ora[k] - ref[k])))
+        assert np.nanargmax(ora[k]) == np.nanargmax(ref[k]), k
