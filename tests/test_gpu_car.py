@@ -132,6 +132,48 @@ def test_fuzz_car(gpu_handle, seed):
     H.assert_corr_close(got, want, 1e-7, f"fuzz CAR seed={seed}")
 
 
+@pytest.mark.parametrize("seed", list(range(500, 512)))
+def test_fuzz_initial_carrington_sub_map_semantics_with_the_identity_lag(gpu_handle, seed):
+    """Random pairs of Carrington maps through the semantics `align_using_initial_carrington` really has (round 5: the
+    sub-map of alignment.py:987-1016 in both branches -- reference map resampled once on the grid of the map to align by
+    `coreg_prepare_reference_helioprojective` with two CAR headers, every lag on that grid), lag axes THROUGH exactly
+    zero: the identity lag-point is swept with the exact identity map and wcslib's CAR chain decides its border pixels
+    (and, for order 1, the tap set of every pixel).  Rolls, unequal / negative pixel sizes, both hemispheres, explicit
+    LONPOLE, NaN pixels, both spline orders; against the oracle's frame "initial_carrington"."""
+    from euispice_coreg_amd import _lib, synthetic
+    from oracle import coreg_oracle as O
+    rng = np.random.default_rng(seed)
+    ny, nx = int(rng.integers(40, 90)), int(rng.integers(40, 90))
+    cd = (0.0101 * rng.uniform(0.8, 1.3) * rng.choice([1.0, -1.0]), 0.0099 * rng.uniform(0.8, 1.3))
+    small, hs, large, hl, _ = synthetic.make_car_scene(small_shape=(ny, nx), large_shape=(int(ny * 1.5), int(nx * 1.6)),
+                                                       seed=seed, small_cdelt=(abs(cd[0]), cd[1]),
+                                                       crota=float(rng.choice([0.0, 0.4, -2.5])),
+                                                       nan_frac=float(rng.choice([0.0, 0.01])),
+                                                       explicit_lonpole=bool(rng.integers(0, 2)))
+    hs = dict(hs)
+    if cd[0] < 0:
+        hs["CDELT1"] = cd[0]
+        lam, rho = hs["CDELT2"] / hs["CDELT1"], np.deg2rad(hs["CROTA"])
+        hs["PC1_2"], hs["PC2_1"] = float(-lam * np.sin(rho)), float(np.sin(rho) / lam)
+    off = float(rng.choice([0.0, 9.0, -21.0]))
+    if "LONPOLE" in hl:
+        off = abs(off) + 0.5  # an explicit LONPOLE = 0 is only valid north of the equator
+    hs["CRVAL2"] += off
+    hl = dict(hl, CRVAL2=hl["CRVAL2"] + off)
+    l1 = np.unique(np.concatenate([[0.0], np.round(rng.uniform(-0.03, 0.03, int(rng.integers(1, 4))), 4)]))
+    l2 = np.unique(np.concatenate([[0.0], np.round(rng.uniform(0.0, 0.03, int(rng.integers(1, 3))), 4)]))
+    lags = (l1, l2, None, None, [0.0] if rng.integers(0, 2) else [0.0, 0.3])
+    order = int(rng.choice([1, 2]))
+    ls = _lib.LagSet(*lags)
+    gpu_handle.set_small(small)
+    gpu_handle.prepare_reference_helioprojective(large, hl, hs, order)
+    got = gpu_handle.sweep_helioprojective(hs, hs, ls, order=order).reshape(ls.shape + (1,))
+    st = H.oracle_state(small.astype(np.float64), hs, large.astype(np.float64), hl, lags, order=order, unit_lag="deg")
+    want = O.find_best_header_parameters(st, "initial_carrington", use_ang2pipi=False)
+    assert np.isfinite(want).any()
+    H.assert_corr_close(got, want, 1e-7, f"CAR sub-map fuzz seed={seed} order={order}")
+
+
 def test_car_invalid_target_header_is_an_error(gpu_handle):
     from euispice_coreg_amd import _lib, synthetic
     small, hs, large, hl, _ = synthetic.make_car_scene(explicit_lonpole=True, small_shape=(40, 40), large_shape=(60, 60))
