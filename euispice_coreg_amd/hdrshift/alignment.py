@@ -332,10 +332,12 @@ class Alignment:
         on_device = (remove_fov_limits is None) and (fov_limits is None)
         n_finite = None
         if on_device:
-            # thresholds applied to the resident copy (self.data_small is left as loaded).  The upload is handed to the
-            # library's upload thread (option "async_upload": staging copies + DMA on a stream of their own) and this
-            # thread goes on to prepare the reference image; the threshold pass -- the first reader of the pixels -- is
-            # issued after that (`finite_pixels`, below).  self.data_small is not modified until then.
+            # thresholds applied to the resident copy (self.data_small is left as loaded).  The upload runs on the handle's
+            # upload stream; the threshold pass -- the first reader of the pixels -- is issued after the reference
+            # preparation (`finite_pixels`, below), which therefore does not wait for the image's DMA.
+            # COREG_ASYNC_UPLOAD=1 also hands the staging copies to the library's upload thread (option "async_upload";
+            # measured +-0.03 ms on the headline call -- the DMA already overlaps the preparation -- hence off by default).
+            # self.data_small is not modified until the sweep has returned.
             # (only when a reference preparation follows -- nothing to overlap with when the prepared reference is still
             # resident, and the hand-over to the thread then costs more than it saves: profiles/r05_api_timing*.json)
             will_prepare = True
@@ -344,7 +346,7 @@ class Alignment:
                 tag0 = self._reference_tag("carrington", self.lonlims, self.latlims, self.shape, sr0)
                 will_prepare = tag0 is None or tag0 != getattr(h, "reference_tag", None)
             use_async = (will_prepare and not use_all and not spread
-                         and os.environ.get("COREG_ASYNC_UPLOAD", "1") != "0")
+                         and os.environ.get("COREG_ASYNC_UPLOAD", "0") == "1")
             if use_async:
                 h.set_option("async_upload", 1)
             try:

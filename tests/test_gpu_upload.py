@@ -397,3 +397,50 @@ def test_compressed_tiles_of_any_size_decode_on_the_gpu(gpu_handle, tmp_path, ti
     rb = gpu_handle.resample_helioprojective(hdr, hdr, order=1, dtype=np.float64)
     m = np.isfinite(rb)
     assert m.mean() > 0.8 and np.abs(rb[m] - host.astype(np.float64)[m]).max() <= 1e-9
+
+
+def test_upload_stream_and_upload_thread_give_the_same_map(gpu_handle):
+    """Round 5: the image to align goes up on the handle's upload stream (option "overlap_upload", default on) and,
+    opt-in, through the handle's upload THREAD ("async_upload": the call returns once the upload is queued; the pixel
+    buffer must outlive the next reader).  Same maps as the one-stream hand-over -- float32 arrays, raw BITPIX = -32 data
+    units -- also when a new image replaces one that an earlier sweep has just read, and when the reference preparation
+    sits between the upload and the sweep."""
+    import tempfile, os
+    from euispice_coreg_amd import _lib
+    from euispice_coreg_amd.utils import fits_io
+    small, hs, large, hl, _ = H.scene(small_n=160, large_n=224)
+    s32 = small.astype(np.float32)
+    other = (small * 1.03 + 2.0).astype(np.float32)
+    grid = _lib.Grid(H.CARR_LON, H.CARR_LAT, (96, 80))
+    ls = _lib.LagSet(17.0 + 2.0 * (np.arange(9) - 4), -9.0 + 2.0 * (np.arange(8) - 4), None, None, None)
+    d = tempfile.mkdtemp(prefix="coreg_async_")
+    p = os.path.join(d, "s.fits")
+    fits_io.write_images(p, [(None, {}), (other, hs)])
+    raw = fits_io.open_raw(p, -1)
+
+    def call(img):
+        gpu_handle.set_small(img)
+        gpu_handle.prepare_reference_carrington(large, hl, grid, 1.004, 2)
+        return gpu_handle.sweep_carrington(hs, grid, 1.004, ls)
+
+    try:
+        gpu_handle.set_option("overlap_upload", 0)
+        want = [call(s32), call(other)]
+        gpu_handle.set_option("overlap_upload", 1)
+        for async_upload in (0, 1):
+            gpu_handle.set_option("async_upload", async_upload)
+            for _ in range(3):
+                assert np.array_equal(call(s32), want[0], equal_nan=True)
+                assert np.array_equal(call(other), want[1], equal_nan=True)
+                assert np.array_equal(call(raw), want[1], equal_nan=True)
+            # readers other than the sweep join too: threshold, pivots, synchronize
+            gpu_handle.set_small(s32)
+            assert gpu_handle.threshold_small(None, None) == int(np.isfinite(s32).sum())
+            gpu_handle.set_small(other)
+            assert np.isfinite(gpu_handle.get_pivots()).all()
+            gpu_handle.set_small(s32)
+            gpu_handle.synchronize()
+    finally:
+        gpu_handle.set_option("async_upload", 0)
+        gpu_handle.set_option("overlap_upload", 1)
+        raw.close()
