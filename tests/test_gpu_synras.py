@@ -76,7 +76,8 @@ def test_spice_composed_map_matches_column_by_column_construction(raster, tmp_pa
     target = {k: ref_hdr[k] for k in ("CRPIX1", "CRPIX2", "CRVAL1", "CRVAL2", "CDELT1", "CDELT2", "PC1_1", "PC1_2", "PC2_1",
                                       "PC2_2", "CUNIT1", "CUNIT2", "CTYPE1", "CTYPE2")}
     target.update(NAXIS1=h4["NAXIS1"], NAXIS2=h4["NAXIS2"], LONPOLE=ref_hdr.get("LONPOLE", 180.0))
-    assert target == {**dict(S.celestial_header(h4)), **target}  # (and this package's flattening agrees with it)
+    flat = dict(S.celestial_header(h4))  # (and this package's flattening agrees with it, card for card)
+    assert all(flat[k] == v for k, v in target.items() if not k.startswith("NAXIS")), target
     want, chosen = _expected(h4, frames, target)
     assert len(set(chosen)) >= 4  # the raster spans several imager frames
     assert data.shape == want.shape
