@@ -1263,15 +1263,16 @@ int fill_refine(coreg_handle* h, RefineArgs* r, int mode, int order, const doubl
     return COREG_OK;
 }
 
-// after a k_finalize that has written the flags and (its last block) listed the flagged slots: re-evaluate them and
-// overwrite their coefficients (the last block of k_refine).  ONE launch, no host round trip; with nothing flagged (the
-// normal case) every block leaves at once.
+// after a k_finalize that has written the flags: list the flagged slots (one block), re-evaluate them and overwrite their
+// coefficients (the last block of k_refine).  Two launches, no host round trip; with nothing flagged (the normal case)
+// every block leaves at once.
 int launch_refine(coreg_handle* h, const RefineArgs& r0, long long n_slots, const long long* outidx_dev,
-                  long long lag_begin, double* out_dev) {
+                  long long lag_begin, double* out_dev, bool list = true) {
     RefineArgs r = r0;
     r.out_index = outidx_dev;
     r.lag_begin = lag_begin;
     r.out = out_dev;
+    if (list) hipLaunchKernelGGL(k_refine_list, dim3(1), dim3(kListThreads), 0, h->stream, r, n_slots, h->counters.as<long long>());
     hipLaunchKernelGGL(k_refine, dim3(kRefineBlocks), dim3(kRefineThreads), 0, h->stream, r, n_slots);
     HIPCHK(hipGetLastError());
     return COREG_OK;
@@ -3616,8 +3617,9 @@ int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device,
         // share) with the same kernels in the same order -- identical coefficients on every rank, and equal to the
         // single-GPU sweep's, without a second collective.  The compacted points of a launch that was not the sweep's
         // last have been overwritten by the later launches: computed again, only when something is flagged.
+        hipLaunchKernelGGL(k_refine_list, dim3(1), dim3(kListThreads), 0, h->stream, rf, pf.n_slots, h->counters.as<long long>());
         HIPCHK(hipGetLastError());
-        int head[2] = {0, 0};  // (listed by k_finalize's last block)
+        int head[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(head, rf.head, sizeof(head), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         if (head[0] == 0) continue;
@@ -3625,7 +3627,7 @@ int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device,
             RETCHK(pf.replay_precompute(h));
             points_of = ip;
         }
-        RETCHK(launch_refine(h, rf, pf.n_slots, f.out_index, pf.lag_begin, out_dev));
+        RETCHK(launch_refine(h, rf, pf.n_slots, f.out_index, pf.lag_begin, out_dev, false));
     }
     HIPCHK(hipGetLastError());
     if (!out_on_device && n_out > 0) {

@@ -2169,8 +2169,8 @@ struct RefineArgs {
     int* flags;           // [n_slots] 1: flagged by k_finalize
     double* slot_pivots;  // [2][n_slots] the lag-point's own means, relative to the global pivots
     int* list;            // [n_slots] flagged slots in slot order (k_refine_list)
-    int* head;            // [0] number of flagged slots, [1] chunks per slot; [2], [3]: tickets of the two
-                          // "last block finishes the job" steps (k_finalize lists, k_refine finalises), zero between launches
+    int* head;            // [0] number of flagged slots, [1] chunks per slot (k_refine_list); [3]: ticket of k_refine's
+                          // "the block that finishes last writes the coefficients" step, zero between launches
     double* partial;      // [max(kRefineItems, n_slots)][kNumSums] partial sums of the work items
     const long long* out_index;  // (k_refine's last block writes the coefficients)
     long long lag_begin;
@@ -2178,9 +2178,11 @@ struct RefineArgs {
     long long* refine_count;
 };
 constexpr double kRefineCond = 1e5;  // default threshold on sum xx / (n var) (one-pass error below it: < 1e-11)
-constexpr int kRefineBlocks = 512;    // grid of k_refine (an empty launch -- the normal case -- costs its dispatch: ~5 us)
-constexpr int kRefineThreads = 1024;
-constexpr int kRefineItems = 1024;    // a sweep with few flagged lag-points is cut in about this many work items
+// k_refine's grid.  An EMPTY launch -- the normal case -- costs the dispatch of its waves (18 us for 2048 blocks, 7 us
+// for 512), and the all-flagged headline sweep (3600 lag-points) takes the same 26-28 ms on either: 512.
+constexpr int kRefineBlocks = 512;
+constexpr int kRefineThreads = 256;
+constexpr int kRefineItems = 2048;    // a sweep with few flagged lag-points is cut in about this many work items
 constexpr int kRefineMaxChunks = 64;
 
 struct FinalizeArgs {
@@ -2207,31 +2209,42 @@ constexpr int kFinSlots = 16;  // lag slots per block: 256-thread blocks, 16 of 
                                // batches (one GPU's share of the headline at N = 8) still spreads over 32 CUs
 constexpr int kFinThreads = kFinSlots * kFinLanes;
 
-// flagged slots in slot order (ONE block of kFinThreads threads: deterministic), their number, and the number of chunks each
+// flagged slots in slot order (ONE block of kListThreads threads: deterministic), their number, and the number of chunks each
 // one's walk over the tile list is cut in: few flagged lag-points -> many chunks each, so that the re-evaluation still
 // fills the chip
+constexpr int kListThreads = 1024;
 __device__ void refine_list_block(const RefineArgs& r, long long n_slots, long long* refine_count) {
-    __shared__ int wave_n[kFinThreads / 64];
+    __shared__ int wave_n[kListThreads / 64];
     __shared__ int base;
     if (threadIdx.x == 0) base = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (long long s0 = 0; s0 < n_slots; s0 += kFinThreads) {
-        const long long slot = s0 + threadIdx.x;
-        const int f = slot < n_slots ? ((volatile const int*)r.flags)[slot] : 0;
-        const unsigned long long m = __ballot(f != 0);
-        if (lane == 0) wave_n[wave] = __popcll(m);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += wave_n[w];
-        if (f) r.list[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)slot;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int t = 0;
-            for (int w = 0; w < kFinThreads / 64; ++w) t += wave_n[w];
-            base += t;
+    constexpr int kPre = 4;   // flags fetched ahead per thread: the loads (other XCDs wrote them) overlap instead of queueing
+    for (long long c0 = 0; c0 < n_slots; c0 += (long long)kPre * kListThreads) {
+        int f[kPre];
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const long long slot = c0 + (long long)q * kListThreads + threadIdx.x;
+            f[q] = slot < n_slots ? ((volatile const int*)r.flags)[slot] : 0;
         }
-        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const long long s0 = c0 + (long long)q * kListThreads;
+            if (s0 >= n_slots) break;  // (uniform)
+            const unsigned long long m = __ballot(f[q] != 0);
+            if (lane == 0) wave_n[wave] = __popcll(m);
+            __syncthreads();
+            int off = base;
+            for (int w = 0; w < wave; ++w) off += wave_n[w];
+            if (f[q]) r.list[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)(s0 + threadIdx.x);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int t = 0;
+                for (int w = 0; w < kListThreads / 64; ++w) t += wave_n[w];
+                base += t;
+            }
+            __syncthreads();
+        }
     }
     if (threadIdx.x == 0) {
         const int n = base;
@@ -2300,17 +2313,11 @@ __global__ void __launch_bounds__(kFinThreads) k_finalize(const FinalizeArgs a) 
         }
         if (a.refine.enabled) a.refine.flags[slot] = flag;
     }
-    if (!a.refine.enabled) return;  // (uniform)
-    // the block that finishes last lists the flagged slots (no launch of its own: nothing is flagged in an ordinary sweep
-    // and this costs a few microseconds inside one block)
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd((unsigned int*)a.refine.head + 2, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    refine_list_block(a.refine, a.n_slots, a.refine_count);
+}
+// (Listing the flagged slots by "the block of k_finalize that finishes last" was tried and is SLOWER than this one-block
+// kernel: the device-scope fence it needs writes the XCD's L2 back -- k_finalize 10 -> 34 us on the headline.)
+__global__ void __launch_bounds__(kListThreads) k_refine_list(const RefineArgs r, long long n_slots, long long* refine_count) {
+    refine_list_block(r, n_slots, refine_count);
 }
 
 // one work item = (flagged lag-point, chunk of the tile list): six sums about the lag-point's own pivots over the chunk's
