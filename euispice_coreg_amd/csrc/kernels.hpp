@@ -2147,7 +2147,7 @@ __global__ void __launch_bounds__(256) k_tap_fix(const TapFixArgs a) {
 // inside a flat region -- the subtraction  sum xx - (sum x)^2 / n  cancels (relative error eps * sum xx / (n var)).
 // k_finalize notices (both quotients are at hand), FLAGS such a lag-point and leaves its own two means -- which the
 // one-pass sums do give accurately -- as the lag-point's private pivots.  Round 5: every flagged lag-point is then
-// re-evaluated, by kernels of their own (k_refine_list -> k_refine -> k_refine_final), with sums centred on THOSE pivots
+// re-evaluated, by kernels of their own (k_refine_list -> k_refine, whose last block finalises), with sums centred on THOSE pivots
 // and the corrected two-pass formula  cov = S_ab - S_a S_b / n  (the residual S_a, S_b of an approximate mean cancel to
 // first order: the result has the accuracy of c_correlate.py:39-72's means-first evaluation).  One pass over the
 // compacted points per flagged lag-point, spread over (lag-point x chunk of the tile list) work items in a fixed order:
