@@ -191,6 +191,11 @@ def main():
     run_case("carr_cdelt1_serial", "A", A_, dict(cd, parallelism=False), "carrington", carr)
     run_case("helio_cdelt2_raises", "A", A_, dict(cd, lag_cdelt1=[0.0], lag_cdelt2=[0.0, 0.05], parallelism=False),
              "helioprojective")
+    # the same lag set through the parallel branch: the worker that meets the first d_cdelt2 != 0 dies and its whole
+    # np.array_split chunk -- valid lag-points behind it included -- keeps the initial 0.0 (quirk Q9)
+    run_case("helio_cdelt2_parallel_zeros", "A", A_, dict(cd, lag_cdelt1=[0.0], lag_cdelt2=[0.0, 0.05], parallelism=True,
+                                                          counts_cpu_max=3), "helioprojective",
+             note="quirk Q9: failed workers leave zeros")
     # thresholds + order 1
     th = dict(lag_crval1=l1[1:6], lag_crval2=l2[1:5], lag_cdelt1=None, lag_cdelt2=None, lag_crota=[0.3],
               small_fov_value_min=150.0, small_fov_value_max=900.0, reprojection_order=1)

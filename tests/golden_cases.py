@@ -19,11 +19,17 @@ def load():
     return _cache["g"], _cache["m"]
 
 
+# the reference returns a map there, but not one anybody should reproduce: dead workers leave their chunks at 0.0 (Q9)
+ZEROS_LEFT_BY_DEAD_WORKERS = {"helio_cdelt2_parallel_zeros"}
+
+
 def case_names(kind=None):
     """kind: 'corr' (a map was returned), 'raises', 'results' (AlignmentResults surface), None = all."""
     _, m = load()
     out = []
     for name, c in sorted(m["cases"].items()):
+        if name in ZEROS_LEFT_BY_DEAD_WORKERS:
+            continue
         k = "raises" if "raises" in c else ("results" if "shift_arcsec" in c else "corr")
         if kind is None or k == kind:
             out.append(name)

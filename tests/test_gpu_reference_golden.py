@@ -73,6 +73,20 @@ def test_second_solar_r_is_a_documented_deviation(fits_dir):
     assert np.nanmax(np.abs(got[..., 1] - got[..., 0])) > 1e-6  # a different radius, a different map
 
 
+def test_dead_workers_zeros_are_a_documented_deviation(fits_dir):
+    """Quirk Q9: where the reference's parallel branch returns 0.0 for every lag-point of a chunk whose worker died
+    (a d_cdelt2 != 0 lag-point: alignment.py:440), this package evaluates what can be evaluated and marks the rest NaN."""
+    want, c = G.expected("helio_cdelt2_parallel_zeros")
+    assert np.all(want == 0.0)
+    with _nowarn():
+        _, got = G.product_replay("helio_cdelt2_parallel_zeros", fits_dir)
+    k = c["ctor"]["lag_cdelt2"].index(0.0)
+    assert np.isfinite(got[:, :, :, k]).all() and np.isnan(np.delete(got, k, axis=3)).all()
+    # ... and those values are the ones the reference gives when no worker dies (same lags, serial branch up to the raise
+    # is not comparable; the d_cdelt2 = 0 slice of the parallel semantics is the case without CDELT2 lags)
+    assert np.nanmax(np.abs(got[:, :, :, k])) < 1.0
+
+
 @pytest.mark.parametrize("name", G.case_names("raises"))
 def test_raises_where_the_reference_raises(name, fits_dir):
     c = G.load()[1]["cases"][name]

@@ -32,7 +32,7 @@ TOL = {
 
 def test_fixture_is_what_the_generator_describes():
     g, m = G.load()
-    assert m["interpreter"]["astropy"] == "4.3.1" and len(G.case_names("corr")) >= 28
+    assert m["interpreter"]["astropy"] == "4.3.1" and len(G.case_names("corr")) >= 28 and len(m["cases"]) == 39
     assert len(G.case_names("raises")) >= 5 and len(G.case_names("results")) == 3
     for name in G.case_names("corr"):
         assert list(g[f"case/{name}/corr"].shape) == m["cases"][name]["shape"]
@@ -91,6 +91,18 @@ def test_quirk_q2_cdelt1_lags_are_no_ops_in_the_reference():
     assert np.array_equal(want[:, :, 0], want[:, :, 1]) and np.array_equal(want[:, :, 2], want[:, :, 1])
     want, _ = G.expected("helio_cdelt1_serial")  # helioprojective: the lag still rebuilds PC from CROTA (quirk Q3)
     assert np.array_equal(want[:, :, 0], want[:, :, 2])
+
+
+def test_quirk_q9_dead_workers_leave_zeros_in_the_reference():
+    """Parallel branch, a lag set with d_cdelt2 != 0: every np.array_split chunk meets such a lag-point, its worker dies
+    with the AttributeError of alignment.py:440 BEFORE it writes anything (alignment.py:502-506 runs at the end of the
+    chunk), and the reference returns its zero-initialised map (:635-639) -- 0.0 even where d_cdelt2 == 0.  The serial
+    branch raises instead (case helio_cdelt2_raises).  This package: NaN on the lag-points that cannot be evaluated, the
+    value everywhere else (tests/test_gpu_reference_golden.py)."""
+    want, c = G.expected("helio_cdelt2_parallel_zeros")
+    assert want.shape == (3, 3, 1, 2, 1, 1) and np.all(want == 0.0)
+    with pytest.raises(AttributeError):
+        G.oracle_replay("helio_cdelt2_parallel_zeros")
 
 
 def test_quirk_q10_second_solar_r_is_nan_in_the_reference():
