@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -250,6 +251,17 @@ int fail(coreg_handle* h, int code, const std::string& msg) {
         if (_r != COREG_OK) return _r; \
     } while (0)
 
+// COREG_TRACE=1: host-side timestamps (microseconds since the first one) of the hand-over's stages on stderr
+inline void trace(const char* what) {
+    static const bool on = [] {
+        const char* e = std::getenv("COREG_TRACE");
+        return e && std::atoi(e) == 1;
+    }();
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    std::fprintf(stderr, "[coreg %9.1f us] %s\n", us, what);
+}
 int bind_device_nowait(coreg_handle* h) {
     HIPCHK(hipSetDevice(h->device));
     return COREG_OK;
@@ -260,6 +272,7 @@ int bind_device_nowait(coreg_handle* h) {
 // make the handle's stream wait for it
 int join_small(coreg_handle* h) {
     if (!h->small_pending) return COREG_OK;
+    trace("join_small: waiting for the upload thread");
     hipError_t worker_rc = hipSuccess;
     {
         std::unique_lock<std::mutex> lk(h->up_m);
@@ -271,6 +284,7 @@ int join_small(coreg_handle* h) {
     if (worker_rc != hipSuccess)
         return fail(h, COREG_EHIP, std::string("asynchronous upload of the image to align: ") + hipGetErrorString(worker_rc));
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_small, 0));
+    trace("join_small: joined");
     return COREG_OK;
 }
 int bind_device(coreg_handle* h) {
@@ -539,6 +553,7 @@ int staged_upload(coreg_handle* h, void* dev, const void* host, size_t bytes, hi
 // the same on the handle's upload thread: staging and events of its own, plain HIP error codes (h->err belongs to the
 // calling thread), then the byte swap of a BITPIX = -32 data unit and the pivot of the image, all on stream `s`
 hipError_t upload_small_worker(coreg_handle* h, void* dev, const void* host, size_t n_elem, bool swap32, hipStream_t s) {
+    trace("worker: upload begins");
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return e;
     const size_t bytes = n_elem * 4;
@@ -565,7 +580,9 @@ hipError_t upload_small_worker(coreg_handle* h, void* dev, const void* host, siz
     hipLaunchKernelGGL(k_mean_final, dim3(1), dim3(64), 0, s, h->red_sum_up.as<double>(), h->red_cnt_up.as<long long>(), 256,
                        h->pivots.as<double>() + 1);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    return hipEventRecord(h->ev_small, s);
+    e = hipEventRecord(h->ev_small, s);
+    trace("worker: upload issued");
+    return e;
 }
 
 // A float64 image (host: staged upload; device: the caller's buffer) is kept as float32 on the device when every finite
@@ -1321,6 +1338,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
 
     const dim3 grid((unsigned)((long long)g_per * n_batches)), block(kSweepThreads);
     RETCHK(join_small(h));  // the first kernel of the call that reads the image to align
+    trace("launch_sweep: launching k_sweep");
     EventPair* ev = next_event(h, h->ev_sweep, h->ev_sweep_used);
     if (!ev) return fail(h, COREG_EHIP, "hipEventCreate failed");
 #define SWP(M, O, TS, R, Q, P)                                                                                       \
@@ -1949,7 +1967,9 @@ int end_sweep(coreg_handle* h, long long n_out, double* corr_out, int out_on_dev
         HIPCHK(hipMemcpyAsync(corr_out, out_dev, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     h->stats_pending = true;  // (timings and the kept-point count are gathered when coreg_last_stats asks: collect_stats)
     // host output: the values must be there on return; device output: the sweep stays stream-ordered work
+    trace("end_sweep: everything issued");
     if (!out_on_device) HIPCHK(hipStreamSynchronize(h->stream));
+    trace("end_sweep: map on the host");
     return COREG_OK;
 }
 
@@ -2219,6 +2239,7 @@ int coreg_set_small(coreg_handle* h, const double* img, int32_t ny, int32_t nx) 
 int coreg_set_small_f32(coreg_handle* h, const float* img, int32_t ny, int32_t nx) {
     if (!h) return COREG_EINVAL;
     if (!img || ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "set_small_f32: bad image");
+    trace("set_small_f32: enter");
     RETCHK(bind_device(h));
     const size_t n = (size_t)ny * nx;
     HIPCHK(h->small.reserve(n * sizeof(float)));
@@ -2233,6 +2254,7 @@ int coreg_set_small_f32(coreg_handle* h, const float* img, int32_t ny, int32_t n
         void* dev = h->small.p;
         post_upload(h, [h, dev, img, n, s] { return upload_small_worker(h, dev, img, n, false, s); });
         h->small_pending = true;  // (join_small: waits for the worker to have issued everything, then for ev_small)
+        trace("set_small_f32: handed to the upload thread");
         return COREG_OK;
     }
     RETCHK(staged_upload(h, h->small.p, img, n * sizeof(float), s));
@@ -2240,6 +2262,7 @@ int coreg_set_small_f32(coreg_handle* h, const float* img, int32_t ny, int32_t n
     h->sW = nx;
     h->sH = ny;
     RETCHK(device_mean<float>(h, h->small.as<float>(), (long long)n, h->pivots.as<double>() + 1, s));
+    trace("set_small_f32: issued");
     return end_small_upload(h, s);
 }
 
@@ -2606,6 +2629,7 @@ static int prepare_carrington(coreg_handle* h, const void* large, const PixFmt& 
     if (!h) return COREG_EINVAL;
     if (!large || !hdr || !grid || ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
     RETCHK(check_order(h, order));
+    trace("prepare_carrington: enter");
     RETCHK(bind_device_nowait(h));  // (touches neither the image to align nor its pivot: no join with the upload stream)
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -2618,6 +2642,7 @@ static int prepare_carrington(coreg_handle* h, const void* large, const PixFmt& 
     a.gh = grid->n_lat;
     CropRect crop = {0, 0, nx, ny};
     if (kind == SRC_HOST) RETCHK(reference_crop(h, MODE_TRANSLATE, a, order, &crop));
+    trace("prepare_carrington: crop box known");
     bool f32;
     const void* img_dev = nullptr;
     RETCHK(upload_reference_source(h, large, (size_t)ny * nx, fmt, &f32, kind, &img_dev, nx, &crop));
@@ -2630,6 +2655,7 @@ static int prepare_carrington(coreg_handle* h, const void* large, const PixFmt& 
     h->gH = a.gh;
     h->ref_dtype = COREG_F64;
     RETCHK(ref_pivot(h));
+    trace("prepare_carrington: issued");
     // no host sync: the pinned staging is guarded by staged_upload's own wait, everything else is stream-ordered
     return COREG_OK;  // tmp_img stays allocated: the next preparation re-uses it (hipFree would stall the device)
 }
@@ -2850,6 +2876,7 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
                            int64_t lag_end, double* corr_out, int out_on_device) {
     if (!h) return COREG_EINVAL;
     const ComboRange combo = take_combo_range(h);
+    trace("sweep_carrington: enter");
     if (!hdr_small || !grid) return fail(h, COREG_EINVAL, "sweep_carrington: null header/grid");
     if (method != COREG_METHOD_CORRELATION && method != COREG_METHOD_RESIDUS)
         return fail(h, COREG_ENOTIMPL, "method must be COREG_METHOD_CORRELATION or COREG_METHOD_RESIDUS");
