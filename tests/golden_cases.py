@@ -1,6 +1,7 @@
 """The reference-run fixtures (tests/golden/alignment_golden.{npz,json}, produced by tests/golden/make_golden_alignment.py
-from the reference's own `Alignment`) and the two ways the tests replay a case: through the oracle (CPU) and through the
-product's drop-in `Alignment` on FITS files (GPU)."""
+from the reference's own `Alignment`; `fixture="alignment_fuzz_golden"`: the seeded random family of
+make_golden_alignment_fuzz.py, same layout) and the two ways the tests replay a case: through the oracle (CPU) and
+through the product's drop-in `Alignment` on FITS files (GPU)."""
 import json
 import os
 
@@ -11,21 +12,24 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _cache = {}
 
 
-def load():
-    if "g" not in _cache:
-        _cache["g"] = np.load(os.path.join(GOLDEN, "alignment_golden.npz"))
-        with open(os.path.join(GOLDEN, "alignment_golden.json")) as f:
-            _cache["m"] = json.load(f)
-    return _cache["g"], _cache["m"]
+DEFAULT = "alignment_golden"
+
+
+def load(fixture=DEFAULT):
+    if fixture not in _cache:
+        g = np.load(os.path.join(GOLDEN, fixture + ".npz"))
+        with open(os.path.join(GOLDEN, fixture + ".json")) as f:
+            _cache[fixture] = (g, json.load(f))
+    return _cache[fixture]
 
 
 # the reference returns a map there, but not one anybody should reproduce: dead workers leave their chunks at 0.0 (Q9)
 ZEROS_LEFT_BY_DEAD_WORKERS = {"helio_cdelt2_parallel_zeros"}
 
 
-def case_names(kind=None):
+def case_names(kind=None, fixture=DEFAULT):
     """kind: 'corr' (a map was returned), 'raises', 'results' (AlignmentResults surface), None = all."""
-    _, m = load()
+    _, m = load(fixture)
     out = []
     for name, c in sorted(m["cases"].items()):
         if name in ZEROS_LEFT_BY_DEAD_WORKERS:
@@ -36,15 +40,15 @@ def case_names(kind=None):
     return out
 
 
-def scene(name):
+def scene(name, fixture=DEFAULT):
     """(small float32, hdr_small, large float32, hdr_large) exactly as the reference read them from its FITS files."""
-    g, m = load()
+    g, m = load(fixture)
     sc = m["scenes"][name]
     return g[f"scene/{name}/small"], dict(sc["hdr_small"]), g[f"scene/{name}/large"], dict(sc["hdr_large"])
 
 
-def expected(name):
-    g, m = load()
+def expected(name, fixture=DEFAULT):
+    g, m = load(fixture)
     return g[f"case/{name}/corr"], m["cases"][name]
 
 
@@ -56,12 +60,12 @@ def _deg(lims, unit):
     return [[v * f for v in lims[0]], [v * f for v in lims[1]]]
 
 
-def oracle_replay(name, counts=None, hdr_small=None):
+def oracle_replay(name, counts=None, hdr_small=None, fixture=DEFAULT):
     """The case through oracle/coreg_oracle.py, configured as the REFERENCE behaves (cdelt_semantics='reference',
     failed lag-points left as the reference leaves them).  Returns the 6-D map or raises what the oracle raises."""
     from oracle import coreg_oracle as O
-    _, c = expected(name) if f"case/{name}/corr" in load()[0].files else (None, load()[1]["cases"][name])
-    small, hs, large, hl = scene(c["scene"])
+    c = load(fixture)[1]["cases"][name]
+    small, hs, large, hl = scene(c["scene"], fixture)
     if hdr_small is not None:
         hs = dict(hdr_small)
     ctor, call, ck = c["ctor"], c["call"], dict(c.get("call_kwargs") or {})
@@ -103,11 +107,11 @@ def oracle_replay(name, counts=None, hdr_small=None):
         counts=counts, use_ang2pipi=(call != "initial_carrington"), reference_quirks=True)
 
 
-def write_scene_fits(tmpdir, scene_name):
+def write_scene_fits(tmpdir, scene_name, fixture=DEFAULT):
     """The scene as FITS files written by THIS package's writer (no astropy on the GPU box): empty primary + float32
     image extension, the layout the generator used."""
     from euispice_coreg_amd.utils import fits_io
-    small, hs, large, hl = scene(scene_name)
+    small, hs, large, hl = scene(scene_name, fixture)
     ps, pl = os.path.join(str(tmpdir), scene_name + "_small.fits"), os.path.join(str(tmpdir), scene_name + "_large.fits")
     if not os.path.isfile(ps):
         fits_io.write_images(ps, [(None, {}), (small, hs)])
@@ -115,12 +119,12 @@ def write_scene_fits(tmpdir, scene_name):
     return ps, pl
 
 
-def product_replay(name, tmpdir, return_type="corr", **extra):
+def product_replay(name, tmpdir, return_type="corr", fixture=DEFAULT, **extra):
     """The case through euispice_coreg_amd.hdrshift.Alignment (FITS in), configured to reproduce the reference
     (cdelt_semantics='reference')."""
     from euispice_coreg_amd.hdrshift import Alignment
-    c = load()[1]["cases"][name]
-    ps, pl = write_scene_fits(tmpdir, c["scene"])
+    c = load(fixture)[1]["cases"][name]
+    ps, pl = write_scene_fits(tmpdir, c["scene"], fixture)
     ctor = dict(c["ctor"])
     for k in ("lag_crval1", "lag_crval2", "lag_cdelt1", "lag_cdelt2", "lag_crota", "lag_solar_r"):
         if ctor.get(k) is not None:
