@@ -208,6 +208,24 @@ def main_threads(args):
     os.dup2(2, 1)
 
 
+def reference_run_points(np, small, large, corr):
+    """89 entries of the headline map as the REFERENCE ITSELF computed them in the build container (its own
+    Alignment.align_using_carrington on a sub-lattice of the lags: tests/golden/make_golden_headline_reference.py ->
+    tests/golden/headline_reference.npz, data only).  None when this run's scene is not the fixture's (--nan-frac,
+    --small-f64): the fingerprint of the pixels decides."""
+    path = os.path.join(ROOT, "tests", "golden", "headline_reference.npz")
+    if not os.path.isfile(path):
+        return None
+    r = np.load(path)
+    fp = np.array([np.nansum(small), np.nansum(large), float(np.isnan(small).sum()), small[1000, 1000], large[1500, 1500]])
+    if not np.array_equal(fp, r["fingerprint"]):
+        return None
+    d = np.abs(corr.ravel()[r["index"]] - r["corr"])
+    return {"max_abs_dcorr": float(np.max(d)), "n": int(r["index"].size),
+            "argmax_equal": bool(int(r["index"][np.argmax(r["corr"])]) == int(np.nanargmax(corr))),
+            "what": "entries of this map computed by the reference's own Alignment in the build container"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -679,6 +697,8 @@ def main():
                                                                           np.nanargmax(corr_cpu.ravel()[subset]))}
         else:
             out["cpu_baseline"] = None
+        if not dry:
+            out["parity_vs_reference_run"] = reference_run_points(np, small, large, corr)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

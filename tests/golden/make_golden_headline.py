@@ -44,5 +44,20 @@ def main():
     print("wrote", dst, "max", vals.max(), "at", idx[np.argmax(vals)])
 
 
+def dump_scene(path):
+    """The headline scene as a BITPIX = -32 FITS pair holds it, for make_golden_headline_reference.py (the reference's
+    own run of a sub-lattice of the 60 x 60 lags)."""
+    import json
+    small, hs, large, hl, truth = synthetic.make_scene()
+    s32, l32 = small.astype(np.float32), large.astype(np.float32)
+    assert np.array_equal(s32.astype(np.float64), small, equal_nan=True) and np.array_equal(l32.astype(np.float64), large)
+    np.savez(path, small=s32, large=l32, hdr_small=np.array(json.dumps(hs)), hdr_large=np.array(json.dumps(hl)),
+             fingerprint=fingerprint(small, large))
+    print("wrote", path)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--dump-scene":
+        dump_scene(sys.argv[2])
+        sys.exit(0)
     main()

@@ -170,6 +170,13 @@ def test_headline_60x60_map_against_the_oracle(gpu_handle, big_scene, small_f64)
     d = np.abs(full.ravel()[g["index"]] - g["corr"])
     print("headline map vs 256 committed oracle lag-points: max |dcorr|", d.max())
     assert d.max() <= 1e-10
+    # (i') 89 entries of this very map as the REFERENCE ITSELF computed them in the build container: its own
+    # Alignment.align_using_carrington on a sub-lattice of the lags (tests/golden/make_golden_headline_reference.py)
+    r = np.load(os.path.join(GOLDEN, "headline_reference.npz"))
+    assert np.array_equal(r["fingerprint"], g["fingerprint"])
+    dr = np.abs(full.ravel()[r["index"]] - r["corr"])
+    print("headline map vs 89 lag-points of the reference's own run: max |dcorr|", dr.max())
+    assert dr.max() <= 1e-10 and int(r["index"][np.argmax(r["corr"])]) == int(np.argmax(full))
     # (ii) 64 more, evaluated NOW by the oracle's process pool (alignment.py:667-744 restated) on this box's cores
     rng = np.random.default_rng(5)
     idx = np.sort(rng.choice(np.setdiff1d(np.arange(3600), g["index"]), size=64, replace=False))

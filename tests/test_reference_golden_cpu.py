@@ -201,3 +201,23 @@ def test_cfg1_oracle_golden_equals_the_references_own_run():
         assert np.array_equal(np.isnan(ora[k]), np.isnan(ref[k])), k
         assert np.nanmax(np.abs(ora[k] - ref[k])) <= tol, (k, np.nanmax(np.abs(ora[k] - ref[k])))
         assert np.nanargmax(ora[k]) == np.nanargmax(ref[k]), k
+
+
+def test_headline_oracle_lag_points_equal_the_references_own_run():
+    """The HEADLINE workload (2048^2 image against 3072^2, Carrington grid 2048^2, lags arange(-30, 30, 1)) as the
+    REFERENCE ran it in the build container on a sub-lattice of the lags (tests/golden/make_golden_headline_reference.py
+    -> headline_reference.npz: 8 x 8 spread over the map + 5 x 5 around the peak = 89 entries of the 60 x 60 map), next to
+    the committed oracle output for the same seeded scene (headline_sample.npz, 256 entries): the entries both hold are
+    bit-equal -- float64 throughout, as every Carrington case -- and the reference's own peak is the injected shift."""
+    import os
+    from tests.conftest import GOLDEN
+    ora = np.load(os.path.join(GOLDEN, "headline_sample.npz"))
+    ref = np.load(os.path.join(GOLDEN, "headline_reference.npz"))
+    assert np.array_equal(ora["fingerprint"], ref["fingerprint"])  # the same pixels went into both runs
+    assert ref["index"].size == 89 and np.isfinite(ref["corr"]).all()
+    common, ia, ib = np.intersect1d(ora["index"], ref["index"], return_indices=True)
+    assert common.size >= 4
+    assert np.array_equal(ora["corr"][ia], ref["corr"][ib])
+    lag = np.arange(-30.0, 30.0, 1.0)
+    k = int(ref["index"][np.argmax(ref["corr"])])
+    assert (lag[k // 60], lag[k % 60]) == (17.0, -9.0)
