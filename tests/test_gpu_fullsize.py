@@ -30,6 +30,32 @@ def carr_ready(gpu_handle, big_scene):
     return grid
 
 
+def _reference_run(name, small, large, cfg4=False):
+    """Entries of a config's full map as the REFERENCE ITSELF computed them in the build container, on a sub-lattice of
+    the config's lags (tests/golden/make_golden_configs_reference.py -> configs_reference.npz): (index [n, 3] into the
+    crval1 / crval2 / crota axes, coefficients).  The fingerprint says the regenerated scene holds the same pixels."""
+    import os
+    from tests.conftest import GOLDEN
+    from tests.golden.make_golden_configs_reference import cfg4_fingerprint
+    from tests.golden.make_golden_headline import fingerprint
+    r = np.load(os.path.join(GOLDEN, "configs_reference.npz"))
+    if cfg4:
+        assert np.array_equal(cfg4_fingerprint(np, small, large), r["fingerprint_cfg4"])
+    else:
+        assert np.array_equal(fingerprint(small, large), r["fingerprint_big"])
+    return r[name + "_index"], r[name + "_corr"]
+
+
+def _reference_headers(tag):
+    """The header cards as the reference read them from its FITS files (astropy 4.3.1 writes floats with 16 significant
+    digits: a header in degrees comes back an ulp away here and there)."""
+    import json
+    import os
+    from tests.conftest import GOLDEN
+    r = np.load(os.path.join(GOLDEN, "configs_reference.npz"))
+    return json.loads(str(r["hdr_small_" + tag])), json.loads(str(r["hdr_large_" + tag]))
+
+
 def _sweep(h, hs, grid, lags, **kw):
     from euispice_coreg_amd import _lib
     ls = _lib.LagSet(*lags)
@@ -292,6 +318,12 @@ def test_cfg2_helioprojective_61x61_full_size(gpu_handle, big_scene):
         want = O.step(st, "helioprojective", st.data_small, sub, d1, d2, 0.0, 0.0, 0.0, 1.004)
         got = full[int(d1) + 30, int(d2) + 30]
         assert abs(got - want) <= 1e-7, (d1, d2, got, want)
+    # 58 entries of this map from the reference's own run of the configuration (7 x 7 lattice, zero lag included, + 3 x 3
+    # around the peak)
+    idx, want = _reference_run("cfg2", small, large)
+    d = np.abs(full[idx[:, 0], idx[:, 1]] - want)
+    print("cfg2 map vs", want.size, "lag-points of the reference's own run: max |dcorr|", d.max())
+    assert d.max() <= 1e-7 and np.argmax(want) == np.argmax(full[idx[:, 0], idx[:, 1]])
     # slices of the raveled lag range concatenate to the full map
     n = ls.size
     parts = [gpu_handle.sweep_helioprojective(hs, hs, ls, lag_begin=a, lag_end=b) for a, b in
@@ -414,6 +446,10 @@ def test_cfg3_carrington_121x121_full_size(gpu_handle, big_scene, carr_ready):
     for i1, i2 in ((77, 51), (0, 120), (120, 3)):
         want = _spot(st, "carrington", ref, (l1[i1], l2[i2], 0.0, 0.0, 0.0))
         assert abs(full[i1, i2, 0, 0, 0] - want) <= 1e-10, (i1, i2)
+    idx, want = _reference_run("cfg3", small, large)  # 58 entries from the reference's own run of the configuration
+    d = np.abs(full[idx[:, 0], idx[:, 1], 0, 0, 0] - want)
+    print("cfg3 map vs", want.size, "lag-points of the reference's own run: max |dcorr|", d.max())
+    assert d.max() <= 1e-10
     one = _sweep(gpu_handle, hs, grid, ([-44.0], [52.0], [0.01], [-0.02], [0.3]))[0, 0, 0, 0, 0]
     assert abs(one - _spot(st, "carrington", ref, (-44.0, 52.0, 0.01, -0.02, 0.3))) <= 1e-10
     # LDS-window gather == global-memory gather on a strided lag subset; contiguous slices concatenate to the map
@@ -465,6 +501,11 @@ def test_cfg4_spice_like_61x61x21_full_size(gpu_handle):
     from oracle import coreg_oracle as O
     small, hs, large, hl, truth = synthetic.make_scene(small_shape=(832, 192), small_cdelt=(4.0, 1.098),
                                                        small_unit="deg", large_n=3072)
+    # the cards as a FITS file hands them over (the reference's run below read them from one): CRVAL2, CDELT, PC1_2, PC2_1
+    # of this header in degrees come back one ulp away -- which decides border pixels of the zero lag
+    hs_file, hl_file = _reference_headers("cfg4")
+    assert all(abs(hs_file[k] - hs[k]) <= 5e-16 * abs(hs[k]) for k in ("CRVAL1", "CRVAL2", "CDELT1", "CDELT2", "PC1_2", "PC2_1"))
+    hs, hl = dict(hs, **{k: hs_file[k] for k in hs if k in hs_file}), dict(hl, **{k: hl_file[k] for k in hl if k in hl_file})
     l1 = l2 = np.arange(-30, 31, 1.0) / 3600.0  # header units (alignment.py:819-837 converts arcsec lags)
     lr = np.round(np.arange(-10, 11) * 0.1, 10)
     lags = (l1, l2, None, None, lr)
@@ -478,6 +519,11 @@ def test_cfg4_spice_like_61x61x21_full_size(gpu_handle):
     for i1, i2, i5 in ((47, 21, 13), (0, 60, 0), (30, 30, 10), (58, 2, 20)):  # (30, 30, 10) is the zero lag
         want = _spot(st, "helioprojective", sub, (l1[i1], l2[i2], 0.0, 0.0, lr[i5]))
         assert abs(full[i1, i2, 0, 0, i5, 0] - want) <= 1e-7, (i1, i2, i5)
+    # 127 entries from the reference's own run (lags handed over in arcsec, converted by alignment.py:819-837)
+    idx, want = _reference_run("cfg4", small, large, cfg4=True)
+    d = np.abs(full[idx[:, 0], idx[:, 1], 0, 0, idx[:, 2], 0] - want)
+    print("cfg4 map vs", want.size, "lag-points of the reference's own run: max |dcorr|", d.max())
+    assert d.max() <= 1e-7
     one = H.gpu_helio(gpu_handle, small, hs, large, hl, ([l1[40]], [l2[9]], [2e-6], [-1e-6], [0.4]), prepare=False)
     assert abs(one.ravel()[0] - _spot(st, "helioprojective", sub, (l1[40], l2[9], 2e-6, -1e-6, 0.4))) <= 1e-7
     subl = (l1[::12], l2[::10], None, None, lr[::5])
@@ -521,6 +567,12 @@ def test_cfg5_five_d_sweep_4096_grid_full_size(gpu_handle, big_scene):
     for idx in ((37, 11, 2, 2, 8), (0, 40, 0, 4, 10), (20, 20, 3, 1, 0)):
         want = _spot(st, "carrington", ref, (l1[idx[0]], l2[idx[1]], lc[idx[2]], lc[idx[3]], lr[idx[4]]))
         assert abs(full[idx] - want) <= 1e-10, idx
+    # 27 entries of the d_cdelt1 = d_cdelt2 = 0 plane from the reference's own run on the 4096^2 grid (a d_cdelt2 != 0
+    # lag-point raises in the reference, quirk Q2: the rest of the 5-D map has the oracle only)
+    idx, want = _reference_run("cfg5", small, large)
+    d = np.abs(full[idx[:, 0], idx[:, 1], 2, 2, idx[:, 2]] - want)
+    print("cfg5 map vs", want.size, "lag-points of the reference's own run: max |dcorr|", d.max())
+    assert d.max() <= 1e-10
     subl = (l1[::8], l2[::10], lc[::2], lc[1::3], lr[::5])
     a = _sweep(gpu_handle, hs, grid, subl)
     gpu_handle.set_option("use_lds", 0)
