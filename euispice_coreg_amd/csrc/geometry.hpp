@@ -244,10 +244,13 @@ struct WcslibTan {
     bool unity;
     double e0, e1, e2, e3, e4;  // celprm euler: lng_p, 90 - lat_p, phi_p, cos(e1), sin(e1)
 
+    // wcstrig.c: abs((int)floor(v)) % 4 -- through fmod, so that an angle of 1e20 degrees in a header is not an
+    // out-of-range float -> int conversion (same value wherever wcslib's own cast is defined)
+    static int quadrant(double v) { return (int)std::fmod(std::fabs(std::floor(v)), 4.0); }
     static void sincosd(double a, double* s, double* c) {
 #pragma clang fp contract(off)
         if (std::fmod(a, 90.0) == 0.0) {
-            const int i = std::abs((int)std::floor(a / 90.0 + 0.5)) % 4;
+            const int i = quadrant(a / 90.0 + 0.5);
             switch (i) {
                 case 0: *s = 0.0; *c = 1.0; return;
                 case 1: *s = (a > 0.0) ? 1.0 : -1.0; *c = 0.0; return;
@@ -260,7 +263,7 @@ struct WcslibTan {
     static double cosd(double a) {
 #pragma clang fp contract(off)
         if (std::fmod(a, 90.0) == 0.0) {
-            const int i = std::abs((int)std::floor(a / 90.0 + 0.5)) % 4;
+            const int i = quadrant(a / 90.0 + 0.5);
             return i == 0 ? 1.0 : (i == 2 ? -1.0 : 0.0);
         }
         return std::cos(a * kPi / 180.0);
@@ -268,7 +271,7 @@ struct WcslibTan {
     static double sind(double a) {
 #pragma clang fp contract(off)
         if (std::fmod(a, 90.0) == 0.0) {
-            const int i = std::abs((int)std::floor(a / 90.0 - 0.5)) % 4;
+            const int i = quadrant(a / 90.0 - 0.5);
             return i == 0 ? 1.0 : (i == 2 ? -1.0 : 0.0);
         }
         return std::sin(a * kPi / 180.0);
