@@ -971,7 +971,23 @@ int check_lags(coreg_handle* h, const coreg_lags* l, LagDims* d, int64_t begin, 
     }
     if (begin < 0 || end > d->total() || begin > end)
         return fail(h, COREG_EINVAL, "lag_begin/lag_end outside [0, n_lags]");
+    const double* ax[5] = {l->crval1, l->crval2, l->cdelt1, l->cdelt2, l->crota};
+    const int32_t na[5] = {l->n_crval1, l->n_crval2, l->n_cdelt1, l->n_cdelt2, l->n_crota};
+    for (int k = 0; k < 5; ++k)
+        for (int32_t i = 0; i < na[k]; ++i)
+            if (!std::isfinite(ax[k][i])) return fail(h, COREG_EINVAL, "lags: a non-finite value");
     return COREG_OK;
+}
+
+// Headers / grids that cannot give finite pixel coordinates are refused before anything is planned or launched
+// (geometry.hpp wcs_problem: the reference would hand such a header to astropy, which raises, or return NaN everywhere).
+static int check_wcs(coreg_handle* h, const coreg_wcs2d* w, bool carrington_transform) {
+    const char* why = wcs_problem(*w, carrington_transform);
+    return why ? fail(h, COREG_EINVAL, why) : COREG_OK;
+}
+static int check_grid(coreg_handle* h, const coreg_carr_grid* g) {
+    const char* why = grid_problem(*g);
+    return why ? fail(h, COREG_EINVAL, why) : COREG_OK;
 }
 
 // Local pixel-space geometry of a sweep (host estimates; they steer the plan, never the results):
@@ -2629,6 +2645,9 @@ static int prepare_carrington(coreg_handle* h, const void* large, const PixFmt& 
     if (!h) return COREG_EINVAL;
     if (!large || !hdr || !grid || ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
     RETCHK(check_order(h, order));
+    RETCHK(check_wcs(h, hdr, true));
+    RETCHK(check_grid(h, grid));
+    if (!std::isfinite(solar_r) || !(solar_r > 0.0)) return fail(h, COREG_EINVAL, "solar_r must be positive");
     trace("prepare_carrington: enter");
     RETCHK(bind_device_nowait(h));  // (touches neither the image to align nor its pivot: no join with the upload stream)
     ResampleArgs a;
@@ -2681,6 +2700,8 @@ static int prepare_helioprojective(coreg_handle* h, const void* large, const Pix
     if (hdr_large->proj != hdr_small->proj || (hdr_small->proj != COREG_PROJ_TAN && hdr_small->proj != COREG_PROJ_CAR))
         return fail(h, COREG_ENOTIMPL, "prepare_reference_helioprojective: both headers TAN, or both CAR");
     RETCHK(check_order(h, order));
+    RETCHK(check_wcs(h, hdr_large, false));
+    RETCHK(check_wcs(h, hdr_small, false));
     RETCHK(bind_device_nowait(h));
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -2814,6 +2835,9 @@ int coreg_resample_carrington(coreg_handle* h, const coreg_wcs2d* hdr, const cor
     if (!hdr || !grid || !out) return fail(h, COREG_EINVAL, "resample_carrington: bad argument");
     if (!h->small.p) return fail(h, COREG_ESTATE, "coreg_set_small has not been called");
     RETCHK(check_order(h, order));
+    RETCHK(check_wcs(h, hdr, true));
+    RETCHK(check_grid(h, grid));
+    if (!std::isfinite(solar_r) || !(solar_r > 0.0)) return fail(h, COREG_EINVAL, "solar_r must be positive");
     RETCHK(bind_device(h));
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -2841,6 +2865,8 @@ static int resample_helio(coreg_handle* h, const coreg_wcs2d* hdr_target, const 
     if (!h->small.p) return fail(h, COREG_ESTATE, "coreg_set_small has not been called");
     if (hdr_target->naxis1 < 1 || hdr_target->naxis2 < 1) return fail(h, COREG_EINVAL, "hdr_target: NAXIS missing");
     RETCHK(check_order(h, order));
+    RETCHK(check_wcs(h, hdr_target, false));
+    RETCHK(check_wcs(h, hdr, false));
     RETCHK(bind_device(h));
     ResampleArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -2881,6 +2907,9 @@ int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const 
     if (method != COREG_METHOD_CORRELATION && method != COREG_METHOD_RESIDUS)
         return fail(h, COREG_ENOTIMPL, "method must be COREG_METHOD_CORRELATION or COREG_METHOD_RESIDUS");
     RETCHK(check_order(h, order));
+    RETCHK(check_wcs(h, hdr_small, true));
+    RETCHK(check_grid(h, grid));
+    if (!std::isfinite(solar_r) || !(solar_r > 0.0)) return fail(h, COREG_EINVAL, "solar_r must be positive");
     LagDims d;
     RETCHK(check_lags(h, lags, &d, lag_begin, lag_end, combo));
     RETCHK(bind_device_nowait(h));  // (the image to align is joined right before k_sweep: launch_sweep)
@@ -3289,6 +3318,8 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     if (method != COREG_METHOD_CORRELATION && method != COREG_METHOD_RESIDUS)
         return fail(h, COREG_ENOTIMPL, "method must be COREG_METHOD_CORRELATION or COREG_METHOD_RESIDUS");
     RETCHK(check_order(h, order));
+    RETCHK(check_wcs(h, hdr_target, false));
+    RETCHK(check_wcs(h, hdr_small, false));
     LagDims d;
     RETCHK(check_lags(h, lags, &d, lag_begin, lag_end, combo));
     RETCHK(bind_device_nowait(h));

@@ -77,7 +77,43 @@ inline int shift_header(const coreg_wcs2d& ref, double d_crval1, double d_crval2
         out->pc1_2 = -lam * std::sin(rho);
         out->pc2_1 = (1.0 / lam) * std::sin(rho);
     }
+    // a lag that leaves no header to evaluate (CDELT + d = 0, a non-finite card): the lag-point stays NaN, as one whose
+    // worker died in the reference (astropy refuses such a header)
+    if (!(out->cdelt1 != 0.0 && out->cdelt2 != 0.0) || !std::isfinite(out->cdelt1) || !std::isfinite(out->cdelt2) ||
+        !std::isfinite(out->crota) || (change_pcij && (!std::isfinite(out->pc1_2) || !std::isfinite(out->pc2_1))))
+        return 2;
     return 0;
+}
+
+// What the sweeps, resamplers and reference preparations refuse (COREG_EINVAL) before anything is planned or launched:
+// a header the arithmetic below cannot turn into finite pixel coordinates.  `carrington_transform`: the header feeds
+// utils/rectify.py's transform (CRPIX, CRVAL, CDELT, CROTA, DSUN_OBS, CRLN_OBS, CRLT_OBS; PCi_j ignored, quirk Q4);
+// otherwise it is a TAN or CAR WCS (PCi_j, unit, LONPOLE; LATPOLE and a CAR LONPOLE may be NaN = FITS default).
+inline const char* wcs_problem(const coreg_wcs2d& w, bool carrington_transform) {
+    const double core[] = {w.crpix1, w.crpix2, w.crval1, w.crval2, w.cdelt1, w.cdelt2, w.crota};
+    for (double v : core)
+        if (!std::isfinite(v)) return "a non-finite CRPIX / CRVAL / CDELT / CROTA card";
+    if (w.cdelt1 == 0.0 || w.cdelt2 == 0.0) return "CDELT1 or CDELT2 is zero";
+    if (carrington_transform) {
+        if (!std::isfinite(w.dsun_obs) || !(w.dsun_obs > 0.0)) return "DSUN_OBS must be a positive distance";
+        if (!std::isfinite(w.crln_obs) || !std::isfinite(w.crlt_obs)) return "a non-finite CRLN_OBS / CRLT_OBS card";
+        return nullptr;
+    }
+    const double pc[] = {w.pc1_1, w.pc1_2, w.pc2_1, w.pc2_2};
+    for (double v : pc)
+        if (!std::isfinite(v)) return "a non-finite PCi_j card";
+    if (!std::isfinite(w.unit_to_deg) || !(w.unit_to_deg > 0.0)) return "unit_to_deg must be positive";
+    const double det = w.pc1_1 * w.pc2_2 - w.pc1_2 * w.pc2_1;
+    if (!(det != 0.0) || !std::isfinite(det)) return "PCi_j is singular";
+    if (w.proj != COREG_PROJ_CAR && !std::isfinite(w.lonpole)) return "a non-finite LONPOLE card";
+    if (std::isinf(w.lonpole) || std::isinf(w.latpole)) return "an infinite LONPOLE / LATPOLE card";
+    return nullptr;
+}
+inline const char* grid_problem(const coreg_carr_grid& g) {
+    if (g.n_lon < 1 || g.n_lat < 1) return "Carrington grid: n_lon and n_lat must be at least 1";
+    if (!std::isfinite(g.lon0) || !std::isfinite(g.lon1) || !std::isfinite(g.lat0) || !std::isfinite(g.lat1))
+        return "Carrington grid: non-finite limits";
+    return nullptr;
 }
 
 // ---- TAN WCS as matrices ------------------------------------------------------------------------------

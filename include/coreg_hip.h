@@ -267,7 +267,14 @@ int coreg_resample_helioprojective_f64(coreg_handle* h, const coreg_wcs2d* hdr_t
  * sharding, alignment.py:677-687); corr_out receives lag_end - lag_begin float64 values
  * (host memory, or device memory when out_on_device != 0).  With a host buffer the call returns when the values are
  * there; with a device buffer it only enqueues the work on the handle's stream (coreg_set_stream) and returns:
- * anything ordered after it on that stream -- an RCCL all-gather, a copy -- sees the results. */
+ * anything ordered after it on that stream -- an RCCL all-gather, a copy -- sees the results.
+ * Headers, grids and lags that cannot give finite pixel coordinates -- a NaN / infinite CRPIX / CRVAL / CDELT / CROTA /
+ * PCi_j card, CDELT = 0, a singular PCi_j, unit_to_deg <= 0, a non-finite LONPOLE on a TAN header, DSUN_OBS <= 0 or a
+ * non-finite CRLN_OBS / CRLT_OBS (Carrington transform), a non-finite grid limit or lag, solar_r <= 0 -- are refused with
+ * COREG_EINVAL by every sweep, resample and reference preparation before anything is planned or launched (the reference
+ * hands such a header to astropy, which raises, or returns NaN everywhere).  A lag-point whose OWN shifted header
+ * degenerates (CDELT + d_cdelt = 0) stays NaN, like one whose worker dies in the reference (coreg_shift_header
+ * returns 2 for it). */
 int coreg_sweep_carrington(coreg_handle* h, const coreg_wcs2d* hdr_small, const coreg_carr_grid* grid,
                            double solar_r, const coreg_lags* lags, int order, int method, int cdelt_semantics,
                            int64_t lag_begin, int64_t lag_end, double* corr_out, int out_on_device);
@@ -365,7 +372,8 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value);
 /* Host-only helpers (no GPU work; usable where no device exists): the header arithmetic the sweep applies per
  * lag-point, exported so that it can be checked against the reference's on CPU.
  *   coreg_shift_header      alignment.py:401-468 (_shift_header); returns 1 when COREG_CDELT_REFERENCE would kill
- *                           the worker (d_cdelt2 != 0), else 0
+ *                           the worker (d_cdelt2 != 0), 2 when the shifted header has CDELT = 0 or a non-finite
+ *                           CDELT / CROTA / PCi_j (no header left to evaluate), else 0
  *   coreg_homography        0-based pixels of `from` -> 0-based pixels of `to` through the sky, row-major 3x3 with
  *                           h[8] = 1: WCS(to).world_to_pixel(WCS(from).pixel_to_world(p)), alignment.py:1041-1065
  *   coreg_lag_homography    the map the helioprojective sweep gives lag-point idx = (i_crval1, i_crval2, i_cdelt1,

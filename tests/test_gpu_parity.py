@@ -313,6 +313,54 @@ def test_errors_are_loud(gpu_handle):
         h2.close()
 
 
+def test_headers_that_cannot_give_pixel_coordinates_are_refused_before_any_launch(gpu_handle):
+    """A NaN / infinite card, CDELT = 0, a singular PCi_j, a non-positive DSUN_OBS or solar radius, a non-finite lag or
+    grid limit: COREG_EINVAL from every entry point that plans kernels from a header (the reference hands such a header to
+    astropy, which raises, or returns NaN everywhere) -- and the handle keeps working afterwards.  A lag that makes
+    CDELT + d_cdelt zero leaves its own lag-points NaN and nothing else."""
+    from euispice_coreg_amd import _lib
+    small, hs, large, hl, _ = H.scene(small_n=48, large_n=64)
+    h2 = _lib.CoregHandle(0)
+    one = _lib.LagSet([0.0, 2.0], [0.0], None, None, None)
+    grid = _lib.Grid((228.0, 262.0), (-12.0, 22.0), (40, 40))
+    try:
+        h2.set_small(small)
+        h2.prepare_reference_helioprojective(large, hl, hs, 2)
+        good = h2.sweep_helioprojective(hs, hs, one)
+        bad_headers = [dict(hs, CDELT1=0.0), dict(hs, CDELT2=float("nan")), dict(hs, CRVAL1=float("inf")),
+                       dict(hs, PC1_1=0.0, PC1_2=0.0), dict(hs, CRPIX2=float("nan")), dict(hs, PC2_1=float("nan"))]
+        for bad in bad_headers:
+            with pytest.raises(_lib.CoregError):
+                h2.sweep_helioprojective(hs, bad, one)
+            with pytest.raises(_lib.CoregError):
+                h2.sweep_helioprojective(bad, hs, one)
+            with pytest.raises(_lib.CoregError):
+                h2.prepare_reference_helioprojective(large, bad, hs, 2)
+            with pytest.raises(_lib.CoregError):
+                h2.resample_helioprojective(hs, bad, 2)
+        with pytest.raises(_lib.CoregError):
+            h2.sweep_helioprojective(hs, hs, _lib.LagSet([0.0, float("nan")], [0.0], None, None, None))
+        assert np.array_equal(h2.sweep_helioprojective(hs, hs, one), good)  # the handle is as it was
+        h2.prepare_reference_carrington(large, hl, grid, 1.004, 2)
+        goodc = h2.sweep_carrington(hs, grid, 1.004, one)
+        for bad in (dict(hs, DSUN_OBS=0.0), dict(hs, CRLN_OBS=float("nan")), dict(hs, CDELT1=0.0), dict(hs, CROTA=float("inf"))):
+            with pytest.raises(_lib.CoregError):
+                h2.sweep_carrington(bad, grid, 1.004, one)
+            with pytest.raises(_lib.CoregError):
+                h2.prepare_reference_carrington(large, bad, grid, 1.004, 2)
+        with pytest.raises(_lib.CoregError):
+            h2.sweep_carrington(hs, grid, 0.0, one)
+        with pytest.raises(_lib.CoregError):
+            h2.sweep_carrington(hs, _lib.Grid((228.0, float("nan")), (-12.0, 22.0), (40, 40)), 1.004, one)
+        assert np.array_equal(h2.sweep_carrington(hs, grid, 1.004, one), goodc)
+        # a CDELT1 lag of exactly -CDELT1 (intended semantics): that slice NaN, the others as without it
+        lc = [-hs["CDELT1"], 0.0]
+        got = h2.sweep_carrington(hs, grid, 1.004, _lib.LagSet([0.0, 2.0], [0.0], lc, None, None)).reshape(2, 1, 2)
+        assert np.isnan(got[:, :, 0]).all() and np.array_equal(got[:, 0, 1], goodc.ravel())
+    finally:
+        h2.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def test_cfg1_against_committed_golden(gpu_handle):
     """BASELINE.json configs[0] (512^2 vs 1024^2, 11 x 11 CRVAL lags): GPU sweeps against the committed oracle

@@ -82,6 +82,19 @@ def test_shift_header_reference_cdelt_semantics(lib):
     assert rc == 1  # the reference's worker dies (alignment.py:440)
 
 
+def test_shift_header_says_when_a_lag_leaves_no_header_to_evaluate(lib):
+    """CDELT + d_cdelt = 0 (or a non-finite lag): return code 2 -- the sweeps leave such lag-points NaN, as they leave
+    those whose worker dies in the reference (astropy refuses a header with CDELT = 0)."""
+    st = _state()
+    cd1, cd2 = st.hdr_small["CDELT1"], st.hdr_small["CDELT2"]
+    assert lib.shift_header(st.hdr_small, 0.0, 0.0, -cd1, 0.0, 0.0)[0] == 2
+    assert lib.shift_header(st.hdr_small, 0.0, 0.0, 0.0, -cd2, 0.3)[0] == 2
+    assert lib.shift_header(st.hdr_small, 0.0, 0.0, 0.0, 0.0, float("nan"))[0] == 2
+    assert lib.shift_header(st.hdr_small, 0.0, 0.0, -0.5 * cd1, 0.0, 0.0)[0] == 0
+    # reference semantics never write d_cdelt1 into the header: nothing degenerates
+    assert lib.shift_header(st.hdr_small, 0.0, 0.0, -cd1, 0.0, 0.0, cdelt_semantics=lib.CDELT_REFERENCE)[0] == 0
+
+
 @pytest.mark.parametrize("d", [(24.0, 6.0, 0.0, 0.0, 0.75), (-30.0, 30.0, 0.0, 0.0, 0.0), (5.0, -5.0, 0.01, -0.02, -1.0)])
 def test_homography_matches_oracle_tan(lib, d):
     """coreg_homography(hdr_target -> shifted hdr) reproduces the per-pixel spherical-trig route
