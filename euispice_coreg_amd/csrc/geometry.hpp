@@ -94,15 +94,23 @@ inline const char* wcs_problem(const coreg_wcs2d& w, bool carrington_transform) 
     for (double v : core)
         if (!std::isfinite(v)) return "a non-finite CRPIX / CRVAL / CDELT / CROTA card";
     if (w.cdelt1 == 0.0 || w.cdelt2 == 0.0) return "CDELT1 or CDELT2 is zero";
+    // (finite but absurd cards overflow to Inf, then Inf - Inf, a few products later: same refusal)
+    for (double v : core)
+        if (std::fabs(v) > 1e12) return "a CRPIX / CRVAL / CDELT / CROTA card beyond 1e12 in magnitude";
+    if (std::fabs(w.cdelt1) < 1e-30 || std::fabs(w.cdelt2) < 1e-30) return "CDELT1 or CDELT2 below 1e-30 in magnitude";
     if (carrington_transform) {
-        if (!std::isfinite(w.dsun_obs) || !(w.dsun_obs > 0.0)) return "DSUN_OBS must be a positive distance";
+        if (!std::isfinite(w.dsun_obs) || !(w.dsun_obs > 0.0) || w.dsun_obs > 1e18)
+            return "DSUN_OBS must be a positive distance (metres, below 1e18)";
         if (!std::isfinite(w.crln_obs) || !std::isfinite(w.crlt_obs)) return "a non-finite CRLN_OBS / CRLT_OBS card";
         return nullptr;
     }
     const double pc[] = {w.pc1_1, w.pc1_2, w.pc2_1, w.pc2_2};
     for (double v : pc)
         if (!std::isfinite(v)) return "a non-finite PCi_j card";
-    if (!std::isfinite(w.unit_to_deg) || !(w.unit_to_deg > 0.0)) return "unit_to_deg must be positive";
+    for (double v : pc)
+        if (std::fabs(v) > 1e12) return "a PCi_j card beyond 1e12 in magnitude";
+    if (!std::isfinite(w.unit_to_deg) || !(w.unit_to_deg > 0.0) || w.unit_to_deg > 1e6)
+        return "unit_to_deg must be positive (and at most 1e6)";
     const double det = w.pc1_1 * w.pc2_2 - w.pc1_2 * w.pc2_1;
     if (!(det != 0.0) || !std::isfinite(det)) return "PCi_j is singular";
     if (w.proj != COREG_PROJ_CAR && !std::isfinite(w.lonpole)) return "a non-finite LONPOLE card";
@@ -111,8 +119,9 @@ inline const char* wcs_problem(const coreg_wcs2d& w, bool carrington_transform) 
 }
 inline const char* grid_problem(const coreg_carr_grid& g) {
     if (g.n_lon < 1 || g.n_lat < 1) return "Carrington grid: n_lon and n_lat must be at least 1";
-    if (!std::isfinite(g.lon0) || !std::isfinite(g.lon1) || !std::isfinite(g.lat0) || !std::isfinite(g.lat1))
-        return "Carrington grid: non-finite limits";
+    if (!std::isfinite(g.lon0) || !std::isfinite(g.lon1) || !std::isfinite(g.lat0) || !std::isfinite(g.lat1) ||
+        std::fabs(g.lon0) > 1e6 || std::fabs(g.lon1) > 1e6 || std::fabs(g.lat0) > 1e6 || std::fabs(g.lat1) > 1e6)
+        return "Carrington grid: non-finite (or absurd) limits";
     return nullptr;
 }
 

@@ -269,7 +269,7 @@ int coreg_resample_helioprojective_f64(coreg_handle* h, const coreg_wcs2d* hdr_t
  * there; with a device buffer it only enqueues the work on the handle's stream (coreg_set_stream) and returns:
  * anything ordered after it on that stream -- an RCCL all-gather, a copy -- sees the results.
  * Headers, grids and lags that cannot give finite pixel coordinates -- a NaN / infinite CRPIX / CRVAL / CDELT / CROTA /
- * PCi_j card, CDELT = 0, a singular PCi_j, unit_to_deg <= 0, a non-finite LONPOLE on a TAN header, DSUN_OBS <= 0 or a
+ * PCi_j card (or one beyond 1e12 in magnitude), CDELT = 0 (or below 1e-30), a singular PCi_j, unit_to_deg <= 0, a non-finite LONPOLE on a TAN header, DSUN_OBS <= 0 or a
  * non-finite CRLN_OBS / CRLT_OBS (Carrington transform), a non-finite grid limit or lag, solar_r <= 0 -- are refused with
  * COREG_EINVAL by every sweep, resample and reference preparation before anything is planned or launched (the reference
  * hands such a header to astropy, which raises, or returns NaN everywhere).  A lag-point whose OWN shifted header

@@ -195,6 +195,11 @@ int main(int argc, char** argv) {
             b = hostile(proj);
         }
         sane_pairs += ok;
+        if (ok && (wcs_problem(a, false) || wcs_problem(a, true) || wcs_problem(b, false))) {
+            std::printf("a sane header was refused: %s\n", wcs_problem(a, false) ? wcs_problem(a, false) : "(transform / lagged)");
+            ++failures;
+        }
+        (void)wcs_problem(b, rng() % 2 == 0);  // hostile ones: any answer, no report
         const auto state = rng;  // exercise() draws grid sizes: same draws for the second run
         const double c1 = exercise(a, b, ok, &failures);
         rng = state;

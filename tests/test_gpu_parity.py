@@ -328,7 +328,8 @@ def test_headers_that_cannot_give_pixel_coordinates_are_refused_before_any_launc
         h2.prepare_reference_helioprojective(large, hl, hs, 2)
         good = h2.sweep_helioprojective(hs, hs, one)
         bad_headers = [dict(hs, CDELT1=0.0), dict(hs, CDELT2=float("nan")), dict(hs, CRVAL1=float("inf")),
-                       dict(hs, PC1_1=0.0, PC1_2=0.0), dict(hs, CRPIX2=float("nan")), dict(hs, PC2_1=float("nan"))]
+                       dict(hs, PC1_1=0.0, PC1_2=0.0), dict(hs, CRPIX2=float("nan")), dict(hs, PC2_1=float("nan")),
+                       dict(hs, CRVAL1=1e300), dict(hs, CDELT2=1e-300)]  # (finite, but Inf - Inf a few products later)
         for bad in bad_headers:
             with pytest.raises(_lib.CoregError):
                 h2.sweep_helioprojective(hs, bad, one)
