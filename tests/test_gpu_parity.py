@@ -313,6 +313,32 @@ def test_errors_are_loud(gpu_handle):
         h2.close()
 
 
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_infinite_pixels_are_masked_as_the_reference_masks_them(gpu_handle, order):
+    """alignment.py:525 masks with `isfinite`, and a spline tap on a +-Inf pixel gives +-Inf (weight != 0) or NaN
+    (weight == 0, or both signs among the taps): an infinite pixel takes out exactly the samples a NaN pixel would, in
+    the image to align and in the reference image alike (where it also passes through the once-only resampling)."""
+    small, hs, large, hl, truth = H.scene(small_n=96, large_n=160)
+    small, large = small.copy(), large.copy()
+    rng = np.random.default_rng(17)
+    for img, n in ((small, 40), (large, 25)):
+        yy, xx = rng.integers(0, img.shape[0], n), rng.integers(0, img.shape[1], n)
+        img[yy, xx] = np.where(rng.random(n) < 0.5, np.inf, -np.inf)
+    small[40, 41], small[40, 42] = np.inf, -np.inf  # both signs inside one tap footprint
+    lags = (truth["lag_crval1"] + np.arange(-4.0, 5.0, 2.0), truth["lag_crval2"] + np.arange(-4.0, 5.0, 2.0), None, None,
+            [0.0, 0.3])
+    with np.errstate(invalid="ignore"):
+        want = H.oracle_carrington(small, hs, large, hl, lags, (72, 64), order=order)
+        wanth = H.oracle_helio(small, hs, large, hl, lags, order=order)
+    got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, (72, 64), order=order)
+    H.assert_corr_close(got, want, 1e-10, f"carrington, Inf pixels, order {order}")
+    goth = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order)
+    H.assert_corr_close(goth, wanth, 1e-7, f"helioprojective, Inf pixels, order {order}")
+    # and they do take samples out: the same sweep without them differs
+    clean = H.gpu_carrington(gpu_handle, np.where(np.isfinite(small), small, 100.0), hs, large, hl, lags, (72, 64), order=order)
+    assert np.nanmax(np.abs(clean - got)) > 1e-6
+
+
 def test_headers_that_cannot_give_pixel_coordinates_are_refused_before_any_launch(gpu_handle):
     """A NaN / infinite card, CDELT = 0, a singular PCi_j, a non-positive DSUN_OBS or solar radius, a non-finite lag or
     grid limit: COREG_EINVAL from every entry point that plans kernels from a header (the reference hands such a header to
