@@ -2296,7 +2296,7 @@ __global__ void __launch_bounds__(kFinThreads) k_finalize(const FinalizeArgs a) 
                         const double m = s[2] / n;
                         r = sqrt(fmax(s[4] / n - m * m, 0.0));
                     }
-                } else if (n > 0.0) {
+                } else if (n > 1.0) {  // (one sample: the reference's centred sums are 0 / sqrt(0 * 0) = NaN, exactly)
                     const double cov = s[5] - s[1] * s[2] / n;
                     const double va = s[3] - s[1] * s[1] / n;
                     const double vb = s[4] - s[2] * s[2] / n;
@@ -2425,7 +2425,7 @@ __global__ void __launch_bounds__(kRefineThreads) k_refine(const RefineArgs r, l
         const int slot = r.list[e];
         const double cnt = s[0];
         double res = __builtin_nan("");
-        if (cnt > 0.0) {
+        if (cnt > 1.0) {
             const double cov = s[5] - s[1] * s[2] / cnt;
             const double va = s[3] - s[1] * s[1] / cnt;
             const double vb = s[4] - s[2] * s[2] / cnt;

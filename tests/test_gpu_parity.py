@@ -339,6 +339,34 @@ def test_infinite_pixels_are_masked_as_the_reference_masks_them(gpu_handle, orde
     assert np.nanmax(np.abs(clean - got)) > 1e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (1, 9), (7, 1), (2, 2), (3, 2), (2, 40), (40, 3)])
+def test_images_of_a_few_pixels(gpu_handle, shape):
+    """The smallest inputs: an axis of length 1 keeps no sample at all away from the zero lag (bounds rule c < 0 or
+    c > n - 1, Util.py:98-102) and ONE at it -- the pixel at CRPIX, the only one wcslib's round trip returns exactly --
+    whose centred sums are 0 / sqrt(0 * 0): NaN everywhere, in both frames and both helioprojective semantics; 2 x 2 and
+    3 x 2 images give maps whose every sample has mirrored taps (and, with a handful of samples, lag-points the one-pass
+    moments cannot carry); 2 x 40 and 40 x 3 images are all border: at the zero lag wcslib's rounding noise decides
+    about EVERY pixel, and the lag-point is what is left after most of the sums have been taken out again."""
+    from euispice_coreg_amd import synthetic
+    ny, nx = shape
+    small, hs, large, hl, _ = synthetic.make_scene(small_shape=shape, small_cdelt=(1008.0 / max(nx, 3), 1008.0 / max(ny, 3)),
+                                                   large_n=96, seed=3, n_blobs=60, nan_frac=0.0)
+    lags = ([-40.0, 0.0, 17.0, 90.0], [-9.0, 0.0, 60.0], None, None, [0.0, 0.3])
+    for order in (1, 2, 3):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            want = H.oracle_carrington(small, hs, large, hl, lags, (24, 20), order=order)
+            wanth = H.oracle_helio(small, hs, large, hl, lags, order=order)
+            wants = H.oracle_helio(small, hs, large, hl, lags, order=order, parallelism=False)
+        if 1 in shape:
+            assert np.isnan(want).all() and np.isnan(wanth).all() and np.isnan(wants).all()
+        H.assert_corr_close(H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, (24, 20), order=order), want, 1e-10,
+                            f"carrington {shape} order {order}")
+        H.assert_corr_close(H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order), wanth, 1e-7,
+                            f"helioprojective sub-map {shape} order {order}")
+        H.assert_corr_close(H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order, serial_semantics=True), wants,
+                            1e-7, f"helioprojective full grid {shape} order {order}")
+
+
 def test_headers_that_cannot_give_pixel_coordinates_are_refused_before_any_launch(gpu_handle):
     """A NaN / infinite card, CDELT = 0, a singular PCi_j, a non-positive DSUN_OBS or solar radius, a non-finite lag or
     grid limit: COREG_EINVAL from every entry point that plans kernels from a header (the reference hands such a header to
