@@ -367,6 +367,42 @@ def test_images_of_a_few_pixels(gpu_handle, shape):
                             1e-7, f"helioprojective full grid {shape} order {order}")
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (1, 12), (9, 1), (2, 2), (3, 5)])
+def test_carrington_grids_of_a_few_points(gpu_handle, shape):
+    """Carrington grids down to one point (np.linspace(lo, hi, 1) = [lo], rectify.py:875-878): one grid point is one
+    sample, NaN; a row, a column, 2 x 2 and 3 x 5 points give coefficients over a handful of samples (the re-evaluation
+    about the lag-point's own means carries most of them)."""
+    small, hs, large, hl, _ = H.scene(small_n=64, large_n=96)
+    lags = ([15.0, 17.0, 21.0], [-9.0, -5.0], None, None, [0.0, 0.3])
+    for order in (1, 2, 3):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            want = H.oracle_carrington(small, hs, large, hl, lags, shape, lonlims=(242.0, 249.0), latlims=(2.0, 8.0), order=order)
+        if shape == (1, 1):
+            assert np.isnan(want).all()
+        else:
+            assert np.isfinite(want).all()
+        got = H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, shape, lonlims=(242.0, 249.0), latlims=(2.0, 8.0),
+                               order=order)
+        H.assert_corr_close(got, want, 1e-10, f"carrington grid {shape} order {order}")
+
+
+@pytest.mark.parametrize("large_n", [1, 2, 3])
+def test_reference_images_of_a_few_pixels(gpu_handle, large_n):
+    """A reference image of 1, 4 or 9 pixels: the once-only resampling (sub-map / Carrington transform) has mirrored taps
+    everywhere or nothing in bounds at all; the full-grid helioprojective semantics correlate over at most 9 grid points."""
+    small, hs, large, hl, _ = H.scene(small_n=48, large_n=large_n)
+    lags = ([15.0, 17.0, 21.0], [-9.0, -5.0], None, None, [0.0, 0.3])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want = H.oracle_helio(small, hs, large, hl, lags)
+        wants = H.oracle_helio(small, hs, large, hl, lags, parallelism=False)
+        wantc = H.oracle_carrington(small, hs, large, hl, lags, (16, 16))
+    H.assert_corr_close(H.gpu_helio(gpu_handle, small, hs, large, hl, lags), want, 1e-7, f"sub-map, large_n {large_n}")
+    H.assert_corr_close(H.gpu_helio(gpu_handle, small, hs, large, hl, lags, serial_semantics=True), wants, 1e-7,
+                        f"full grid, large_n {large_n}")
+    H.assert_corr_close(H.gpu_carrington(gpu_handle, small, hs, large, hl, lags, (16, 16)), wantc, 1e-10,
+                        f"carrington, large_n {large_n}")
+
+
 def test_headers_that_cannot_give_pixel_coordinates_are_refused_before_any_launch(gpu_handle):
     """A NaN / infinite card, CDELT = 0, a singular PCi_j, a non-positive DSUN_OBS or solar radius, a non-finite lag or
     grid limit: COREG_EINVAL from every entry point that plans kernels from a header (the reference hands such a header to
