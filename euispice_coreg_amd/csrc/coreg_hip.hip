@@ -985,7 +985,11 @@ static int check_wcs(coreg_handle* h, const coreg_wcs2d* w, bool carrington_tran
     const char* why = wcs_problem(*w, carrington_transform);
     return why ? fail(h, COREG_EINVAL, why) : COREG_OK;
 }
+// Pixel and grid-point counts are 32-bit in the kernels' lists (active points, border pixels, tiles): refuse what does not fit.
+static bool too_many(long long a, long long b) { return a * b > 2147483647ll; }
 static int check_grid(coreg_handle* h, const coreg_carr_grid* g) {
+    if (g->n_lon >= 1 && g->n_lat >= 1 && too_many(g->n_lon, g->n_lat))
+        return fail(h, COREG_EINVAL, "Carrington grid: more than 2^31 - 1 points");
     const char* why = grid_problem(*g);
     return why ? fail(h, COREG_EINVAL, why) : COREG_OK;
 }
@@ -2239,7 +2243,7 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
 
 int coreg_set_small(coreg_handle* h, const double* img, int32_t ny, int32_t nx) {
     if (!h) return COREG_EINVAL;
-    if (!img || ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "set_small: bad image");
+    if (!img || ny < 1 || nx < 1 || too_many(ny, nx)) return fail(h, COREG_EINVAL, "set_small: bad image");
     RETCHK(bind_device(h));
     const size_t n = (size_t)ny * nx;
     RETCHK(upload_image(h, img, n, h->small, &h->small_f32));
@@ -2254,7 +2258,7 @@ int coreg_set_small(coreg_handle* h, const double* img, int32_t ny, int32_t nx) 
 
 int coreg_set_small_f32(coreg_handle* h, const float* img, int32_t ny, int32_t nx) {
     if (!h) return COREG_EINVAL;
-    if (!img || ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "set_small_f32: bad image");
+    if (!img || ny < 1 || nx < 1 || too_many(ny, nx)) return fail(h, COREG_EINVAL, "set_small_f32: bad image");
     trace("set_small_f32: enter");
     RETCHK(bind_device(h));
     const size_t n = (size_t)ny * nx;
@@ -2285,7 +2289,7 @@ int coreg_set_small_f32(coreg_handle* h, const float* img, int32_t ny, int32_t n
 // image to align from pinned host memory or from this GPU's memory (one asynchronous copy, no staging)
 static int set_small_direct(coreg_handle* h, const void* img, int dtype, int32_t ny, int32_t nx, SrcKind kind) {
     if (!h) return COREG_EINVAL;
-    if (!img || ny < 1 || nx < 1 || (dtype != COREG_F32 && dtype != COREG_F64))
+    if (!img || ny < 1 || nx < 1 || too_many(ny, nx) || (dtype != COREG_F32 && dtype != COREG_F64))
         return fail(h, COREG_EINVAL, "set_small: bad argument");
     RETCHK(bind_device(h));
     const size_t n = (size_t)ny * nx;
@@ -2312,7 +2316,7 @@ static int set_small_fits(coreg_handle* h, const coreg_fits_pixels* px, int32_t 
     if (!h) return COREG_EINVAL;
     PixFmt fmt;
     RETCHK(check_fits(h, px, &fmt));
-    if (ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "set_small_fits: bad image size");
+    if (ny < 1 || nx < 1 || too_many(ny, nx)) return fail(h, COREG_EINVAL, "set_small_fits: bad image size");
     RETCHK(bind_device(h));
     const size_t n = (size_t)ny * nx, eb = fmt.elem();
     DevBuf& dst = fmt.swap_only() ? h->small : h->up_raw;
@@ -2643,7 +2647,8 @@ static int prepare_carrington(coreg_handle* h, const void* large, const PixFmt& 
                               const coreg_wcs2d* hdr, const coreg_carr_grid* grid, double solar_r, int order,
                               SrcKind kind = SRC_HOST) {
     if (!h) return COREG_EINVAL;
-    if (!large || !hdr || !grid || ny < 1 || nx < 1) return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
+    if (!large || !hdr || !grid || ny < 1 || nx < 1 || too_many(ny, nx))
+        return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
     RETCHK(check_order(h, order));
     RETCHK(check_wcs(h, hdr, true));
     RETCHK(check_grid(h, grid));
@@ -2694,9 +2699,10 @@ static int prepare_helioprojective(coreg_handle* h, const void* large, const Pix
                                    const coreg_wcs2d* hdr_large, const coreg_wcs2d* hdr_small, int order,
                                    SrcKind kind = SRC_HOST) {
     if (!h) return COREG_EINVAL;
-    if (!large || !hdr_large || !hdr_small || ny < 1 || nx < 1)
+    if (!large || !hdr_large || !hdr_small || ny < 1 || nx < 1 || too_many(ny, nx))
         return fail(h, COREG_EINVAL, "prepare_reference: bad argument");
-    if (hdr_small->naxis1 < 1 || hdr_small->naxis2 < 1) return fail(h, COREG_EINVAL, "hdr_small: NAXIS1/2 missing");
+    if (hdr_small->naxis1 < 1 || hdr_small->naxis2 < 1 || too_many(hdr_small->naxis1, hdr_small->naxis2))
+        return fail(h, COREG_EINVAL, "hdr_small: NAXIS1/2 missing (or more than 2^31 - 1 pixels)");
     if (hdr_large->proj != hdr_small->proj || (hdr_small->proj != COREG_PROJ_TAN && hdr_small->proj != COREG_PROJ_CAR))
         return fail(h, COREG_ENOTIMPL, "prepare_reference_helioprojective: both headers TAN, or both CAR");
     RETCHK(check_order(h, order));
@@ -2863,7 +2869,8 @@ static int resample_helio(coreg_handle* h, const coreg_wcs2d* hdr_target, const 
     if (!h) return COREG_EINVAL;
     if (!hdr_target || !hdr || !out) return fail(h, COREG_EINVAL, "resample_helioprojective: bad argument");
     if (!h->small.p) return fail(h, COREG_ESTATE, "coreg_set_small has not been called");
-    if (hdr_target->naxis1 < 1 || hdr_target->naxis2 < 1) return fail(h, COREG_EINVAL, "hdr_target: NAXIS missing");
+    if (hdr_target->naxis1 < 1 || hdr_target->naxis2 < 1 || too_many(hdr_target->naxis1, hdr_target->naxis2))
+        return fail(h, COREG_EINVAL, "hdr_target: NAXIS missing (or more than 2^31 - 1 pixels)");
     RETCHK(check_order(h, order));
     RETCHK(check_wcs(h, hdr_target, false));
     RETCHK(check_wcs(h, hdr, false));

@@ -270,7 +270,8 @@ int coreg_resample_helioprojective_f64(coreg_handle* h, const coreg_wcs2d* hdr_t
  * anything ordered after it on that stream -- an RCCL all-gather, a copy -- sees the results.
  * Headers, grids and lags that cannot give finite pixel coordinates -- a NaN / infinite CRPIX / CRVAL / CDELT / CROTA /
  * PCi_j card (or one beyond 1e12 in magnitude), CDELT = 0 (or below 1e-30), a singular PCi_j, unit_to_deg <= 0, a non-finite LONPOLE on a TAN header, DSUN_OBS <= 0 or a
- * non-finite CRLN_OBS / CRLT_OBS (Carrington transform), a non-finite grid limit or lag, solar_r <= 0 -- are refused with
+ * non-finite CRLN_OBS / CRLT_OBS (Carrington transform), a non-finite grid limit or lag, solar_r <= 0, an image or grid
+ * of more than 2^31 - 1 pixels / points -- are refused with
  * COREG_EINVAL by every sweep, resample and reference preparation before anything is planned or launched (the reference
  * hands such a header to astropy, which raises, or returns NaN everywhere).  A lag-point whose OWN shifted header
  * degenerates (CDELT + d_cdelt = 0) stays NaN, like one whose worker dies in the reference (coreg_shift_header

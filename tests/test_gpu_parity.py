@@ -443,6 +443,9 @@ def test_headers_that_cannot_give_pixel_coordinates_are_refused_before_any_launc
             h2.sweep_carrington(hs, grid, 0.0, one)
         with pytest.raises(_lib.CoregError):
             h2.sweep_carrington(hs, _lib.Grid((228.0, float("nan")), (-12.0, 22.0), (40, 40)), 1.004, one)
+        with pytest.raises(_lib.CoregError):  # 2.5e9 grid points: more than the 32-bit point lists hold
+            h2.prepare_reference_carrington(large, hl, _lib.Grid((228.0, 262.0), (-12.0, 22.0), (50000, 50000)), 1.004, 2)
+        h2.prepare_reference_carrington(large, hl, grid, 1.004, 2)
         assert np.array_equal(h2.sweep_carrington(hs, grid, 1.004, one), goodc)
         # a CDELT1 lag of exactly -CDELT1 (intended semantics): that slice NaN, the others as without it
         lc = [-hs["CDELT1"], 0.0]
