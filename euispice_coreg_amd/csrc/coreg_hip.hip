@@ -1537,13 +1537,15 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
 
     FinalizeArgs f = {};
     // ill-conditioned lag-points are flagged by k_finalize and re-evaluated about their own means (kernels.hpp:
-    // RefineArgs) -- not for method 'residus' (another statistic) and not in a launch whose noise-decided border pixels
-    // were taken out of the sums by an extra slab.  Grid shares across GPUs: the flags can only come from the REDUCED
-    // sums, so the re-evaluation is run by coreg_finalize_sums, on every rank, over the whole grid.
+    // RefineArgs) -- not for method 'residus' (another statistic) and not the lag-points whose noise-decided samples
+    // were taken out of (put into) the sums by the extra slab: those keep their one-pass value (FinalizeArgs.fix_slab).
+    // Grid shares across GPUs: the flags can only come from the REDUCED sums, so the re-evaluation is run by
+    // coreg_finalize_sums, on every rank, over the whole grid (and not at all for a launch with a slab).
     const bool fix_any = fix && (!fix->items.empty() || fix->tap_segs > 0);  // (the same on every rank)
-    const bool refinable = h->opt_refine && method != COREG_METHOD_RESIDUS && !fix_any;
+    const bool refinable = h->opt_refine && method != COREG_METHOD_RESIDUS;
     RETCHK(fill_refine(h, &f.refine, mode, order, params_dev, a.car_inv, n_slots));
     f.refine.enabled = (refinable && !sharded) ? 1 : 0;
+    f.fix_slab = fixing ? h->partials.as<double>() + (size_t)g_per * kNumSums * n_slots : nullptr;
     f.refine_count = h->counters.as<long long>();  // (null before the first plan: no sweep without one)
     f.partials = h->partials.as<double>();
     f.n_groups = g_per + (fixing ? 1 : 0);
@@ -1562,7 +1564,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
         pf.outidx_dev = nullptr;  // set by coreg_finalize_sums from fin_outidx
         pf.residus = method == COREG_METHOD_RESIDUS ? 1 : 0;
         pf.refine = f.refine;
-        pf.refine.enabled = refinable ? 1 : 0;
+        pf.refine.enabled = (refinable && !fix_any) ? 1 : 0;  // (the slab is inside the reduced sums: no telling which slots)
         pf.replay_precompute = h->last_precompute;
         h->pending_fin.push_back(pf);
     }

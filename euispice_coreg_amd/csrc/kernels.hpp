@@ -2202,7 +2202,12 @@ struct FinalizeArgs {
     long long part_stride;  // distance between the six sums of a slab (n_slots, or sums_stride when reading reduced sums)
     RefineArgs refine;
     long long* refine_count;  // device counters (diagnostics), or null: [0] re-evaluated lag-points, [1] lag-points that
-                              // were flagged but kept their one-pass value (always 0 since round 5: there is no cap)
+                              // were flagged but kept their one-pass value (fix_slab below; there is no cap)
+    // the extra slab of a launch with noise-decided samples (k_border_fix / k_parity_fix / k_tap_fix), [kNumSums][n_slots],
+    // or null.  A lag-point whose entries are all zero had nothing taken out or put in: it is flagged and re-evaluated like
+    // any other.  One with a correction keeps its one-pass value (the re-evaluation walks the grid without the lists
+    // of those samples) and is counted in refine_count[1] when it was flagged.
+    const double* fix_slab;
 };
 constexpr int kFinLanes = 16;  // threads per lag slot in k_finalize
 constexpr int kFinSlots = 16;  // lag slots per block: 256-thread blocks, 16 of them per 256-lag batch -- a sweep of two
@@ -2303,6 +2308,15 @@ __global__ void __launch_bounds__(kFinThreads) k_finalize(const FinalizeArgs a) 
                     r = cov / sqrt(va * vb);
                     // (negated comparisons: a NaN or non-positive variance is flagged too)
                     flag = !(va > 0.0) || !(vb > 0.0) || !(s[3] <= a.refine.cond * va) || !(s[4] <= a.refine.cond * vb);
+                    if (a.refine.enabled && flag && a.fix_slab) {
+                        bool corrected = false;
+#pragma unroll
+                        for (int k = 0; k < kNumSums; ++k) corrected |= a.fix_slab[(size_t)k * a.n_slots + slot] != 0.0;
+                        if (corrected) {
+                            flag = 0;
+                            if (a.refine_count) atomicAdd((unsigned long long*)a.refine_count + 1, 1ull);
+                        }
+                    }
                     if (a.refine.enabled && flag) {
                         a.refine.slot_pivots[slot] = s[1] / n;
                         a.refine.slot_pivots[a.n_slots + slot] = s[2] / n;
