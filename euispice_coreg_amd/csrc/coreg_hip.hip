@@ -139,6 +139,7 @@ struct coreg_handle {
     int pin_img_next = 0;
     // precompute outputs
     DevBuf pts, tile_count, tile_list, tile_cum, group_first, tile_info, tile_bbox;
+    DevBuf rf_fix_slab;  // [kNumSums][n_slots]: a launch's noise-decided samples about the flagged slots' own pivots
     DevBuf counters;  // [0]: lag-points re-evaluated by k_finalize during the sweep in flight (reset by its prologue)
     // sweep
     DevBuf lane_params, out_index, partials, out_dev, tmp_img;
@@ -1450,12 +1451,50 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     h->stats.n_sweep_launches++;
     h->stats.used_lds = a.use_lds;
 
+    // the noise-decided samples of this launch, as kernel arguments: run once about the global pivots into the
+    // extra slab, and -- when lag-points are re-evaluated -- a second time about the flagged slots' own pivots
+    std::vector<BorderFixArgs> border_items;
+    std::vector<ParityFixArgs> parity_items;
+    TapFixArgs tap_item = {};
+    bool have_tap = false;
+    auto launch_fixes = [&](double* slab, const double* slot_pivots, const int* only_flagged) -> int {
+        for (BorderFixArgs b : border_items) {
+            b.slab = slab;
+            b.slot_pivots = slot_pivots;
+            b.only_flagged = only_flagged;
+            if (h->small_f32) hipLaunchKernelGGL((k_border_fix<float>), dim3(1), dim3(256), 0, h->stream, b);
+            else hipLaunchKernelGGL((k_border_fix<double>), dim3(1), dim3(256), 0, h->stream, b);
+        }
+        for (ParityFixArgs p : parity_items) {
+            p.slab = slab;
+            p.slot_pivots = slot_pivots;
+            p.only_flagged = only_flagged;
+            if (h->small_f32) hipLaunchKernelGGL((k_parity_fix<float>), dim3(p.n_partial), dim3(256), 0, h->stream, p);
+            else hipLaunchKernelGGL((k_parity_fix<double>), dim3(p.n_partial), dim3(256), 0, h->stream, p);
+            hipLaunchKernelGGL(k_parity_fix_final, dim3(1), dim3(64), 0, h->stream, p);
+        }
+        if (have_tap) {
+            TapFixArgs t = tap_item;
+            t.slab = slab;
+            t.slot_pivots = slot_pivots;
+            t.only_flagged = only_flagged;
+            const dim3 tg((unsigned)fix->tap_segs), tb(256);
+            if (fix->tap_mode == MODE_HOMOGRAPHY_SERIES) {
+                if (h->small_f32) hipLaunchKernelGGL((k_tap_fix<float, MODE_HOMOGRAPHY_SERIES>), tg, tb, 0, h->stream, t);
+                else hipLaunchKernelGGL((k_tap_fix<double, MODE_HOMOGRAPHY_SERIES>), tg, tb, 0, h->stream, t);
+            } else {
+                if (h->small_f32) hipLaunchKernelGGL((k_tap_fix<float, MODE_HOMOGRAPHY>), tg, tb, 0, h->stream, t);
+                else hipLaunchKernelGGL((k_tap_fix<double, MODE_HOMOGRAPHY>), tg, tb, 0, h->stream, t);
+            }
+        }
+        HIPCHK(hipGetLastError());
+        return COREG_OK;
+    };
     if (fixing) {
         // one more slab: zero, except minus the dropped border pixels' totals at the identity lag's slot
         double* slab = h->partials.as<double>() + (size_t)g_per * kNumSums * n_slots;
         HIPCHK(hipMemsetAsync(slab, 0, (size_t)kNumSums * n_slots * sizeof(double), h->stream));
-        std::vector<ParityFixArgs> parity_items;
-        BorderFixArgs b;
+        BorderFixArgs b = {};
         b.img = h->small.p;
         b.W = h->sW;
         b.H = h->sH;
@@ -1466,7 +1505,6 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
         b.round_f32 = mode == MODE_TRANSLATE ? 0 : 1;
         b.residus = method == COREG_METHOD_RESIDUS ? 1 : 0;
         b.pivots = h->pivots.as<double>();
-        b.slab = slab;
         b.n_slots = n_slots;
         for (const BorderFix::Item& it : fix->items) {
             b.slot = it.slot;
@@ -1476,7 +1514,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
             if (it.flags_off >= 0) {
                 // odd spline order: re-decide the tap set of every pixel of this lag-point (k_parity_fix), after
                 // k_border_fix has set the slab entry (same stream)
-                ParityFixArgs p;
+                ParityFixArgs p = {};
                 p.img = b.img;
                 p.W = b.W;
                 p.H = b.H;
@@ -1496,17 +1534,10 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
                 if (h->fix_partial.reserve((size_t)p.n_partial * kNumSums * sizeof(double)) != hipSuccess)
                     return fail(h, COREG_EHIP, "hipMalloc failed (parity fix)");
                 p.partial = h->fix_partial.as<double>();
-                p.slab = slab;
                 parity_items.push_back(p);
             }
             if (it.n == 0) continue;
-            if (h->small_f32) hipLaunchKernelGGL((k_border_fix<float>), dim3(1), dim3(256), 0, h->stream, b);
-            else hipLaunchKernelGGL((k_border_fix<double>), dim3(1), dim3(256), 0, h->stream, b);
-        }
-        for (const ParityFixArgs& p : parity_items) {
-            if (h->small_f32) hipLaunchKernelGGL((k_parity_fix<float>), dim3(p.n_partial), dim3(256), 0, h->stream, p);
-            else hipLaunchKernelGGL((k_parity_fix<double>), dim3(p.n_partial), dim3(256), 0, h->stream, p);
-            hipLaunchKernelGGL(k_parity_fix_final, dim3(1), dim3(64), 0, h->stream, p);
+            border_items.push_back(b);
         }
         if (fix->tap_segs > 0) {
             TapFixArgs t = fix->tap;
@@ -1522,17 +1553,10 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
             t.pivots = b.pivots;
             t.hom = params_dev;
             t.n_slots = n_slots;
-            t.slab = slab;
-            const dim3 tg((unsigned)fix->tap_segs), tb(256);
-            if (fix->tap_mode == MODE_HOMOGRAPHY_SERIES) {
-                if (h->small_f32) hipLaunchKernelGGL((k_tap_fix<float, MODE_HOMOGRAPHY_SERIES>), tg, tb, 0, h->stream, t);
-                else hipLaunchKernelGGL((k_tap_fix<double, MODE_HOMOGRAPHY_SERIES>), tg, tb, 0, h->stream, t);
-            } else {
-                if (h->small_f32) hipLaunchKernelGGL((k_tap_fix<float, MODE_HOMOGRAPHY>), tg, tb, 0, h->stream, t);
-                else hipLaunchKernelGGL((k_tap_fix<double, MODE_HOMOGRAPHY>), tg, tb, 0, h->stream, t);
-            }
+            tap_item = t;
+            have_tap = true;
         }
-        HIPCHK(hipGetLastError());
+        RETCHK(launch_fixes(slab, nullptr, nullptr));
     }
 
     FinalizeArgs f = {};
@@ -1546,6 +1570,14 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     RETCHK(fill_refine(h, &f.refine, mode, order, params_dev, a.car_inv, n_slots));
     f.refine.enabled = (refinable && !sharded) ? 1 : 0;
     f.fix_slab = fixing ? h->partials.as<double>() + (size_t)g_per * kNumSums * n_slots : nullptr;
+    if (fixing && f.refine.enabled) {
+        // the re-evaluation of a flagged lag-point of THIS launch needs its noise-decided samples about its own pivots:
+        // a second slab, filled between the listing of the flags and k_refine (kernels that leave at once unless the
+        // slot is flagged)
+        HIPCHK(h->rf_fix_slab.reserve((size_t)kNumSums * n_slots * sizeof(double)));
+        HIPCHK(hipMemsetAsync(h->rf_fix_slab.p, 0, (size_t)kNumSums * n_slots * sizeof(double), h->stream));
+        f.refine.fix_slab = h->rf_fix_slab.as<double>();
+    }
     f.refine_count = h->counters.as<long long>();  // (null before the first plan: no sweep without one)
     f.partials = h->partials.as<double>();
     f.n_groups = g_per + (fixing ? 1 : 0);
@@ -1577,7 +1609,13 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_slots + kFinSlots - 1) / kFinSlots)), dim3(kFinSlots * kFinLanes), 0,
                        h->stream, f);
     HIPCHK(hipGetLastError());
-    if (f.refine.enabled) RETCHK(launch_refine(h, f.refine, n_slots, outidx_dev, lag_begin, out_dev));
+    if (f.refine.enabled && f.refine.fix_slab) {
+        hipLaunchKernelGGL(k_refine_list, dim3(1), dim3(kListThreads), 0, h->stream, f.refine, n_slots, h->counters.as<long long>());
+        RETCHK(launch_fixes(h->rf_fix_slab.as<double>(), f.refine.slot_pivots, f.refine.flags));
+        RETCHK(launch_refine(h, f.refine, n_slots, outidx_dev, lag_begin, out_dev, false));
+    } else if (f.refine.enabled) {
+        RETCHK(launch_refine(h, f.refine, n_slots, outidx_dev, lag_begin, out_dev));
+    }
     return COREG_OK;
 }
 
@@ -2112,7 +2150,7 @@ void coreg_destroy(coreg_handle* h) {
     DevBuf* bufs[] = {&h->rf_flags, &h->rf_pivots, &h->rf_list, &h->rf_head, &h->rf_partial, &h->small, &h->ref, &h->pivots, &h->red_sum, &h->red_cnt, &h->t_sin_lon, &h->t_cos_lon,
                       &h->t_cos_lat, &h->t_sin_lat, &h->pts, &h->tile_count, &h->tile_list, &h->tile_cum, &h->group_first,
                       &h->tile_info, &h->tile_bbox, &h->counters, &h->lane_params, &h->out_index, &h->partials, &h->out_dev,
-                      &h->tmp_img, &h->up_f64, &h->up_flag, &h->up_raw, &h->rice_blob, &h->rice_rand, &h->dec_img, &h->border_dev, &h->sums, &h->fin_outidx, &h->border_flags, &h->fix_partial};
+                      &h->tmp_img, &h->up_f64, &h->up_flag, &h->up_raw, &h->rice_blob, &h->rice_rand, &h->dec_img, &h->border_dev, &h->sums, &h->fin_outidx, &h->border_flags, &h->fix_partial, &h->rf_fix_slab};
     for (DevBuf* b : bufs) b->release();
     for (int k = 0; k < 2; ++k) {
         h->pin_img[k].release();

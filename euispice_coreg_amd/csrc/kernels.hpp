@@ -1778,11 +1778,29 @@ struct BorderFixArgs {
     const double* hom;  // lane parameters of the launch, SoA [9][n_slots]: the slot's (snapped, affine) map
     double* slab;  // [kNumSums][n_slots], the extra slab
     long long n_slots, slot;
+    // second run, for the re-evaluation of an ill-conditioned lag-point (RefineArgs.fix_slab): the same samples about the
+    // lag-point's OWN pivots ([2][n_slots], relative to the global ones), only when the slot is flagged; null otherwise
+    const double* slot_pivots;
+    const int* only_flagged;
 };
+// (the slot's own pivots in a fix kernel's second run -- subtracted AFTER the global ones, as refine_item does; zero in
+// the first run; false: nothing to do for this slot)
+__device__ __forceinline__ bool fix_pivots(const double* slot_pivots, const int* only_flagged, long long n_slots,
+                                           long long slot, double& own_a, double& own_b) {
+    own_a = own_b = 0.0;
+    if (slot_pivots) {
+        if (only_flagged && !only_flagged[slot]) return false;
+        own_a = slot_pivots[slot];
+        own_b = slot_pivots[n_slots + slot];
+    }
+    return true;
+}
 template <typename TS>
 __global__ void __launch_bounds__(256) k_border_fix(const BorderFixArgs a) {
     __shared__ double red[256];
     const double pivot_a = a.pivots[0], pivot_b = a.pivots[1];
+    double own_a, own_b;
+    if (!fix_pivots(a.slot_pivots, a.only_flagged, a.n_slots, a.slot, own_a, own_b)) return;
     double hm[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) hm[k] = a.hom[(long long)k * a.n_slots + a.slot];
@@ -1809,7 +1827,7 @@ __global__ void __launch_bounds__(256) k_border_fix(const BorderFixArgs a) {
                 s[4] = fma(d, d, s[4]);
             }
         } else if (isfinite(v)) {
-            const double av = araw - pivot_a, bm = v - pivot_b;
+            const double av = (araw - pivot_a) - own_a, bm = (v - pivot_b) - own_b;
             s[0] += 1.0;
             s[1] += av;
             s[2] += bm;
@@ -1853,11 +1871,15 @@ struct ParityFixArgs {
     double* partial;  // [gridDim.x][kNumSums]
     double* slab;     // [kNumSums][n_slots]
     int n_partial;
+    const double* slot_pivots;  // as BorderFixArgs
+    const int* only_flagged;
 };
 template <typename TS>
 __global__ void __launch_bounds__(256) k_parity_fix(const ParityFixArgs a) {
     __shared__ double red[256];
     const double pivot_a = a.pivots[0], pivot_b = a.pivots[1];
+    double own_a, own_b;
+    if (!fix_pivots(a.slot_pivots, a.only_flagged, a.n_slots, a.slot, own_a, own_b)) return;
     double hm[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) hm[k] = a.hom[(long long)k * a.n_slots + a.slot];
@@ -1894,7 +1916,7 @@ __global__ void __launch_bounds__(256) k_parity_fix(const ParityFixArgs a) {
                 s[4] += sign * d * d;
             }
         } else {
-            const double av = araw - pivot_a, bm = v - pivot_b;
+            const double av = (araw - pivot_a) - own_a, bm = (v - pivot_b) - own_b;
             s[0] += sign;
             s[1] += sign * av;
             s[2] += sign * bm;
@@ -1916,6 +1938,7 @@ __global__ void __launch_bounds__(256) k_parity_fix(const ParityFixArgs a) {
 }
 __global__ void k_parity_fix_final(const ParityFixArgs a) {
     if (blockIdx.x != 0 || threadIdx.x >= kNumSums) return;
+    if (a.slot_pivots && a.only_flagged && !a.only_flagged[a.slot]) return;  // (k_parity_fix left at once too)
     double t = 0.0;
     for (int b = 0; b < a.n_partial; ++b) t += a.partial[(size_t)b * kNumSums + threadIdx.x];
     a.slab[(size_t)threadIdx.x * a.n_slots + a.slot] += t;
@@ -2084,6 +2107,8 @@ struct TapFixArgs {
     const double* xw;           // [n] wcslib's coordinates of that pixel under the slot's shifted header
     const double* yw;
     double* slab;               // [kNumSums][n_slots] the extra slab
+    const double* slot_pivots;  // as BorderFixArgs
+    const int* only_flagged;
 };
 template <typename TS, int MODE>
 __global__ void __launch_bounds__(256) k_tap_fix(const TapFixArgs a) {
@@ -2091,6 +2116,8 @@ __global__ void __launch_bounds__(256) k_tap_fix(const TapFixArgs a) {
     const int seg = blockIdx.x;
     const long long slot = a.seg_slot[seg];
     const double pivot_a = a.pivots[0], pivot_b = a.pivots[1];
+    double own_a, own_b;
+    if (!fix_pivots(a.slot_pivots, a.only_flagged, a.n_slots, slot, own_a, own_b)) return;
     H9 hm;
 #pragma unroll
     for (int k = 0; k < 9; ++k) hm.h[k] = a.hom[(long long)k * a.n_slots + slot];
@@ -2119,7 +2146,7 @@ __global__ void __launch_bounds__(256) k_tap_fix(const TapFixArgs a) {
                     s[4] += sign * d * d;
                 }
             } else if (isfinite(v)) {
-                const double av = araw - pivot_a, bm = v - pivot_b;
+                const double av = (araw - pivot_a) - own_a, bm = (v - pivot_b) - own_b;
                 s[0] += sign;
                 s[1] += sign * av;
                 s[2] += sign * bm;
@@ -2168,6 +2195,9 @@ struct RefineArgs {
     // work space of the re-evaluation (per handle, sized for the launch)
     int* flags;           // [n_slots] 1: flagged by k_finalize
     double* slot_pivots;  // [2][n_slots] the lag-point's own means, relative to the global pivots
+    // [kNumSums][n_slots] or null: what a launch's noise-decided samples (k_border_fix / k_parity_fix / k_tap_fix, run a
+    // second time about the slot pivots) take out of / put into the re-evaluated sums; added by the last block
+    const double* fix_slab;
     int* list;            // [n_slots] flagged slots in slot order (k_refine_list)
     int* head;            // [0] number of flagged slots, [1] chunks per slot (k_refine_list); [3]: ticket of k_refine's
                           // "the block that finishes last writes the coefficients" step, zero between launches
@@ -2204,9 +2234,10 @@ struct FinalizeArgs {
     long long* refine_count;  // device counters (diagnostics), or null: [0] re-evaluated lag-points, [1] lag-points that
                               // were flagged but kept their one-pass value (fix_slab below; there is no cap)
     // the extra slab of a launch with noise-decided samples (k_border_fix / k_parity_fix / k_tap_fix), [kNumSums][n_slots],
-    // or null.  A lag-point whose entries are all zero had nothing taken out or put in: it is flagged and re-evaluated like
-    // any other.  One with a correction keeps its one-pass value (the re-evaluation walks the grid without the lists
-    // of those samples) and is counted in refine_count[1] when it was flagged.
+    // or null.  With refine.fix_slab set (the fix kernels run a second time, about the slot pivots) every flagged
+    // lag-point is re-evaluated.  Without it, a lag-point whose entries are all zero had nothing taken out or put in and
+    // is re-evaluated like any other; one with a correction keeps its one-pass value (the re-evaluation walks the grid
+    // without the lists of those samples) and is counted in refine_count[1] when it was flagged.
     const double* fix_slab;
 };
 constexpr int kFinLanes = 16;  // threads per lag slot in k_finalize
@@ -2308,7 +2339,7 @@ __global__ void __launch_bounds__(kFinThreads) k_finalize(const FinalizeArgs a) 
                     r = cov / sqrt(va * vb);
                     // (negated comparisons: a NaN or non-positive variance is flagged too)
                     flag = !(va > 0.0) || !(vb > 0.0) || !(s[3] <= a.refine.cond * va) || !(s[4] <= a.refine.cond * vb);
-                    if (a.refine.enabled && flag && a.fix_slab) {
+                    if (a.refine.enabled && flag && a.fix_slab && !a.refine.fix_slab) {
                         bool corrected = false;
 #pragma unroll
                         for (int k = 0; k < kNumSums; ++k) corrected |= a.fix_slab[(size_t)k * a.n_slots + slot] != 0.0;
@@ -2437,6 +2468,10 @@ __global__ void __launch_bounds__(kRefineThreads) k_refine(const RefineArgs r, l
             for (int k = 0; k < kNumSums; ++k) s[k] += p[k];
         }
         const int slot = r.list[e];
+        if (r.fix_slab) {
+#pragma unroll
+            for (int k = 0; k < kNumSums; ++k) s[k] += r.fix_slab[(size_t)k * n_slots + slot];
+        }
         const double cnt = s[0];
         double res = __builtin_nan("");
         if (cnt > 1.0) {

@@ -463,14 +463,7 @@ class Alignment:
             h.drop_small_keepalive()  # (every sweep has returned: the upload thread is done with the pixels)
         if use_all:
             self.last_sharding = h.last_mode
-        elif self.coordinate_frame != "final_carrington" and hasattr(h, "last_visit_counts") and \
-                h.last_visit_counts()["flagged_not_refined"]:
-            # a lag-point whose samples the one-pass moments cannot carry AND whose noise-decided samples were taken out
-            # of the sums (the zero lag on degenerate data): it kept its one-pass value
-            warnings.warn("an ill-conditioned lag-point with noise-decided border samples (the zero lag) was not "
-                          "re-evaluated about its own means: its coefficient may differ from the reference's")
-        if not use_all and int(self.order) % 2 == 1 and self.coordinate_frame != "final_carrington" and \
-                hasattr(h, "last_tap_fix"):
+        elif int(self.order) % 2 == 1 and self.coordinate_frame != "final_carrington" and hasattr(h, "last_tap_fix"):
             #  odd spline orders: samples whose coordinate comes back within 1e-8 px of an integer are
             # re-evaluated with wcslib's own arithmetic; a list beyond "tap_cap" entries is not applied -- say so
             if h.last_tap_fix()["overflow"]:

@@ -316,11 +316,11 @@ int coreg_last_stats(coreg_handle* h, coreg_stats* out);
  * sweep -- all; gathered from an LDS window; of those, "interior" (every sample inside the image: no bounds rule); of
  * those, all-finite windows (no sample mask either).  counts6[4]: lag-points of the WHOLE last sweep whose six sums
  * were too ill-conditioned for the one-pass Pearson formula and were re-evaluated about their own means ("refine");
- * counts6[5]: lag-points that were flagged but kept their one-pass value: there is no cap on the re-evaluations, but a
- * lag-point whose noise-decided samples were taken out of (put into) its sums by the extra slab of a helioprojective
- * launch -- the zero lag, single samples of odd orders -- is not re-evaluated (the re-evaluation walks the grid without
- * the lists of those samples); every other lag-point of such a launch is.  Non-zero only on degenerate data through the
- * zero lag.  Waits for the stream. */
+ * counts6[5]: lag-points that were flagged but kept their one-pass value -- 0: there is no cap on the re-evaluations,
+ * and a lag-point whose noise-decided samples were taken out of (put into) its sums by the extra slab of a
+ * helioprojective launch (the zero lag, single samples of odd orders) is re-evaluated with those samples taken about its
+ * own pivots as well.  (The field counts such lag-points where that second slab is not available; it stays for ABI
+ * stability.)  Waits for the stream. */
 int coreg_last_visit_counts(coreg_handle* h, int64_t* counts6);
 /* Odd spline orders in the helioprojective frame ("tap_fix", below): counts3[0] samples of the last sweep whose mapped
  * coordinate lay within 1e-8 px of an integer and were re-evaluated with wcslib's own arithmetic, counts3[1] lag-points

@@ -828,20 +828,21 @@ def test_ill_conditioned_lag_points_are_re_evaluated_with_centred_sums(gpu_handl
     assert gpu_handle.last_visit_counts()["refined_lag_points"] == 0
 
 
+@pytest.mark.parametrize("order", [1, 2, 3])
 @pytest.mark.parametrize("finite_border", [False, True])
-def test_ill_conditioned_lag_points_are_re_evaluated_next_to_a_zero_lag_too(gpu_handle, finite_border):
-    """A helioprojective sweep THROUGH the zero lag (whose noise-decided border pixels are taken out of the sums by an
-    extra slab) over data the one-pass moments cannot carry: a nearly flat reference on the image's own grid
+def test_ill_conditioned_lag_points_are_re_evaluated_next_to_a_zero_lag_too(gpu_handle, finite_border, order):
+    """A helioprojective sweep THROUGH the zero lag (whose noise-decided samples are taken out of / put into the sums by
+    an extra slab) over data the one-pass moments cannot carry: a nearly flat reference on the image's own grid
     (1000 +- 1e-3) with a block at -1e7 where the image to align is masked -- it moves the pivot, never overlaps.  Every
-    lag-point is flagged.  Until round 5 a launch with a slab was never re-evaluated; now every lag-point whose slab
-    entries are zero is, and gives the two-pass coefficient of c_correlate.py:39-72.  `finite_border`: the image's
-    border pixels are finite, the zero lag HAS samples taken out -- that one lag-point keeps its one-pass value (the
-    re-evaluation walks the grid without the list of those samples) and the counter says so; with a masked border there
-    is nothing to take out and all nine are re-evaluated."""
+    lag-point is flagged, the zero lag included, and every one is re-evaluated about its own means and gives the two-pass
+    coefficient of c_correlate.py:39-72: for a launch with a slab the fix kernels run a second time, about the flagged
+    slots' own pivots, into a slab of the re-evaluation (until round 5 such a launch was never re-evaluated).
+    `finite_border`: the zero lag really has border samples to take out (masked border: nothing to take out); odd
+    orders add the pixels whose tap set the sign of wcslib's noise decides (scattered NaN pixels)."""
     from euispice_coreg_amd import _lib
     from oracle import coreg_oracle as O
     rng = np.random.default_rng(8)
-    small, hs, _, hl, _ = H.scene(small_n=64, large_n=96, nan_frac=0.0)
+    small, hs, _, hl, _ = H.scene(small_n=64, large_n=96, nan_frac=0.01)
     small = small.copy()
     small[:8, :8] = np.nan          # the pivot-moving block of the reference sits under masked pixels ...
     if not finite_border:
@@ -850,27 +851,31 @@ def test_ill_conditioned_lag_points_are_re_evaluated_next_to_a_zero_lag_too(gpu_
     ref = 1000.0 + 1.0e-3 * rng.standard_normal(small.shape)
     ref[:6, :6] = -1.0e7            # ... and away from their tap footprints
     lags = ([-2.0, 0.0, 2.0], [-2.0, 0.0, 2.0], None, None, None)
-    st = H.oracle_state(small, hs, ref, hl, lags)
+    st = H.oracle_state(small, hs, ref, hl, lags, order=order)
     want = O.find_best_header_parameters(st, "helioprojective", prepared_reference=ref)[..., 0].reshape(3, 3)
     assert np.isfinite(want).all() and np.abs(want).max() < 0.2  # noise against structure
     ls = _lib.LagSet(*lags)
     gpu_handle.set_small(small)
     gpu_handle.set_reference_on_grid(ref)
-    got = gpu_handle.sweep_helioprojective(hs, hs, ls).reshape(3, 3)
+    got = gpu_handle.sweep_helioprojective(hs, hs, ls, order=order).reshape(3, 3)
     counts = gpu_handle.last_visit_counts()
-    others = np.ones((3, 3), dtype=bool)
-    if finite_border:
-        assert counts["refined_lag_points"] == 8 and counts["flagged_not_refined"] == 1, counts
-        others[1, 1] = False  # the zero lag: one-pass value, flagged -- not held to the tolerance
-    else:
-        assert counts["refined_lag_points"] == 9 and counts["flagged_not_refined"] == 0, counts
-    assert np.abs(got - want)[others].max() <= 1e-7, np.abs(got - want)
+    assert counts["refined_lag_points"] == 9 and counts["flagged_not_refined"] == 0, counts
+    assert np.abs(got - want).max() <= 1e-7, np.abs(got - want)
     gpu_handle.set_option("refine", 0)
     try:
-        raw = gpu_handle.sweep_helioprojective(hs, hs, ls).reshape(3, 3)
+        raw = gpu_handle.sweep_helioprojective(hs, hs, ls, order=order).reshape(3, 3)
     finally:
         gpu_handle.set_option("refine", 1)
     assert not np.nanmax(np.abs(raw - want)) <= 1e-4  # what the one-pass formula gives on these data
+    if finite_border and order == 2:
+        # and the zero lag's noise-decided samples do matter at this level: without them it is off (odd orders: the
+        # single-sample pass then lists the whole zero-lag grid and decides the border with wcslib's coordinates as well)
+        gpu_handle.set_option("border_fix", 0)
+        try:
+            nofix = gpu_handle.sweep_helioprojective(hs, hs, ls, order=order).reshape(3, 3)
+        finally:
+            gpu_handle.set_option("border_fix", 1)
+        assert np.abs(nofix - want)[1, 1] > 1e-7 and np.abs(np.delete((nofix - want).ravel(), 4)).max() <= 1e-7
 
 
 @pytest.mark.parametrize("order", [1, 2, 3])
