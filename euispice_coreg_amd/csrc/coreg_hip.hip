@@ -159,7 +159,9 @@ struct coreg_handle {
     bool small_pending = false;
     DevBuf red_sum_up, red_cnt_up;  // device_mean's scratch on up_stream
     int64_t opt_overlap_upload = 1;
-    int64_t opt_tap_nan_filter = 1;  // odd orders: list only the near-integer samples that can change the result (k_tap_scan)
+    int64_t opt_tap_nan_filter = 2;  // odd orders: list only the near-integer samples that can change the result (k_tap_scan);
+                                     // 1: a non-finite pixel anywhere in the union of the footprints, 2: + the sharper
+                                     // end-line test where one axis only is near an integer, 0: list them all
     // "async_upload" (opt-in: the caller's image buffer must stay valid and unchanged until the next call that reads the
     // image returns): the staging copies + DMA of coreg_set_small_f32 / _fits run on a worker thread of the handle, so that
     // the calling thread goes on to prepare the reference and plan the sweep meanwhile; joined before the first kernel
@@ -1822,7 +1824,7 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, int order, const coreg_wcs2
     a.W = h->sW;
     a.H = h->sH;
     a.order = order;
-    a.nan_filter = h->opt_tap_nan_filter ? 1 : 0;
+    a.nan_filter = (int)h->opt_tap_nan_filter;
     a.seg_list = h->tap_segq.as<uint4>();
     a.seg_count = h->tap_count.as<unsigned>() + 1;
     a.seg_cap = seg_cap;
@@ -2209,7 +2211,8 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
     } else if (n == "clean_path") {
         h->opt_clean_path = value ? 1 : 0;
     } else if (n == "tap_nan_filter") {
-        h->opt_tap_nan_filter = value ? 1 : 0;
+        if (value < 0 || value > 2) return fail(h, COREG_EINVAL, "tap_nan_filter must be 0, 1 or 2");
+        h->opt_tap_nan_filter = value;
     } else if (n == "overlap_upload") {
         h->opt_overlap_upload = value ? 1 : 0;
     } else if (n == "async_upload") {

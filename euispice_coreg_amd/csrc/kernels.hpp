@@ -1995,6 +1995,31 @@ __device__ __forceinline__ bool tap_union_has_nonfinite(const TS* __restrict__ i
     }
     return false;
 }
+// The sharper form for a coordinate that is near an integer k along ONE axis only (the common case: a curve of such
+// pixels under a pure single-axis lag).  Along that axis the two candidate footprints share the `order` taps
+// k - (order-1)/2 .. k + (order-1)/2 and differ in one end tap, k - hw or k + hw (hw = (order+1)/2); along the other
+// axis the taps are fixed (floor(c) - (order-1)/2 .. + order).  The two samples differ in FINITENESS -- the only
+// difference that matters -- exactly when the common block is finite and one end line is not while the other is.
+template <typename TS>
+__device__ __forceinline__ bool tap_end_lines_differ(const TS* __restrict__ img, int W, int H, int k, double c_other,
+                                                     int order, bool near_is_x) {
+    const int hw = (order + 1) / 2, half = (order - 1) / 2;
+    const int o0 = (int)floor(c_other) - half;  // first tap along the other axis (Spline<ORDER>::eval)
+    const int n_near = near_is_x ? W : H, n_other = near_is_x ? H : W;
+    bool end_lo = true, end_hi = true;  // "every pixel of that end line is finite"
+    for (int t = 0; t <= order; ++t) {
+        const int po = mirror_far(o0 + t, n_other);
+        for (int d = -hw; d <= hw; ++d) {
+            const int pn = mirror_far(k + d, n_near);
+            const double v = (double)(near_is_x ? img[(size_t)po * W + pn] : img[(size_t)pn * W + po]);
+            if (isfinite(v)) continue;
+            if (d == -hw) end_lo = false;
+            else if (d == hw) end_hi = false;
+            else return false;  // a common tap is not finite: NaN whichever way the noise falls
+        }
+    }
+    return end_lo != end_hi;
+}
 // One thread per (lag slot, grid row).  Along a row the mapped coordinate is x(i) = (a i + b) / (c i + d): the offsets
 // x - i and y - j are evaluated at the ends of 64-pixel segments and bounded in between by the chord plus
 // max|f''| L^2 / 8 (f'' = 2 c (b c - a d) / (c i + d)^3, bounded over the row); only segments whose bound comes within
@@ -2018,9 +2043,24 @@ __device__ __forceinline__ void tap_scan_pixel(const TapScanArgs& a, const H9& h
         const bool on_bound = fabs(x) < a.tol || fabs(x - a.wmax) < a.tol || fabs(y) < a.tol || fabs(y - a.hmax) < a.tol;
         if (!on_bound) {
             const int mx = (int)rint(x), my = (int)rint(y), hw = (a.order + 1) / 2;
-            const bool nonfinite = a.img_f32 ? tap_union_has_nonfinite((const float*)a.img, a.W, a.H, mx, my, hw)
-                                             : tap_union_has_nonfinite((const double*)a.img, a.W, a.H, mx, my, hw);
-            if (!nonfinite) return;
+            const bool near_x = fabs(x - rint(x)) < a.tol, near_y = fabs(y - rint(y)) < a.tol;
+            bool can_change;
+            if (near_x != near_y && a.nan_filter > 1) {
+                // one axis only, and the other coordinate clear of its own integers by far more than any noise
+                const double co = near_x ? y : x;
+                if (fabs(co - rint(co)) < 1e-3) {
+                    can_change = a.img_f32 ? tap_union_has_nonfinite((const float*)a.img, a.W, a.H, mx, my, hw)
+                                           : tap_union_has_nonfinite((const double*)a.img, a.W, a.H, mx, my, hw);
+                } else {
+                    can_change = a.img_f32
+                        ? tap_end_lines_differ((const float*)a.img, a.W, a.H, near_x ? mx : my, co, a.order, near_x)
+                        : tap_end_lines_differ((const double*)a.img, a.W, a.H, near_x ? mx : my, co, a.order, near_x);
+                }
+            } else {
+                can_change = a.img_f32 ? tap_union_has_nonfinite((const float*)a.img, a.W, a.H, mx, my, hw)
+                                       : tap_union_has_nonfinite((const double*)a.img, a.W, a.H, mx, my, hw);
+            }
+            if (!can_change) return;
         }
     }
     const unsigned k = atomicAdd(a.count, 1u);

@@ -345,8 +345,10 @@ int coreg_last_tap_fix(coreg_handle* h, int64_t* counts3);
  *                  (staging copies + DMA run there while the caller prepares the reference and plans the sweep).  The
  *                  caller's pixel buffer must then stay valid and unchanged until the next call on this handle that reads
  *                  the image (a sweep, coreg_threshold_small, coreg_synchronize, ...) has returned
- *   "tap_nan_filter"  1 (default) the odd-order pass ("tap_fix") lists only the near-integer samples that can change the
- *                  result: on the bounds rule, or with a non-finite pixel in the union of the two tap sets; 0: all of them
+ *   "tap_nan_filter"  2 (default) the odd-order pass ("tap_fix") lists only the near-integer samples that can change the
+ *                  result: on the bounds rule, or -- one axis near an integer -- with the taps the two footprints share
+ *                  all finite and exactly one of the two end lines not, or -- both axes -- with a non-finite pixel in the
+ *                  union of the footprints; 1: the union test everywhere; 0: all near-integer samples
  *   "tap_fix"      1 (default): helioprojective sweeps with an odd spline order re-evaluate, with wcslib's own arithmetic
  *                  on the host, every sample whose mapped coordinate comes back within 1e-8 px of an integer -- there
  *                  the sign of the rounding noise of the reference's round trip (alignment.py:1038-1069) picks the

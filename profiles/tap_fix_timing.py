@@ -54,7 +54,16 @@ def main():
                     res["unfiltered_sweep_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
                     res["unfiltered_samples"] = h.last_tap_fix()["samples"] if "samples" in h.last_tap_fix() else h.last_tap_fix()
                     res["filtered_vs_unfiltered_max"] = float(np.nanmax(np.abs(full - out[1])))
+                    # the round's first filter (a non-finite pixel anywhere in the union of the two footprints), for
+                    # comparison with the end-line test that is the default now
                     h.set_option("tap_nan_filter", 1)
+                    h.sweep_helioprojective(hdr, hdr, lags, order=order)
+                    t0 = time.perf_counter()
+                    union = h.sweep_helioprojective(hdr, hdr, lags, order=order)
+                    res["union_filter_sweep_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+                    res["union_filter_samples"] = h.last_tap_fix()["samples"]
+                    res["union_filter_vs_default_max"] = float(np.nanmax(np.abs(union - out[1])))
+                    h.set_option("tap_nan_filter", 2)
                 print(json.dumps(res), flush=True)
     # serial semantics (parallelism=False: the target is the reference's own, coarser grid -- every 64-pixel segment of
     # the scan spans many integers and is tested pixel by pixel)

@@ -531,7 +531,7 @@ def test_zero_lag_border_pixels_follow_wcslib(gpu_handle):
                                         f"zero lag by the general pass, unfiltered, seed={seed}")
                     assert gpu_handle.last_tap_fix()["samples"] >= 50 * 50
                 finally:
-                    gpu_handle.set_option("tap_nan_filter", 1)
+                    gpu_handle.set_option("tap_nan_filter", 2)
                 gpu_handle.set_option("tap_fix", 0)
             raw = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order)
         finally:
