@@ -107,6 +107,24 @@ def random_call(rng, err, unit_hdr, frame, parallel):
     return ctor, ck
 
 
+def reference_results(entry, corr, ctor):
+    """The reference's own `AlignmentResults` on the map it returned (AlignmentResults.py:24-101 argmax and lag
+    bookkeeping, :218-341 the sub-lag Gaussian fit through scipy 1.7.1's curve_fit): what `return_type='AlignmentResults'`
+    hands the user for this call.  An all-NaN map, or a fit the reference cannot make, is recorded as such."""
+    from euispice_coreg.hdrshift.AlignmentResults import AlignmentResults
+    arr = {k: (None if ctor.get(k) is None else np.asarray(ctor[k], dtype=np.float64))
+           for k in ("lag_crval1", "lag_crval2", "lag_cdelt1", "lag_cdelt2", "lag_crota")}
+    try:
+        res = AlignmentResults(corr=np.array(corr), unit_lag="arcsec", **arr)
+        entry["results"] = {
+            "max_index": [int(v) for v in res.max_index], "shift_pixels": M.jsonable(list(res.shift_pixels)),
+            "shift_arcsec": M.jsonable(list(res.shift_arcsec)),
+            "parameters_alignment_arcsec": {k: M.jsonable(v) for k, v in res.parameters_alignment_arcsec.items()}}
+    except Exception as e:  # noqa: BLE001 -- what it raises IS the fixture
+        entry["results_raises"] = type(e).__name__
+        entry["results_message"] = str(e)[:160]
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="golden_alignment_fuzz_")
     M.ARR.clear()
@@ -125,9 +143,10 @@ def main():
                 # map (kept for scene S01, both branches); the other scenes in degrees go through the TAN chain
                 frame = "helioprojective"
             ctor, ck = random_call(rng, err, unit, frame, par)
-            e = M.run_case(f"{name}_{j}_{frame[:5]}_{'par' if par else 'ser'}_o{ctor['reprojection_order']}", name, paths,
-                           ctor, frame, ck)
+            e_name = f"{name}_{j}_{frame[:5]}_{'par' if par else 'ser'}_o{ctor['reprojection_order']}"
+            e = M.run_case(e_name, name, paths, ctor, frame, ck)
             assert "raises" not in e, e
+            reference_results(e, M.ARR[f"case/{e_name}/corr"], ctor)
     import astropy
     import scipy
     M.META["interpreter"] = {"python": sys.version.split()[0], "numpy": np.__version__, "scipy": scipy.__version__,

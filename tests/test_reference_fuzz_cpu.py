@@ -47,3 +47,49 @@ def test_oracle_reproduces_the_reference_map(name):
     d = np.abs(got - want)
     assert np.nanmax(d) <= _tol(c), f"max |oracle - reference| = {np.nanmax(d):.3e} > {_tol(c):.1e}"
     assert np.nanargmax(got) == np.nanargmax(want)
+
+
+def _with_results():
+    _, m = G.load(F)
+    return sorted(n for n, c in m["cases"].items() if "results" in c)
+
+
+@pytest.mark.parametrize("name", _with_results())
+def test_alignment_results_against_the_reference_object(name):
+    """AlignmentResults.py:24-101, 218-341 on the reference's own map of every random case: the argmax, the sub-lag
+    Gaussian fit (the library's restatement of scipy's bounded TRF and the literal scipy call -- scipy 1.15 here against
+    1.7.1 in the reference run), the lag bookkeeping in arcsec."""
+    from euispice_coreg_amd.hdrshift import AlignmentResults
+    corr, c = G.expected(name, F)
+    ctor, want = c["ctor"], c["results"]
+    lags = {k: ctor.get(k) for k in ("lag_crval1", "lag_crval2", "lag_cdelt1", "lag_cdelt2", "lag_crota")}
+    # a peak the fit places INSIDE the lag window is determined by the points around it: 1e-3 px (measured <= 2.9e-4, both
+    # fits); one it extrapolates beyond the window (3 to 5 lags per axis here) is flat along the way out and the
+    # stopping rule decides: 1e-2 px (measured: the literal scipy call, 1.15 against the reference's 1.7.1, 5.0e-3)
+    sp, shp = want["shift_pixels"], corr.shape
+    inside = all(0.0 <= sp[k] <= shp[k] - 1 for k in (0, 1))
+    tol = 1e-3 if inside else 1e-2
+    step = max(np.diff(ctor["lag_crval1"]).max(), np.diff(ctor["lag_crval2"]).max())
+    for fit in ("native", "scipy"):
+        R = AlignmentResults(corr=corr, unit_lag="arcsec", fit=fit, **lags)
+        assert [int(v) for v in R.max_index] == want["max_index"], fit
+        assert np.allclose(np.asarray(R.shift_pixels, dtype=float), want["shift_pixels"], rtol=0, atol=tol), fit
+        assert np.allclose(np.asarray(R.shift_arcsec, dtype=float), want["shift_arcsec"], rtol=0, atol=tol * step), fit
+        for k, v in want["parameters_alignment_arcsec"].items():
+            assert np.allclose(R.parameters_alignment_arcsec[k], v, rtol=0, atol=1e-9), k
+
+
+def test_alignment_results_of_an_all_nan_map_raise_as_the_reference_does():
+    """The two Carrington-in-degrees maps (quirk Q17) are NaN everywhere: the reference's AlignmentResults raises
+    `ValueError: All-NaN slice encountered` (np.nanargmax, AlignmentResults.py:60-62), and so does this package's."""
+    from euispice_coreg_amd.hdrshift import AlignmentResults
+    _, m = G.load(F)
+    names = sorted(n for n, c in m["cases"].items() if "results_raises" in c)
+    assert names == sorted(CARRINGTON_IN_DEGREES)
+    for name in names:
+        corr, c = G.expected(name, F)
+        assert c["results_raises"] == "ValueError"
+        ctor = c["ctor"]
+        lags = {k: ctor.get(k) for k in ("lag_crval1", "lag_crval2", "lag_cdelt1", "lag_cdelt2", "lag_crota")}
+        with pytest.raises(ValueError):
+            AlignmentResults(corr=corr, unit_lag="arcsec", **lags)
