@@ -114,6 +114,19 @@ struct EventPair {
 
 }  // namespace
 
+// The noise-decided samples of ONE launch as kernel arguments: run once about the global pivots into the
+// launch's extra slab and -- when lag-points of the launch are re-evaluated -- a second time about the flagged slots'
+// own pivots (launch_sweep, coreg_finalize_sums).  The device lists the arguments point to live until the next sweep.
+struct FixLaunch {
+    std::vector<BorderFixArgs> border;
+    std::vector<ParityFixArgs> parity;
+    TapFixArgs tap = {};
+    bool have_tap = false;
+    int tap_segs = 0, tap_mode = 0;
+    bool small_f32 = true;
+    bool empty() const { return border.empty() && parity.empty() && !have_tap; }
+};
+
 struct coreg_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -207,6 +220,7 @@ struct coreg_handle {
         // same sweep have overwritten the compacted points, how to compute them again
         RefineArgs refine;
         std::function<int(coreg_handle*)> replay_precompute;
+        FixLaunch fixes;  // the launch's noise-decided samples, for the second run about the flagged slots' pivots
     };
     std::function<int(coreg_handle*)> last_precompute;  // the precompute launch the next launch_sweep follows
     DevBuf rf_flags, rf_pivots, rf_list, rf_head, rf_partial;  // work space of the re-evaluation (kernels.hpp: RefineArgs)
@@ -1318,6 +1332,42 @@ int launch_refine(coreg_handle* h, const RefineArgs& r0, long long n_slots, cons
     return COREG_OK;
 }
 
+// the fix kernels of one launch (FixLaunch) into `slab`; slot_pivots / only_flagged: the second run (kernels.hpp:
+// BorderFixArgs)
+int launch_fix_kernels(coreg_handle* h, const FixLaunch& fl, double* slab, const double* slot_pivots, const int* only_flagged) {
+    for (BorderFixArgs b : fl.border) {
+        b.slab = slab;
+        b.slot_pivots = slot_pivots;
+        b.only_flagged = only_flagged;
+        if (fl.small_f32) hipLaunchKernelGGL((k_border_fix<float>), dim3(1), dim3(256), 0, h->stream, b);
+        else hipLaunchKernelGGL((k_border_fix<double>), dim3(1), dim3(256), 0, h->stream, b);
+    }
+    for (ParityFixArgs p : fl.parity) {
+        p.slab = slab;
+        p.slot_pivots = slot_pivots;
+        p.only_flagged = only_flagged;
+        if (fl.small_f32) hipLaunchKernelGGL((k_parity_fix<float>), dim3(p.n_partial), dim3(256), 0, h->stream, p);
+        else hipLaunchKernelGGL((k_parity_fix<double>), dim3(p.n_partial), dim3(256), 0, h->stream, p);
+        hipLaunchKernelGGL(k_parity_fix_final, dim3(1), dim3(64), 0, h->stream, p);
+    }
+    if (fl.have_tap) {
+        TapFixArgs t = fl.tap;
+        t.slab = slab;
+        t.slot_pivots = slot_pivots;
+        t.only_flagged = only_flagged;
+        const dim3 tg((unsigned)fl.tap_segs), tb(256);
+        if (fl.tap_mode == MODE_HOMOGRAPHY_SERIES) {
+            if (fl.small_f32) hipLaunchKernelGGL((k_tap_fix<float, MODE_HOMOGRAPHY_SERIES>), tg, tb, 0, h->stream, t);
+            else hipLaunchKernelGGL((k_tap_fix<double, MODE_HOMOGRAPHY_SERIES>), tg, tb, 0, h->stream, t);
+        } else {
+            if (fl.small_f32) hipLaunchKernelGGL((k_tap_fix<float, MODE_HOMOGRAPHY>), tg, tb, 0, h->stream, t);
+            else hipLaunchKernelGGL((k_tap_fix<double, MODE_HOMOGRAPHY>), tg, tb, 0, h->stream, t);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return COREG_OK;
+}
+
 int launch_sweep(coreg_handle* h, int mode, int order, int method, const double* params_dev,
                  const long long* outidx_dev, int n_batches, int n_tiles, long long lag_begin, double* out_dev,
                  const LaunchU* car_inv = nullptr, const BorderFix* fix = nullptr, long long sums_off = 0,
@@ -1453,49 +1503,12 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     h->stats.n_sweep_launches++;
     h->stats.used_lds = a.use_lds;
 
-    // the noise-decided samples of this launch, as kernel arguments: run once about the global pivots into the
-    // extra slab, and -- when lag-points are re-evaluated -- a second time about the flagged slots' own pivots
-    std::vector<BorderFixArgs> border_items;
-    std::vector<ParityFixArgs> parity_items;
-    TapFixArgs tap_item = {};
-    bool have_tap = false;
-    auto launch_fixes = [&](double* slab, const double* slot_pivots, const int* only_flagged) -> int {
-        for (BorderFixArgs b : border_items) {
-            b.slab = slab;
-            b.slot_pivots = slot_pivots;
-            b.only_flagged = only_flagged;
-            if (h->small_f32) hipLaunchKernelGGL((k_border_fix<float>), dim3(1), dim3(256), 0, h->stream, b);
-            else hipLaunchKernelGGL((k_border_fix<double>), dim3(1), dim3(256), 0, h->stream, b);
-        }
-        for (ParityFixArgs p : parity_items) {
-            p.slab = slab;
-            p.slot_pivots = slot_pivots;
-            p.only_flagged = only_flagged;
-            if (h->small_f32) hipLaunchKernelGGL((k_parity_fix<float>), dim3(p.n_partial), dim3(256), 0, h->stream, p);
-            else hipLaunchKernelGGL((k_parity_fix<double>), dim3(p.n_partial), dim3(256), 0, h->stream, p);
-            hipLaunchKernelGGL(k_parity_fix_final, dim3(1), dim3(64), 0, h->stream, p);
-        }
-        if (have_tap) {
-            TapFixArgs t = tap_item;
-            t.slab = slab;
-            t.slot_pivots = slot_pivots;
-            t.only_flagged = only_flagged;
-            const dim3 tg((unsigned)fix->tap_segs), tb(256);
-            if (fix->tap_mode == MODE_HOMOGRAPHY_SERIES) {
-                if (h->small_f32) hipLaunchKernelGGL((k_tap_fix<float, MODE_HOMOGRAPHY_SERIES>), tg, tb, 0, h->stream, t);
-                else hipLaunchKernelGGL((k_tap_fix<double, MODE_HOMOGRAPHY_SERIES>), tg, tb, 0, h->stream, t);
-            } else {
-                if (h->small_f32) hipLaunchKernelGGL((k_tap_fix<float, MODE_HOMOGRAPHY>), tg, tb, 0, h->stream, t);
-                else hipLaunchKernelGGL((k_tap_fix<double, MODE_HOMOGRAPHY>), tg, tb, 0, h->stream, t);
-            }
-        }
-        HIPCHK(hipGetLastError());
-        return COREG_OK;
-    };
-    if (fixing) {
-        // one more slab: zero, except minus the dropped border pixels' totals at the identity lag's slot
-        double* slab = h->partials.as<double>() + (size_t)g_per * kNumSums * n_slots;
-        HIPCHK(hipMemsetAsync(slab, 0, (size_t)kNumSums * n_slots * sizeof(double), h->stream));
+    // the noise-decided samples of this launch as kernel arguments (FixLaunch): built on every rank of a
+    // grid-shared sweep (the re-evaluation of a flagged lag-point runs on every rank), run here -- about the global
+    // pivots, into the extra slab -- on the rank that carries the correction
+    FixLaunch fl;
+    fl.small_f32 = h->small_f32;
+    if (fix && (!fix->items.empty() || fix->tap_segs > 0)) {
         BorderFixArgs b = {};
         b.img = h->small.p;
         b.W = h->sW;
@@ -1536,10 +1549,10 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
                 if (h->fix_partial.reserve((size_t)p.n_partial * kNumSums * sizeof(double)) != hipSuccess)
                     return fail(h, COREG_EHIP, "hipMalloc failed (parity fix)");
                 p.partial = h->fix_partial.as<double>();
-                parity_items.push_back(p);
+                fl.parity.push_back(p);
             }
             if (it.n == 0) continue;
-            border_items.push_back(b);
+            fl.border.push_back(b);
         }
         if (fix->tap_segs > 0) {
             TapFixArgs t = fix->tap;
@@ -1555,10 +1568,17 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
             t.pivots = b.pivots;
             t.hom = params_dev;
             t.n_slots = n_slots;
-            tap_item = t;
-            have_tap = true;
+            fl.tap = t;
+            fl.have_tap = true;
+            fl.tap_segs = fix->tap_segs;
+            fl.tap_mode = fix->tap_mode;
         }
-        RETCHK(launch_fixes(slab, nullptr, nullptr));
+    }
+    if (fixing) {
+        // one more slab: zero, except minus the dropped border pixels' totals at the identity lag's slot
+        double* slab = h->partials.as<double>() + (size_t)g_per * kNumSums * n_slots;
+        HIPCHK(hipMemsetAsync(slab, 0, (size_t)kNumSums * n_slots * sizeof(double), h->stream));
+        RETCHK(launch_fix_kernels(h, fl, slab, nullptr, nullptr));
     }
 
     FinalizeArgs f = {};
@@ -1566,8 +1586,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     // RefineArgs) -- not for method 'residus' (another statistic) and not the lag-points whose noise-decided samples
     // were taken out of (put into) the sums by the extra slab: those keep their one-pass value (FinalizeArgs.fix_slab).
     // Grid shares across GPUs: the flags can only come from the REDUCED sums, so the re-evaluation is run by
-    // coreg_finalize_sums, on every rank, over the whole grid (and not at all for a launch with a slab).
-    const bool fix_any = fix && (!fix->items.empty() || fix->tap_segs > 0);  // (the same on every rank)
+    // coreg_finalize_sums, on every rank, over the whole grid (with the second run of this launch's fix kernels).
     const bool refinable = h->opt_refine && method != COREG_METHOD_RESIDUS;
     RETCHK(fill_refine(h, &f.refine, mode, order, params_dev, a.car_inv, n_slots));
     f.refine.enabled = (refinable && !sharded) ? 1 : 0;
@@ -1598,8 +1617,9 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
         pf.outidx_dev = nullptr;  // set by coreg_finalize_sums from fin_outidx
         pf.residus = method == COREG_METHOD_RESIDUS ? 1 : 0;
         pf.refine = f.refine;
-        pf.refine.enabled = (refinable && !fix_any) ? 1 : 0;  // (the slab is inside the reduced sums: no telling which slots)
+        pf.refine.enabled = refinable ? 1 : 0;
         pf.replay_precompute = h->last_precompute;
+        pf.fixes = fl;  // (the slab is inside the reduced sums; the second run of the fix kernels happens on every rank)
         h->pending_fin.push_back(pf);
     }
     f.n_slots = n_slots;
@@ -1613,7 +1633,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     HIPCHK(hipGetLastError());
     if (f.refine.enabled && f.refine.fix_slab) {
         hipLaunchKernelGGL(k_refine_list, dim3(1), dim3(kListThreads), 0, h->stream, f.refine, n_slots, h->counters.as<long long>());
-        RETCHK(launch_fixes(h->rf_fix_slab.as<double>(), f.refine.slot_pivots, f.refine.flags));
+        RETCHK(launch_fix_kernels(h, fl, h->rf_fix_slab.as<double>(), f.refine.slot_pivots, f.refine.flags));
         RETCHK(launch_refine(h, f.refine, n_slots, outidx_dev, lag_begin, out_dev, false));
     } else if (f.refine.enabled) {
         RETCHK(launch_refine(h, f.refine, n_slots, outidx_dev, lag_begin, out_dev));
@@ -1825,6 +1845,8 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, int order, const coreg_wcs2
     a.H = h->sH;
     a.order = order;
     a.nan_filter = (int)h->opt_tap_nan_filter;
+    a.bounds_only = (order & 1) ? 0 : 1;
+    if (a.bounds_only) a.nan_filter = 0;  // (nothing read from the image to align: no join with its upload either)
     a.seg_list = h->tap_segq.as<uint4>();
     a.seg_count = h->tap_count.as<unsigned>() + 1;
     a.seg_cap = seg_cap;
@@ -3434,7 +3456,12 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     BorderFix fix;
     std::vector<std::vector<unsigned char>> flags_host;  // per noise-decided lag-point (odd spline orders only)
     // odd spline orders: what prepare_tap_fix needs to rebuild a slot's shifted header
-    const bool tap_fixing = h->opt_tap_fix && (order & 1) && (h->opt_shard_world <= 1 || h->opt_shard_rank == 0);
+    // (grid shares across GPUs: every rank lists the samples -- the re-evaluation of a flagged lag-point needs them on
+    // every rank; the correction itself is launched on rank 0 only, launch_sweep)
+    // Odd orders: every sample within 1e-8 px of an integer coordinate (the sign of wcslib's noise picks the taps); even
+    // orders: only those within 1e-8 px of a BOUND of the image (the sign decides the bounds rule) -- a pure CRVAL1 or
+    // CRVAL2 lag under an unrotated header keeps whole border rows / columns of the grid there.
+    const bool tap_fixing = h->opt_tap_fix != 0;
     std::vector<coreg_wcs2d> tap_combo;      // the (cdelt, crota)-shifted header of each combination
     std::vector<int> tap_slot_combo, tap_slot_i1, tap_slot_i2;
     std::vector<unsigned char> tap_skip;     // padding lanes and lag-points the structured fix handles
@@ -3735,7 +3762,15 @@ int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device,
             RETCHK(pf.replay_precompute(h));
             points_of = ip;
         }
-        RETCHK(launch_refine(h, rf, pf.n_slots, f.out_index, pf.lag_begin, out_dev, false));
+        RefineArgs rf2 = rf;
+        if (!pf.fixes.empty()) {
+            // the launch's noise-decided samples about the flagged slots' own pivots (as launch_sweep does on one GPU)
+            HIPCHK(h->rf_fix_slab.reserve((size_t)kNumSums * pf.n_slots * sizeof(double)));
+            HIPCHK(hipMemsetAsync(h->rf_fix_slab.p, 0, (size_t)kNumSums * pf.n_slots * sizeof(double), h->stream));
+            rf2.fix_slab = h->rf_fix_slab.as<double>();
+            RETCHK(launch_fix_kernels(h, pf.fixes, h->rf_fix_slab.as<double>(), rf.slot_pivots, rf.flags));
+        }
+        RETCHK(launch_refine(h, rf2, pf.n_slots, f.out_index, pf.lag_begin, out_dev, false));
     }
     HIPCHK(hipGetLastError());
     if (!out_on_device && n_out > 0) {

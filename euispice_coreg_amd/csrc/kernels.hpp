@@ -1972,6 +1972,9 @@ struct TapScanArgs {
     // footprints ((order + 2)^2 pixels around the nearest pixel, edges mirrored), are listed for wcslib's chain.
     const void* img;
     int img_f32, W, H, order, nan_filter;
+    // even spline orders: the taps do not depend on which side of an integer the coordinate falls, the BOUNDS rule does
+    // (c < 0 or c > n - 1, Util.py:98-102) -- 1: list only the samples within `tol` of a bound of the image
+    int bounds_only;
     // Round 5: a thread of k_tap_scan owns (lag slot, rows) and used to test the pixels of every segment it could not
     // dismiss by itself -- for the pure CRVAL1 / CRVAL2 lags of an unrotated header that is whole columns of pixels walked
     // by a handful of lanes.  Such segments are now queued (slot, row, first pixel) and tested by k_tap_scan_segments, one
@@ -2039,8 +2042,9 @@ __device__ __forceinline__ void tap_scan_pixel(const TapScanArgs& a, const H9& h
     const int inr = (int)(x >= -a.tol) & (int)(x <= a.wmax + a.tol) & (int)(y >= -a.tol) & (int)(y <= a.hmax + a.tol);
     const int near = (int)(fabs(x - rint(x)) < a.tol) | (int)(fabs(y - rint(y)) < a.tol);
     if (!(inr & near)) return;
-    if (a.nan_filter) {
-        const bool on_bound = fabs(x) < a.tol || fabs(x - a.wmax) < a.tol || fabs(y) < a.tol || fabs(y - a.hmax) < a.tol;
+    const bool on_bound = fabs(x) < a.tol || fabs(x - a.wmax) < a.tol || fabs(y) < a.tol || fabs(y - a.hmax) < a.tol;
+    if (a.bounds_only && !on_bound) return;
+    if (a.nan_filter && !a.bounds_only) {
         if (!on_bound) {
             const int mx = (int)rint(x), my = (int)rint(y), hw = (a.order + 1) / 2;
             const bool near_x = fabs(x - rint(x)) < a.tol, near_y = fabs(y - rint(y)) < a.tol;
@@ -2108,6 +2112,20 @@ __global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
         const bool sane = dmin > 0.5 && bulge_x < 0.25 && bulge_y < 0.25;  // else: every segment is tested
         double x0, y0;
         apply_map<MODE>(hm, cu, (double)a.i_lo, dj, x0, y0);
+        {
+            // the whole row first, with the same chord + curvature bound over its full length: a generic lag keeps the
+            // offsets within 1e-3 px of "lag in pixels" along the row and the row is dismissed by its two end points
+            const double lr = (double)(a.i_hi - a.i_lo);
+            const double row_bx = 1.25 * f2x * lr * lr / 8.0 + 1e-12 + a.tol, row_by = 1.25 * f2y * lr * lr / 8.0 + 1e-12 + a.tol;
+            if (dmin > 0.5 && row_bx < 0.25 && row_by < 0.25) {
+                double xe, ye;
+                apply_map<MODE>(hm, cu, last, dj, xe, ye);
+                const double gx0 = x0 - (double)a.i_lo, gx1 = xe - last, gy0 = y0 - dj, gy1 = ye - dj;
+                const double rxlo = fmin(gx0, gx1) - row_bx, rxhi = fmax(gx0, gx1) + row_bx;
+                const double rylo = fmin(gy0, gy1) - row_by, ryhi = fmax(gy0, gy1) + row_by;
+                if (ceil(rxlo) > rxhi && ceil(rylo) > ryhi) continue;  // no integer offset anywhere along this row
+            }
+        }
         for (int i0 = a.i_lo; i0 <= a.i_hi; i0 += L) {
             const int i1 = min(i0 + L, a.i_hi);
             double x1, y1;
@@ -2117,7 +2135,14 @@ __global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
             const double ylo = fmin(fy0, fy1) - bulge_y, yhi = fmax(fy0, fy1) + bulge_y;
             // an integer inside [lo, hi]?  (negated comparisons: a NaN coordinate tests the segment, whose pixels then
             // fail the range test one by one)
-            const bool hit = !sane || !(ceil(xlo) > xhi) || !(ceil(ylo) > yhi);
+            bool hit = !sane || !(ceil(xlo) > xhi) || !(ceil(ylo) > yhi);
+            if (hit && sane && a.bounds_only) {
+                // even orders: only a BOUND of the image inside the segment's coordinate range matters
+                const double cxlo = fmin(x0, x1) - bulge_x, cxhi = fmax(x0, x1) + bulge_x;
+                const double cylo = fmin(y0, y1) - bulge_y, cyhi = fmax(y0, y1) + bulge_y;
+                hit = (cxlo <= 0.0 && cxhi >= 0.0) || (cxlo <= a.wmax && cxhi >= a.wmax) || (cylo <= 0.0 && cyhi >= 0.0) ||
+                      (cylo <= a.hmax && cyhi >= a.hmax);
+            }
             if (hit) {
                 const int iend = (i0 + L > a.i_hi) ? a.i_hi + 1 : i1;  // (the shared end point belongs to the next segment)
                 const unsigned q = a.seg_list ? atomicAdd(a.seg_count, 1u) : a.seg_cap;

@@ -463,10 +463,11 @@ class Alignment:
             h.drop_small_keepalive()  # (every sweep has returned: the upload thread is done with the pixels)
         if use_all:
             self.last_sharding = h.last_mode
-        elif int(self.order) % 2 == 1 and self.coordinate_frame != "final_carrington" and hasattr(h, "last_tap_fix"):
-            #  odd spline orders: samples whose coordinate comes back within 1e-8 px of an integer are
-            # re-evaluated with wcslib's own arithmetic; a list beyond "tap_cap" entries is not applied -- say so
+        elif self.coordinate_frame != "final_carrington" and hasattr(h, "last_tap_fix"):
+            #  samples whose coordinate comes back within 1e-8 px of an integer (odd spline orders) or of a
+            # bound of the image (even orders) are re-evaluated with wcslib's own arithmetic; a list beyond "tap_cap"
+            # entries is not applied -- say so
             if h.last_tap_fix()["overflow"]:
-                warnings.warn("more noise-decided samples than the library's 'tap_cap': isolated lag-points of this odd-order "
+                warnings.warn("more noise-decided samples than the library's 'tap_cap': isolated lag-points of this "
                               "sweep may differ from the reference by up to 1e-5 (raise it with set_option('tap_cap', n))")
         return out

@@ -349,11 +349,14 @@ int coreg_last_tap_fix(coreg_handle* h, int64_t* counts3);
  *                  result: on the bounds rule, or -- one axis near an integer -- with the taps the two footprints share
  *                  all finite and exactly one of the two end lines not, or -- both axes -- with a non-finite pixel in the
  *                  union of the footprints; 1: the union test everywhere; 0: all near-integer samples
- *   "tap_fix"      1 (default): helioprojective sweeps with an odd spline order re-evaluate, with wcslib's own arithmetic
- *                  on the host, every sample whose mapped coordinate comes back within 1e-8 px of an integer -- there
- *                  the sign of the rounding noise of the reference's round trip (alignment.py:1038-1069) picks the
- *                  taps, hence which neighbour's NaN poisons the sample (one scan kernel before the sweep, one
- *                  correction kernel after it; orders 0, 2, 4 never pay for it); 0: the homography's coordinate decides
+ *   "tap_fix"      1 (default): helioprojective sweeps re-evaluate, with wcslib's own arithmetic on the host, the samples
+ *                  whose fate hangs on the sign of the rounding noise of the reference's round trip
+ *                  (alignment.py:1038-1069).  Odd spline orders: every sample whose mapped coordinate comes back within
+ *                  1e-8 px of an integer -- the sign picks the taps, hence which neighbour's NaN poisons the sample.
+ *                  Even orders: only those within 1e-8 px of a BOUND of the image -- the sign decides the bounds rule
+ *                  c < 0 or c > n - 1 (a pure CRVAL1 / CRVAL2 lag under an unrotated header keeps whole border rows /
+ *                  columns of the grid there).  One scan kernel before the sweep (0.1-0.2 ms on a 2048^2 grid x 3721
+ *                  lags), one correction kernel after it when anything was listed; 0: the homography's coordinate decides
  *   "tap_cap"      2^24 (default): most samples listed per sweep; beyond it nothing is applied (coreg_last_tap_fix)
  *   "tile_w"       0 (default, auto) or a power of two in [4, 256]: grid-tile width in points (tile = 1024 pts)
  *   "n_groups"     0 (default, auto): tile groups (partial-sum slabs) per lag batch

@@ -337,12 +337,18 @@ def test_cfg2_helioprojective_61x61_full_size(gpu_handle, big_scene):
     finally:
         gpu_handle.set_option("use_lds", 1)
     assert np.abs(glob - full[::4, ::4]).max() <= 1e-12
-    # without the wcslib border decision only the zero lag moves, and by less than 1e-4
+    # without the zero-lag machinery the bounds pass of even orders ("tap_fix": samples within 1e-8 px of a bound of the
+    # image, decided with wcslib's chain) lists the zero lag's border pixels itself and gives the same map ...
     gpu_handle.set_option("border_fix", 0)
     try:
+        by_pass = gpu_handle.sweep_helioprojective(hs, hs, ls).reshape(61, 61)
+        assert gpu_handle.last_tap_fix()["samples"] >= 4 * 2048 - 4 and np.abs(by_pass - full).max() <= 1e-9
+        # ... and without any wcslib decision only the zero lag moves, by less than 1e-4
+        gpu_handle.set_option("tap_fix", 0)
         raw = gpu_handle.sweep_helioprojective(hs, hs, ls).reshape(61, 61)
     finally:
         gpu_handle.set_option("border_fix", 1)
+        gpu_handle.set_option("tap_fix", 1)
     d = np.abs(raw - full)
     assert 0.0 < d[30, 30] < 1e-4
     d[30, 30] = 0.0
@@ -359,10 +365,12 @@ def test_zero_lag_full_size_measured(gpu_handle, big_scene):
     lags = (np.array([-1.0, 0.0, 17.0]), np.array([-9.0, 0.0, 1.0]), None, None, None)
     got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags)
     gpu_handle.set_option("border_fix", 0)
+    gpu_handle.set_option("tap_fix", 0)  # (the bounds pass of even orders would decide the border by itself)
     try:
         raw = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, prepare=False)
     finally:
         gpu_handle.set_option("border_fix", 1)
+        gpu_handle.set_option("tap_fix", 1)
     st = H.oracle_state(small, hs, large, hl, lags)
     O.set_initial_header_values(st)
     sub = O.create_submap_of_large_data(st)

@@ -97,3 +97,27 @@ def test_single_samples_decided_by_wcslib_noise(gpu_handle, seed, scale, orders,
     assert gpu_handle.last_tap_fix()["samples"] == 0
     assert 0.5 * before < np.nanmax(np.abs(raw - want)) < 2.0 * before
     assert (np.abs(raw - got) > 0).sum() <= 4  # (the lag-point concerned, and its no-op CDELT1 twin)
+
+
+def test_border_rows_decided_by_wcslib_noise_at_an_even_order(gpu_handle):
+    """The case the closing fuzz run of round 5 met (seed 621381 of 5 000; 130 000 earlier cases had not): order 2, an
+    unrotated header and a pure CRVAL1 lag keep the FIRST ROW of the grid within 7e-9 px of the image's bound y = 0 --
+    below and above it along the row -- so that the bounds rule (c < 0, Util.py:98-102) is decided by the sign of wcslib's
+    rounding noise for the pixels around the crossing; the exact homography drops 31 pixels of that row, wcslib 30.  Even
+    orders now run the bounds half of the single-sample pass ("tap_fix": samples within 1e-8 px of a bound re-evaluated
+    with wcslib's chain): within the tolerance, and 2.2e-5 off when the pass is switched off."""
+    from tests import deep_fuzz as DF
+    c = DF.build_case(621381, 1, [1, 2, 3], True)
+    assert c["frame"] == "helio" and c["order"] == 2 and c["hs"]["CROTA"] == 0.0 and not c["serial"]
+    sem = 0 if c["sem"] == "intended" else 1
+    want = H.oracle_helio(c["small"], c["hs"], c["large"], c["hl"], c["lags"], order=2, cdelt_semantics=c["sem"])
+    got = H.gpu_helio(gpu_handle, c["small_up"], c["hs"], c["large_up"], c["hl"], c["lags"], order=2, cdelt_semantics=sem)
+    tf = gpu_handle.last_tap_fix()
+    H.assert_corr_close(got, want, 1e-7, "seed=621381")
+    assert np.nanmax(np.abs(got - want)) < 1e-9 and 0 < tf["samples"] < 2000 and not tf["overflow"]
+    gpu_handle.set_option("tap_fix", 0)
+    try:
+        raw = H.gpu_helio(gpu_handle, c["small_up"], c["hs"], c["large_up"], c["hl"], c["lags"], order=2, cdelt_semantics=sem)
+    finally:
+        gpu_handle.set_option("tap_fix", 1)
+    assert 1e-5 < np.nanmax(np.abs(raw - want)) < 5e-5 and (np.abs(raw - got) > 0).sum() <= 2

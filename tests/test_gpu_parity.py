@@ -532,7 +532,12 @@ def test_zero_lag_border_pixels_follow_wcslib(gpu_handle):
                     assert gpu_handle.last_tap_fix()["samples"] >= 50 * 50
                 finally:
                     gpu_handle.set_option("tap_nan_filter", 2)
-                gpu_handle.set_option("tap_fix", 0)
+            else:
+                # even orders: the bounds pass (samples within 1e-8 px of a bound of the image) does the same
+                H.assert_corr_close(H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order), want, 1e-7,
+                                    f"zero lag by the bounds pass, seed={seed}")
+                assert gpu_handle.last_tap_fix()["samples"] >= 4 * 50 - 4
+            gpu_handle.set_option("tap_fix", 0)
             raw = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order)
         finally:
             gpu_handle.set_option("border_fix", 1)
@@ -867,14 +872,30 @@ def test_ill_conditioned_lag_points_are_re_evaluated_next_to_a_zero_lag_too(gpu_
     finally:
         gpu_handle.set_option("refine", 1)
     assert not np.nanmax(np.abs(raw - want)) <= 1e-4  # what the one-pass formula gives on these data
-    if finite_border and order == 2:
-        # and the zero lag's noise-decided samples do matter at this level: without them it is off (odd orders: the
-        # single-sample pass then lists the whole zero-lag grid and decides the border with wcslib's coordinates as well)
+    # grid shares across GPUs (two and three ranks, emulated on this handle): the flags come from the REDUCED sums,
+    # every rank re-evaluates over the whole grid and runs the launch's fix kernels a second time itself
+    for world in (2, 3):
+        total = None
+        try:
+            for r in range(world):
+                gpu_handle.set_point_shard(r, world)
+                gpu_handle.sweep_helioprojective(hs, hs, ls, order=order)
+                part = gpu_handle.copy_sums()
+                total = part if total is None else total + part
+            shared = gpu_handle.finalize_sums(total, ls.size).reshape(3, 3)
+        finally:
+            gpu_handle.set_point_shard(0, 1)
+        assert gpu_handle.last_visit_counts()["refined_lag_points"] == 9
+        assert np.abs(shared - want).max() <= 1e-7 and np.abs(shared - got).max() <= 1e-10, (world, np.abs(shared - got))
+    if finite_border:
+        # and the zero lag's noise-decided samples do matter at this level: without them it is off
         gpu_handle.set_option("border_fix", 0)
+        gpu_handle.set_option("tap_fix", 0)
         try:
             nofix = gpu_handle.sweep_helioprojective(hs, hs, ls, order=order).reshape(3, 3)
         finally:
             gpu_handle.set_option("border_fix", 1)
+            gpu_handle.set_option("tap_fix", 1)
         assert np.abs(nofix - want)[1, 1] > 1e-7 and np.abs(np.delete((nofix - want).ravel(), 4)).max() <= 1e-7
 
 
