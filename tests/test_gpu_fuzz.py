@@ -121,3 +121,31 @@ def test_border_rows_decided_by_wcslib_noise_at_an_even_order(gpu_handle):
     finally:
         gpu_handle.set_option("tap_fix", 1)
     assert 1e-5 < np.nanmax(np.abs(raw - want)) < 5e-5 and (np.abs(raw - got) > 0).sum() <= 2
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("cdelt_sign", [1.0, -1.0])
+def test_lags_of_whole_pixels_under_an_unrotated_header(gpu_handle, order, cdelt_sign):
+    """A class the random generator does not draw: CRVAL lags that are whole multiples of CDELT under an unrotated header
+    (a SPICE raster swept in steps of its own 4-arcsec pixel).  Rows map to rows and columns to columns shifted by whole
+    pixels, up to the field distortion of the tangent-plane round trip: every coordinate comes back within 1e-6 .. 1e-9 px
+    of an integer, whole rows and columns sit on or near the bounds rule, and for every one of them the sign of wcslib's
+    noise decides (odd orders: the taps; every order: the bounds).  Sub-map and full-grid semantics against the oracle,
+    whose coordinates near integers / bounds are wcslib's bit for bit."""
+    from euispice_coreg_amd import synthetic
+    rng = np.random.default_rng(77 + order)
+    small, hs, large, hl, _ = synthetic.make_scene(small_shape=(54, 46), small_cdelt=(20.0, 18.0), large_n=112, seed=4,
+                                                   n_blobs=90, nan_frac=0.02, pointing_error=(40.0, -36.0, 0.0))
+    hs = dict(hs)
+    hs["CDELT1"] *= cdelt_sign
+    hs.update(CROTA=0.0, PC1_1=1.0, PC1_2=0.0, PC2_1=0.0, PC2_2=1.0)
+    l1 = np.array([-2, -1, 0, 1, 3]) * abs(hs["CDELT1"])
+    l2 = np.array([-2, 0, 1, 2]) * hs["CDELT2"]
+    lags = (l1, l2, None, None, None)
+    for serial in (False, True):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            want = H.oracle_helio(small, hs, large, hl, lags, order=order, parallelism=not serial)
+        got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=order, serial_semantics=serial)
+        H.assert_corr_close(got, want, 1e-7, f"whole-pixel lags, order {order}, serial {serial}")
+        if not serial:
+            assert gpu_handle.last_tap_fix()["samples"] > 0
