@@ -132,14 +132,9 @@ def test_fuzz_car(gpu_handle, seed):
     H.assert_corr_close(got, want, 1e-7, f"fuzz CAR seed={seed}")
 
 
-@pytest.mark.parametrize("seed", list(range(500, 512)))
-def test_fuzz_initial_carrington_sub_map_semantics_with_the_identity_lag(gpu_handle, seed):
-    """Random pairs of Carrington maps through the semantics `align_using_initial_carrington` really has (round 5: the
-    sub-map of alignment.py:987-1016 in both branches -- reference map resampled once on the grid of the map to align by
-    `coreg_prepare_reference_helioprojective` with two CAR headers, every lag on that grid), lag axes THROUGH exactly
-    zero: the identity lag-point is swept with the exact identity map and wcslib's CAR chain decides its border pixels
-    (and, for order 1, the tap set of every pixel).  Rolls, unequal / negative pixel sizes, both hemispheres, explicit
-    LONPOLE, NaN pixels, both spline orders; against the oracle's frame "initial_carrington"."""
+def _sub_map_case(gpu_handle, seed):
+    """One random pair of Carrington maps through the sub-map semantics, lag axes through exactly zero: (GPU map, oracle
+    map, lags, order, header of the map to align)."""
     from euispice_coreg_amd import _lib, synthetic
     from oracle import coreg_oracle as O
     rng = np.random.default_rng(seed)
@@ -171,7 +166,40 @@ def test_fuzz_initial_carrington_sub_map_semantics_with_the_identity_lag(gpu_han
     st = H.oracle_state(small.astype(np.float64), hs, large.astype(np.float64), hl, lags, order=order, unit_lag="deg")
     want = O.find_best_header_parameters(st, "initial_carrington", use_ang2pipi=False)
     assert np.isfinite(want).any()
+    return got, want, lags, order, hs
+
+
+@pytest.mark.parametrize("seed", list(range(500, 512)))
+def test_fuzz_initial_carrington_sub_map_semantics_with_the_identity_lag(gpu_handle, seed):
+    """Random pairs of Carrington maps through the semantics `align_using_initial_carrington` really has (round 5: the
+    sub-map of alignment.py:987-1016 in both branches -- reference map resampled once on the grid of the map to align by
+    `coreg_prepare_reference_helioprojective` with two CAR headers, every lag on that grid), lag axes THROUGH exactly
+    zero: the identity lag-point is swept with the exact identity map and wcslib's CAR chain decides its border pixels
+    (and, for order 1, the tap set of every pixel).  Rolls, unequal / negative pixel sizes, both hemispheres, explicit
+    LONPOLE, NaN pixels, both spline orders; against the oracle's frame "initial_carrington"."""
+    got, want, lags, order, _ = _sub_map_case(gpu_handle, seed)
     H.assert_corr_close(got, want, 1e-7, f"CAR sub-map fuzz seed={seed} order={order}")
+
+
+@pytest.mark.parametrize("seed", [1143, 1325, 1403, 1412, 1934])
+def test_known_deviation_pure_latitude_lags_of_unrotated_carrington_maps_at_order_1(gpu_handle, seed):
+    """What tests/deep_fuzz_car.py met at the end of round 5 (5 of 3 000 cases) and the round did NOT close: two UNROTATED
+    Carrington maps, an odd spline order, and a lag in CRVAL2 alone.  Columns then map to columns -- x' comes back within
+    wcslib's rounding noise of the integer i for every pixel -- and the sign of that noise picks the taps of the order-1
+    spline, hence which neighbour's NaN poisons the sample.  The helioprojective sweeps re-evaluate such samples with
+    wcslib's chain; the plate-carree sweep does so for its identity lag only.  Stated, bounded and kept
+    visible here: only lag-points of that kind deviate, by less than 1e-4; every other lag-point of the same sweeps is
+    within the tolerance.  (Round 6: the single-sample pass for MODE_CAR.)"""
+    got, want, lags, order, hs = _sub_map_case(gpu_handle, seed)
+    assert order == 1 and hs["CROTA"] == 0.0
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    d = np.abs(got - want)[..., 0]
+    l1, l2, lr = lags[0], lags[1], np.asarray(lags[4])
+    kind = (l1[:, None, None, None, None] == 0.0) & (l2[None, :, None, None, None] != 0.0) & \
+           (lr[None, None, None, None, :] == 0.0)
+    kind = np.broadcast_to(kind, d.shape)
+    assert d[~kind].max() <= 1e-7, d
+    assert 1e-7 < d[kind].max() < 1e-4, d
 
 
 def test_car_invalid_target_header_is_an_error(gpu_handle):
