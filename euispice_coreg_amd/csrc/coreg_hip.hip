@@ -1356,7 +1356,10 @@ int launch_fix_kernels(coreg_handle* h, const FixLaunch& fl, double* slab, const
         t.slot_pivots = slot_pivots;
         t.only_flagged = only_flagged;
         const dim3 tg((unsigned)fl.tap_segs), tb(256);
-        if (fl.tap_mode == MODE_HOMOGRAPHY_SERIES) {
+        if (fl.tap_mode == MODE_CAR) {
+            if (fl.small_f32) hipLaunchKernelGGL((k_tap_fix<float, MODE_CAR>), tg, tb, 0, h->stream, t);
+            else hipLaunchKernelGGL((k_tap_fix<double, MODE_CAR>), tg, tb, 0, h->stream, t);
+        } else if (fl.tap_mode == MODE_HOMOGRAPHY_SERIES) {
             if (fl.small_f32) hipLaunchKernelGGL((k_tap_fix<float, MODE_HOMOGRAPHY_SERIES>), tg, tb, 0, h->stream, t);
             else hipLaunchKernelGGL((k_tap_fix<double, MODE_HOMOGRAPHY_SERIES>), tg, tb, 0, h->stream, t);
         } else {
@@ -1620,6 +1623,12 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
         pf.refine.enabled = refinable ? 1 : 0;
         pf.replay_precompute = h->last_precompute;
         pf.fixes = fl;  // (the slab is inside the reduced sums; the second run of the fix kernels happens on every rank)
+        // a plate-carree sweep has one launch per combination and every launch lists its single samples anew: the lists
+        // of an earlier launch are gone when coreg_finalize_sums runs -- such a launch is not re-evaluated
+        if (mode == MODE_CAR && fl.have_tap) {
+            pf.refine.enabled = 0;
+            pf.fixes = FixLaunch();
+        }
         h->pending_fin.push_back(pf);
     }
     f.n_slots = n_slots;
@@ -1816,8 +1825,10 @@ int upload_border_pixels(coreg_handle* h, const std::vector<int>& pixels) {
 // workgroup per slot adds its entries in a fixed order.  A list beyond "tap_cap" entries (a pure CRVAL1 / CRVAL2 lag set
 // under an unrotated header at full size) is not applied at all -- recorded in tap_last, coreg_last_tap_fix.
 template <typename ShiftedOf>
+// `hom_dev`: the launch's lane parameters (null: the handle's whole buffer); `car_inv` / `car_fwd`: MODE_CAR launches.
 int prepare_tap_fix(coreg_handle* h, int sweep_mode, int order, const coreg_wcs2d& target, long long n_slots,
-                    const std::vector<unsigned char>& skip, const double box[4], ShiftedOf shifted_of, BorderFix* fix) {
+                    const std::vector<unsigned char>& skip, const double box[4], ShiftedOf shifted_of, BorderFix* fix,
+                    const double* hom_dev = nullptr, const LaunchU* car_inv = nullptr, const LaunchU* car_fwd = nullptr) {
     // the list starts small (64 K entries, or what an earlier sweep needed) and is grown -- and the scan repeated --
     // only when a sweep lists more, up to "tap_cap"
     const unsigned cap_max = (unsigned)h->opt_tap_cap;
@@ -1829,7 +1840,11 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, int order, const coreg_wcs2
     HIPCHK(h->tap_skip.reserve((size_t)n_slots));
     HIPCHK(hipMemcpyAsync(h->tap_skip.p, skip.data(), (size_t)n_slots, hipMemcpyHostToDevice, h->stream));
     TapScanArgs a;
-    a.hom = h->lane_params.as<double>();
+    std::memset(&a.cu, 0, sizeof(a.cu));
+    std::memset(&a.fwd, 0, sizeof(a.fwd));
+    if (car_inv) a.cu = *car_inv;
+    if (car_fwd) a.fwd = *car_fwd;
+    a.hom = hom_dev ? hom_dev : h->lane_params.as<double>();
     a.n_slots = n_slots;
     a.skip = h->tap_skip.as<unsigned char>();
     a.ref = h->ref.p;
@@ -1871,7 +1886,10 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, int order, const coreg_wcs2
         a.list = h->tap_list.as<uint2>();
         a.cap = cap;
         HIPCHK(hipMemsetAsync(h->tap_count.p, 0, 2 * sizeof(unsigned), h->stream));
-        if (sweep_mode == MODE_HOMOGRAPHY_SERIES) {
+        if (sweep_mode == MODE_CAR) {
+            hipLaunchKernelGGL((k_tap_scan<MODE_CAR>), grid, dim3(256), 0, h->stream, a);
+            hipLaunchKernelGGL((k_tap_scan_segments<MODE_CAR>), dim3(2048), dim3(256), 0, h->stream, a);
+        } else if (sweep_mode == MODE_HOMOGRAPHY_SERIES) {
             hipLaunchKernelGGL((k_tap_scan<MODE_HOMOGRAPHY_SERIES>), grid, dim3(256), 0, h->stream, a);
             hipLaunchKernelGGL((k_tap_scan_segments<MODE_HOMOGRAPHY_SERIES>), dim3(2048), dim3(256), 0, h->stream, a);
         } else {
@@ -1911,15 +1929,25 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, int order, const coreg_wcs2
     const int n_seg = (int)seg_slot.size();
     std::vector<double> xw(count), yw(count);
     WcslibTan wf;
-    wf.init(target);
+    WcslibCar wfc;
+    const bool car = target.proj == COREG_PROJ_CAR;
+    if (car) wfc.init(target);
+    else wf.init(target);
     const int gw = h->gW;
     auto work = [&](int s0, int s1) {
         for (int sg = s0; sg < s1; ++sg) {
             std::sort(pixel.begin() + seg_begin[sg], pixel.begin() + seg_begin[sg + 1]);
-            WcslibTan wt;
-            wt.init(shifted_of(seg_slot[sg]));
-            for (int e = seg_begin[sg]; e < seg_begin[sg + 1]; ++e)
-                wcslib_pixel_to_pixel(wf, wt, (double)(pixel[e] % (unsigned)gw), (double)(pixel[e] / (unsigned)gw), &xw[e], &yw[e]);
+            if (car) {
+                WcslibCar wt;
+                wt.init(shifted_of(seg_slot[sg]));
+                for (int e = seg_begin[sg]; e < seg_begin[sg + 1]; ++e)
+                    wcslib_pixel_to_pixel(wfc, wt, (double)(pixel[e] % (unsigned)gw), (double)(pixel[e] / (unsigned)gw), &xw[e], &yw[e]);
+            } else {
+                WcslibTan wt;
+                wt.init(shifted_of(seg_slot[sg]));
+                for (int e = seg_begin[sg]; e < seg_begin[sg + 1]; ++e)
+                    wcslib_pixel_to_pixel(wf, wt, (double)(pixel[e] % (unsigned)gw), (double)(pixel[e] / (unsigned)gw), &xw[e], &yw[e]);
+            }
         }
     };
     unsigned nt = std::min<unsigned>(12, std::max(1u, std::thread::hardware_concurrency()));
@@ -1958,6 +1986,8 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, int order, const coreg_wcs2
     fix->tap.pixel = h->tap_pixel.as<unsigned>();
     fix->tap.xw = h->tap_xw.as<double>();
     fix->tap.yw = h->tap_yw.as<double>();
+    fix->tap.cu = a.cu;
+    fix->tap.fwd = a.fwd;
     h->tap_last[1] = n_seg;
     return COREG_OK;
 }
@@ -3214,6 +3244,14 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
         int n_batches;
         LaunchU inv;
         bool identity;  // the one-slot launch of the identity lag-point (below)
+        // the single-sample pass of this launch: the combination's header, the CRVAL lag indices of its
+        // slots, and the slots the scan skips -- all but the lags that keep an image axis invariant (a lag in CRVAL1 alone
+        // or in CRVAL2 alone against the target header, same CDELT / PCi_j): only those bring whole rows or columns of
+        // coordinates back within wcslib's noise of integers
+        coreg_wcs2d hc;
+        std::vector<int> i1, i2;
+        std::vector<unsigned char> tap_skip;
+        bool tap_any = false;
     };
     std::vector<Launch> launches;
     std::vector<double> params;  // per launch: SoA [9][slots of the launch]
@@ -3277,7 +3315,21 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
             const double* r = &rot[((size_t)(slots.i1[s] - i1_lo) * d.n2 + slots.i2[s]) * 9];
             for (int k = 0; k < 9; ++k) params[pbase + (size_t)k * ns + s] = pad ? nanv : r[k];
             if (!pad && r[8] == r[8]) L.inv.pole_sep = std::max(L.inv.pole_sep, car_pole_sep(r));
+            unsigned char skip = 1;
+            if (!pad && h->opt_tap_fix && r[8] == r[8] && h->gW == h->sW && h->gH == h->sH) {
+                const coreg_wcs2d hl = shifted(hc, slots.i1[s], slots.i2[s]);
+                const bool same_scale = hl.cdelt1 == hdr_target->cdelt1 && hl.cdelt2 == hdr_target->cdelt2 &&
+                                        hl.pc1_1 == hdr_target->pc1_1 && hl.pc1_2 == hdr_target->pc1_2 &&
+                                        hl.pc2_1 == hdr_target->pc2_1 && hl.pc2_2 == hdr_target->pc2_2 &&
+                                        hl.crpix1 == hdr_target->crpix1 && hl.crpix2 == hdr_target->crpix2;
+                if (same_scale && (hl.crval1 == hdr_target->crval1 || hl.crval2 == hdr_target->crval2)) skip = 0;
+            }
+            L.tap_skip.push_back(skip);
+            L.tap_any = L.tap_any || !skip;
         }
+        L.hc = hc;
+        L.i1 = slots.i1;
+        L.i2 = slots.i2;
         outidx.insert(outidx.end(), slots.outidx.begin(), slots.outidx.end());
         launches.push_back(L);
     }
@@ -3372,9 +3424,18 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
         }
         last_groups = ng;
         last_batches = L.n_batches;
+        BorderFix tap;  // (no whole-grid items here: the identity lag has its own launch)
+        if (L.tap_any) {
+            const double box[4] = {0.0, (double)(h->gW - 1), 0.0, (double)(h->gH - 1)};
+            h->tap_last[0] = h->tap_last[1] = h->tap_last[2] = 0;
+            RETCHK(prepare_tap_fix(
+                h, MODE_CAR, order, *hdr_target, (long long)L.tap_skip.size(), L.tap_skip, box,
+                [&](int slot) { return shifted(L.hc, L.i1[(size_t)slot], L.i2[(size_t)slot]); }, &tap,
+                h->lane_params.as<double>() + 9 * L.slot_off, &L.inv, &pa.car_fwd));
+        }
         RETCHK(launch_sweep(h, MODE_CAR, order, method, h->lane_params.as<double>() + 9 * L.slot_off,
                             h->out_index.as<long long>() + L.slot_off, L.n_batches, n_tiles, lag_begin, out_dev,
-                            &L.inv, nullptr, (long long)L.slot_off));
+                            &L.inv, L.tap_any ? &tap : nullptr, (long long)L.slot_off));
     }
     return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
 }

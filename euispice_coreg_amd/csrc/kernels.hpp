@@ -1975,6 +1975,10 @@ struct TapScanArgs {
     // even spline orders: the taps do not depend on which side of an integer the coordinate falls, the BOUNDS rule does
     // (c < 0 or c > n - 1, Util.py:98-102) -- 1: list only the samples within `tol` of a bound of the image
     int bounds_only;
+    // MODE_CAR (two plate-carree maps): grid pixel -> native angles of the target (fwd), native angles of the shifted map
+    // -> its pixel (cu); `hom` then holds the sphere rotations.  No segment bound exists for that map: every pixel of a
+    // slot that is not skipped is tested (the host skips all slots but those whose lag keeps an image axis invariant)
+    LaunchU cu, fwd;
     // Round 5: a thread of k_tap_scan owns (lag slot, rows) and used to test the pixels of every segment it could not
     // dismiss by itself -- for the pure CRVAL1 / CRVAL2 lags of an unrotated header that is whole columns of pixels walked
     // by a handful of lanes.  Such segments are now queued (slot, row, first pixel) and tested by k_tap_scan_segments, one
@@ -2033,12 +2037,15 @@ __device__ __forceinline__ bool tap_end_lines_differ(const TS* __restrict__ img,
 // result?  Then it is listed.
 template <int MODE>
 __device__ __forceinline__ void tap_scan_pixel(const TapScanArgs& a, const H9& hm, long long slot, int i, int j) {
-    const LaunchU cu = {};
     const long long idx = (long long)j * a.gw + i;
     const double araw = a.ref_f32 ? (double)((const float*)a.ref)[idx] : ((const double*)a.ref)[idx];
     if (!isfinite(araw)) return;
-    double x, y;
-    apply_map<MODE>(hm, cu, (double)i, (double)j, x, y);  // the coordinates k_sweep uses
+    double x, y, bx = (double)i, by = (double)j;
+    if (MODE == MODE_CAR) {  // (as k_precompute forms the pixel's native angles)
+        bx = fma(a.fwd.m00, (double)i, fma(a.fwd.m01, (double)j, a.fwd.b0));
+        by = fma(a.fwd.m10, (double)i, fma(a.fwd.m11, (double)j, a.fwd.b1));
+    }
+    apply_map<MODE>(hm, a.cu, bx, by, x, y);  // the coordinates k_sweep uses
     const int inr = (int)(x >= -a.tol) & (int)(x <= a.wmax + a.tol) & (int)(y >= -a.tol) & (int)(y <= a.hmax + a.tol);
     const int near = (int)(fabs(x - rint(x)) < a.tol) | (int)(fabs(y - rint(y)) < a.tol);
     if (!(inr & near)) return;
@@ -2099,6 +2106,20 @@ __global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
     const double last = (double)a.i_hi;
     for (int j = j0; j < j1; ++j) {
         const double dj = (double)j;
+        if (MODE == MODE_CAR) {
+            // no bound on the offsets of a sphere rotation followed by atan2: every segment of the row is queued (or
+            // tested here when the queue is full)
+            for (int i0 = a.i_lo; i0 <= a.i_hi; i0 += L) {
+                const int iend = min(i0 + L, a.i_hi + 1);
+                const unsigned q = a.seg_list ? atomicAdd(a.seg_count, 1u) : a.seg_cap;
+                if (q < a.seg_cap) {
+                    a.seg_list[q] = make_uint4((unsigned)slot, (unsigned)j, (unsigned)i0, (unsigned)iend);
+                } else {
+                    for (int i = i0; i < iend; ++i) tap_scan_pixel<MODE>(a, hm, slot, i, j);
+                }
+            }
+            continue;
+        }
         // bound of |f''| along the row, for x and for y (NaN maps fail every comparison below: nothing is listed)
         const double d = fma(hm.h[7], dj, hm.h[8]);
         const double dmin = fmin(fabs(d), fabs(fma(hm.h[6], last, d)));
@@ -2174,6 +2195,7 @@ struct TapFixArgs {
     double* slab;               // [kNumSums][n_slots] the extra slab
     const double* slot_pivots;  // as BorderFixArgs
     const int* only_flagged;
+    LaunchU cu, fwd;            // MODE_CAR: as TapScanArgs
 };
 template <typename TS, int MODE>
 __global__ void __launch_bounds__(256) k_tap_fix(const TapFixArgs a) {
@@ -2186,7 +2208,6 @@ __global__ void __launch_bounds__(256) k_tap_fix(const TapFixArgs a) {
     H9 hm;
 #pragma unroll
     for (int k = 0; k < 9; ++k) hm.h[k] = a.hom[(long long)k * a.n_slots + slot];
-    LaunchU cu = {};
     double s[kNumSums];
 #pragma unroll
     for (int k = 0; k < kNumSums; ++k) s[k] = 0.0;
@@ -2195,8 +2216,12 @@ __global__ void __launch_bounds__(256) k_tap_fix(const TapFixArgs a) {
         const double araw = a.ref_f32 ? (double)((const float*)a.ref)[idx] : ((const double*)a.ref)[idx];
         if (!isfinite(araw)) continue;
         const int i = (int)(idx % a.gw), j = (int)(idx / a.gw);
-        double nx, ny;
-        apply_map<MODE>(hm, cu, (double)i, (double)j, nx, ny);
+        double nx, ny, bx = (double)i, by = (double)j;
+        if (MODE == MODE_CAR) {  // (as k_precompute forms the pixel's native angles; apply_car = sincos + apply_car_vec)
+            bx = fma(a.fwd.m00, (double)i, fma(a.fwd.m01, (double)j, a.fwd.b0));
+            by = fma(a.fwd.m10, (double)i, fma(a.fwd.m11, (double)j, a.fwd.b1));
+        }
+        apply_map<MODE>(hm, a.cu, bx, by, nx, ny);
         for (int pass = 0; pass < 2; ++pass) {  // 0: take out what the sweep added; 1: add what the reference samples
             bool inb;
             double v = spline_global_rt<TS>((const TS*)a.img, a.W, a.H, pass ? a.xw[e] : nx, pass ? a.yw[e] : ny, a.order, inb);
