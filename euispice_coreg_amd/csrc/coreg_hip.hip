@@ -3245,9 +3245,9 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
         LaunchU inv;
         bool identity;  // the one-slot launch of the identity lag-point (below)
         // the single-sample pass of this launch: the combination's header, the CRVAL lag indices of its
-        // slots, and the slots the scan skips -- all but the lags that keep an image axis invariant (a lag in CRVAL1 alone
-        // or in CRVAL2 alone against the target header, same CDELT / PCi_j): only those bring whole rows or columns of
-        // coordinates back within wcslib's noise of integers
+        // slots, and the slots the scan skips -- all but the lags that leave CRVAL1 or CRVAL2 of the target header alone:
+        // only those bring whole rows or columns of coordinates (or, with a CROTA / CDELT lag on top, the reference pixel)
+        // back within wcslib's noise of integers
         coreg_wcs2d hc;
         std::vector<int> i1, i2;
         std::vector<unsigned char> tap_skip;
@@ -3317,12 +3317,10 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
             if (!pad && r[8] == r[8]) L.inv.pole_sep = std::max(L.inv.pole_sep, car_pole_sep(r));
             unsigned char skip = 1;
             if (!pad && h->opt_tap_fix && r[8] == r[8] && h->gW == h->sW && h->gH == h->sH) {
+                // (a CROTA / CDELT lag on top of it included: with both CRVAL equal the map is affine about CRPIX and
+                // returns the reference pixel itself to within the noise)
                 const coreg_wcs2d hl = shifted(hc, slots.i1[s], slots.i2[s]);
-                const bool same_scale = hl.cdelt1 == hdr_target->cdelt1 && hl.cdelt2 == hdr_target->cdelt2 &&
-                                        hl.pc1_1 == hdr_target->pc1_1 && hl.pc1_2 == hdr_target->pc1_2 &&
-                                        hl.pc2_1 == hdr_target->pc2_1 && hl.pc2_2 == hdr_target->pc2_2 &&
-                                        hl.crpix1 == hdr_target->crpix1 && hl.crpix2 == hdr_target->crpix2;
-                if (same_scale && (hl.crval1 == hdr_target->crval1 || hl.crval2 == hdr_target->crval2)) skip = 0;
+                if (hl.crval1 == hdr_target->crval1 || hl.crval2 == hdr_target->crval2) skip = 0;
             }
             L.tap_skip.push_back(skip);
             L.tap_any = L.tap_any || !skip;

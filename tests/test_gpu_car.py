@@ -272,3 +272,19 @@ def test_sweep_car_on_a_full_sun_map_up_to_the_pole(gpu_handle, use_lds):
                           unit_lag="deg")
     assert np.isfinite(want).sum() >= 12
     H.assert_corr_close(got, want, 1e-7, f"CAR sweep up to the pole, lds={use_lds}")
+
+
+def test_a_pure_crota_lag_returns_the_reference_pixel_to_itself(gpu_handle):
+    """Seed 3196 of tests/deep_fuzz_car.py: a CROTA lag with both CRVAL lags zero rotates the map about CRPIX, whose pixel
+    (integer here) comes back to itself within wcslib's noise -- ONE sample whose order-1 taps the sign decides.  The
+    single-sample pass lists it (the scan covers every lag that leaves CRVAL1 or CRVAL2 alone, CROTA / CDELT lags on top
+    included): within the tolerance, 4.0e-6 with the pass off."""
+    got, want, lags, order, hs = _sub_map_case(gpu_handle, 3196)
+    assert order == 1 and gpu_handle.last_tap_fix()["samples"] >= 0
+    H.assert_corr_close(got, want, 1e-7, "CAR sub-map seed=3196")
+    gpu_handle.set_option("tap_fix", 0)
+    try:
+        raw, _, _, _, _ = _sub_map_case(gpu_handle, 3196)
+    finally:
+        gpu_handle.set_option("tap_fix", 1)
+    assert 1e-7 < np.nanmax(np.abs(raw - want)) < 1e-4
