@@ -1070,12 +1070,29 @@ struct Taps<4> {
 // (ux, uy) = coordinate - 1 - window origin: trunc(u) is the window index of the first of the four taps per axis,
 // fract(u) the spline argument.  Sixteen hand-issued reads, the weights (six-fold, see spline_weights6_o3) computed under
 // their latency, one multiplication by 1/36 at the end.
-template <int PITCH>
-__device__ __forceinline__ double gather_o3(unsigned win, int pitch, double ux, double uy) {
-    const int c0 = (int)ux, r0 = (int)uy;
+template <int PITCH, bool FOLDED = false>
+__device__ __forceinline__ double gather_o3(unsigned win, int pitch, double cx, double cy, double offx, double offy) {
+    // floor and fraction of the COORDINATE itself, the (integer) window offset added afterwards: near the left / top edge
+    // of the image the cubic apron puts the window origin at -2, the offset is +1, and c + 1 can round a coordinate one
+    // ulp below an integer up to it -- another first tap than scipy's floor(c) (met by whole-pixel lags, round 5)
+    // (FOLDED: the coordinate handed over is window-relative already and non-negative -- the Carrington sweep's interior
+    // path, whose lane origin carries the offset: truncation and v_fract, two instructions fewer per axis)
+    int c0, r0;
+    double fx, fy;
+    if constexpr (FOLDED) {
+        c0 = (int)cx;
+        r0 = (int)cy;
+        fx = __builtin_amdgcn_fract(cx);
+        fy = __builtin_amdgcn_fract(cy);
+    } else {
+        const double flx = floor(cx), fly = floor(cy);
+        c0 = (int)flx + (int)offx;
+        r0 = (int)fly + (int)offy;
+        fx = cx - flx;
+        fy = cy - fly;
+    }
     const unsigned a0 = win + 8u * (unsigned)(__mul24(r0, PITCH > 0 ? PITCH : pitch) + c0);
     Taps<4> tp;
-    double fx = __builtin_amdgcn_fract(ux), fy = __builtin_amdgcn_fract(uy);
     if constexpr (PITCH > 0) {
         tp.template issue_before_imm<PITCH>(a0, fx, fy);
     } else {
@@ -1165,12 +1182,11 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
         // origin (order 2) / coordinate - origin (order 1): trunc(u) = window index of the first tap, fract(u) -> t.
         // (For TRANSLATE the constant is folded into the lane's origin, which moves the float64 rounding of the sum by
         // at most one ulp of the coordinate, ~2e-13 px.)
-        double ux, uy;
+        double ux, uy, mx = 0.0, my = 0.0;
         if (MODE == MODE_TRANSLATE) {
             ux = pxw + b0;
             uy = pyw + b1;
         } else {
-            double mx, my;
             if (MODE == MODE_CAR) apply_car_vec(hm, cu, b0, b1, isa, mx, my);  // (b0, b1, isa) = unit vector
             else apply_map<MODE>(hm, cu, b0, b1, mx, my);
             ux = mx + pxw;
@@ -1180,7 +1196,9 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
         if constexpr (ORDER == 2) {
             v = gather_o2<PITCH>(win, pitch, ux, uy);
         } else if constexpr (ORDER == 3) {
-            v = gather_o3<PITCH>(win, pitch, ux, uy);
+            // (TRANSLATE: the window offset is folded into the lane's origin, the coordinate IS window-relative)
+            if (MODE == MODE_TRANSLATE) v = gather_o3<PITCH, true>(win, pitch, ux, uy, 0.0, 0.0);
+            else v = gather_o3<PITCH>(win, pitch, mx, my, pxw, pyw);
         } else {
             const int c0 = (int)ux, r0 = (int)uy;
             const unsigned a0 = win + 8u * (unsigned)(__mul24(r0, pitch) + c0);
@@ -1253,7 +1271,7 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
             // origin turn the coordinate into the window-relative one
             v = gather_o2<PITCH>(win, pitch, nx + pxw, ny + pyw);
         } else if constexpr (LDS && ORDER == 3) {
-            v = gather_o3<PITCH>(win, pitch, nx + pxw, ny + pyw);  // (pxw, pyw) = -1 - window origin
+            v = gather_o3<PITCH>(win, pitch, nx, ny, pxw, pyw);  // (pxw, pyw) = -1 - window origin
         } else if constexpr (LDS) {
             // tap addresses first, so that the reads are in flight while the weights are computed
             const double fx = floor(nx + (ORDER == 2 ? 0.5 : 0.0)), fy = floor(ny + (ORDER == 2 ? 0.5 : 0.0));
@@ -1581,8 +1599,13 @@ __global__ void __launch_bounds__(kSweepThreads) k_sweep(const SweepArgs a) {
         mxy = fmax(fmax(wred[0][3], wred[1][3]), fmax(wred[2][3], wred[3][3]));
         // no in-bounds sample possible for this (tile, batch)?  (uniform)
         if (!(mxx >= 0.0) || !(mnx <= (double)(W - 1)) || !(mxy >= 0.0) || !(mny <= (double)(H - 1))) continue;
-        // every (point, lag) of this visit inside the image?  (uniform; the box covers all non-padding lanes)
-        const bool interior = (mnx >= 0.0) & (mxx <= (double)(W - 1)) & (mny >= 0.0) & (mxy <= (double)(H - 1));
+        // every (point, lag) of this visit inside the image?  (uniform; the box covers all non-padding lanes.)  The box is
+        // made of mapped CORNERS: a pixel between them can come out a few ulp beyond (a whole-pixel lag under an unrotated
+        // header puts column 0 at x = -3e-16 between corners at 0.0) -- such a visit must keep the per-sample bounds rule,
+        // which is also what k_tap_fix assumes when it takes a noise-decided sample out again: "interior" needs clearance
+        constexpr double kClear = 1e-9;
+        const bool interior = (mnx >= kClear) & (mxx <= (double)(W - 1) - kClear) & (mny >= kClear) &
+                              (mxy <= (double)(H - 1) - kClear);
         // integer window with the mirrored apron: taps of in-bounds samples lie in [floor(c)-1, floor(c)+2] (orders 1, 2);
         // run-time orders: [floor(c) - order/2 - 1, floor(c) + order - order/2 + 1]
         // (kWide: the apron can reach several samples past the image edge -- run-time orders and the cubic kernel)

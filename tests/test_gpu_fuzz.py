@@ -149,3 +149,27 @@ def test_lags_of_whole_pixels_under_an_unrotated_header(gpu_handle, order, cdelt
         H.assert_corr_close(got, want, 1e-7, f"whole-pixel lags, order {order}, serial {serial}")
         if not serial:
             assert gpu_handle.last_tap_fix()["samples"] > 0
+
+
+@pytest.mark.parametrize("seed", [6187, 7570, 8796, 9036])
+def test_cubic_window_taps_of_coordinates_an_ulp_below_an_integer(gpu_handle, seed):
+    """What tests/deep_fuzz_whole_pixels.py met (4 of 6 000 cases, all order 3 from the LDS window, up to 9.6e-4): near the
+    left / top edge of the image the cubic apron puts the window origin at -2, the window offset is +1, and `c + 1` rounded
+    a coordinate one ulp below an integer UP to it -- another first tap than scipy's floor(c), hence another neighbour's
+    NaN in the footprint (and another sample than the one the single-sample pass takes out again).  `gather_o3` now takes
+    floor and fraction of the coordinate itself and adds the integer offset afterwards: the LDS and the global-memory
+    gathers pick the same taps and the map is within the tolerance."""
+    from tests.deep_fuzz_whole_pixels import make_case
+    small, hs, large, hl, lags, order, serial, unit = make_case(seed)
+    assert order == 3 and not serial
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want = H.oracle_helio(small, hs, large, hl, lags, order=3, unit_lag=unit)
+    got = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=3)
+    H.assert_corr_close(got, want, 1e-7, f"seed={seed}")
+    gpu_handle.set_option("use_lds", 0)
+    try:
+        glob = H.gpu_helio(gpu_handle, small, hs, large, hl, lags, order=3)
+    finally:
+        gpu_handle.set_option("use_lds", 1)
+    # (the two gathers weigh the taps in another order: a float32 rounding of a sample flips now and then, 1e-10)
+    assert np.array_equal(np.isnan(glob), np.isnan(got)) and np.nanmax(np.abs(glob - got)) <= 1e-9
