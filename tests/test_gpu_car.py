@@ -132,7 +132,7 @@ def test_fuzz_car(gpu_handle, seed):
     H.assert_corr_close(got, want, 1e-7, f"fuzz CAR seed={seed}")
 
 
-def _sub_map_case(gpu_handle, seed):
+def _sub_map_case(gpu_handle, seed, force_order=None):
     """One random pair of Carrington maps through the sub-map semantics, lag axes through exactly zero: (GPU map, oracle
     map, lags, order, header of the map to align)."""
     from euispice_coreg_amd import _lib, synthetic
@@ -159,6 +159,8 @@ def _sub_map_case(gpu_handle, seed):
     l2 = np.unique(np.concatenate([[0.0], np.round(rng.uniform(0.0, 0.03, int(rng.integers(1, 3))), 4)]))
     lags = (l1, l2, None, None, [0.0] if rng.integers(0, 2) else [0.0, 0.3])
     order = int(rng.choice([1, 2]))
+    if force_order is not None:
+        order = int(force_order)
     ls = _lib.LagSet(*lags)
     gpu_handle.set_small(small)
     gpu_handle.prepare_reference_helioprojective(large, hl, hs, order)
