@@ -255,6 +255,9 @@ struct coreg_multi {
     int force_mode = -1;            // coreg_multi_set_option "force_mode": tests of one partition on any lag set
     int opt_image_shares = 1;       // "image_shares": 1 = row shares + one all-gather when RCCL is in use, 0 = N copies
     std::string rccl_error;         // why RCCL was given up on this handle ("" = it was not)
+    std::vector<hipEvent_t> pre;    // per device: recorded on the stream right before a group's collective (what the
+                                    // bounded wait times is the collective, not the sweep queued in front of it)
+    double phase_s[3] = {0, 0, 0};  // the last abandoned group: polling the streams, ncclCommAbort, draining the streams
     bool force_collective = false;  // COREG_MULTI_FORCE_RCCL=1 with ONE device: the RCCL calls run with a one-rank group
 };
 
@@ -303,7 +306,21 @@ int multi_sync_pivots(coreg_multi* m) {
 void multi_drop_rccl(coreg_multi* m, const char* why) {
     m->use_rccl = false;
     m->rccl_error = why;
+    const auto t0 = std::chrono::steady_clock::now();
     (void)multi_run(m, [&](int k) { return coreg_synchronize(m->h[k]); });
+    m->phase_s[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// the stream position "just before the group": call on every device after its sweep is enqueued, before GroupStart
+int multi_mark_pre_group(coreg_multi* m) {
+    if (m->pre.size() != (size_t)m->n) m->pre.assign(m->n, nullptr);
+    return multi_run(m, [&](int k) {
+        coreg_handle* h = m->h[k];
+        RETCHK(bind_device(h));
+        if (!m->pre[k]) HIPCHK(hipEventCreateWithFlags(&m->pre[k], hipEventDisableTiming));
+        HIPCHK(hipEventRecord(m->pre[k], h->stream));
+        return COREG_OK;
+    });
 }
 
 // ---- every wait on RCCL is bounded ------------------------------------------------------------
@@ -318,17 +335,21 @@ inline double multi_rccl_wait_limit() {
 
 // Fault injection for the tests (COREG_RCCL_TEST_STALL=1): instead of the group's collective, every stream gets a kernel
 // that spins on a flag in page-locked host memory -- a collective that never completes, as far as the stream can tell.
-// The abort path sets the flag; the kernel also leaves by itself after ~3 s of GPU clock, so that a bug in the recovery
-// cannot hold the device.
-__global__ void k_test_stall(volatile int* release) {
+// The abort path sets the flag; the kernel also leaves by itself after ~12 s of GPU clock, so that a bug in the recovery
+// cannot hold the device -- far enough above every wait limit the tests use (0.4 s) that a recovery released by this
+// self-limit cannot pass for one released by the abort path.  The flag is COHERENT (fine-grained)
+// page-locked memory, re-read with a system-scope atomic load on every turn: a host store reaches the spinning wave.
+__global__ void k_test_stall(int* release) {
     const long long t0 = wall_clock64();
-    while (*release == 0 && wall_clock64() - t0 < 300000000LL) __builtin_amdgcn_s_sleep(64);  // 100 MHz counter: 3 s
+    while (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 &&
+           wall_clock64() - t0 < 1200000000LL)  // 100 MHz counter: 12 s
+        __builtin_amdgcn_s_sleep(64);
 }
 struct StallFlag {
     int* p = nullptr;
     StallFlag() {
-        if (hipHostMalloc((void**)&p, sizeof(int), hipHostMallocPortable) != hipSuccess) p = nullptr;
-        if (p) *p = 0;
+        if (hipHostMalloc((void**)&p, sizeof(int), hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) p = nullptr;
+        if (p) __atomic_store_n(p, 0, __ATOMIC_SEQ_CST);
     }
     ~StallFlag() {
         if (p) (void)hipHostFree(p);
@@ -344,11 +365,27 @@ inline bool multi_test_stall() {
 bool multi_wait_group(coreg_multi* m, const char* what, StallFlag* stall = nullptr) {
     const double limit = multi_rccl_wait_limit();
     std::vector<int> state(m->n, 0);  // 1 = drained, 2 = error, 3 = timed out
+    const bool have_pre = m->pre.size() == (size_t)m->n;
+    const auto t_poll = std::chrono::steady_clock::now();
     (void)multi_run(m, [&](int k) {
         coreg_handle* h = m->h[k];
         RETCHK(bind_device(h));
-        const auto t0 = std::chrono::steady_clock::now();
+        // the clock of the limit starts when the work queued BEFORE the group (this device's sweep) has left the stream
+        // (a long sweep is not a hung collective); that part is waited for without a limit, as every
+        // stream-ordered call of the library waits for its own kernels
+        bool started = !(have_pre && m->pre[k]);
+        auto t0 = std::chrono::steady_clock::now();
         for (;;) {
+            if (!started) {
+                const hipError_t qe = hipEventQuery(m->pre[k]);
+                if (qe == hipSuccess) {
+                    started = true;
+                    t0 = std::chrono::steady_clock::now();
+                } else if (qe != hipErrorNotReady) {
+                    state[k] = 2;
+                    return COREG_OK;
+                }
+            }
             const hipError_t q = hipStreamQuery(h->stream);
             if (q == hipSuccess) {
                 state[k] = 1;
@@ -359,7 +396,7 @@ bool multi_wait_group(coreg_multi* m, const char* what, StallFlag* stall = nullp
                 return COREG_OK;
             }
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (dt > limit) {
+            if (started && dt > limit) {
                 state[k] = 3;
                 return COREG_OK;
             }
@@ -373,9 +410,11 @@ bool multi_wait_group(coreg_multi* m, const char* what, StallFlag* stall = nullp
         timed_out = timed_out || state[k] == 3;
     }
     if (ok) return true;
+    m->phase_s[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_poll).count();
     // (test: the injected "collective" is what the abort releases -- before ncclCommAbort, which waits for the
     // communicator's stream work)
-    if (stall && stall->p) *stall->p = 1;
+    if (stall && stall->p) __atomic_store_n(stall->p, 1, __ATOMIC_SEQ_CST);
+    const auto t_abort = std::chrono::steady_clock::now();
     RcclApi& api = RcclApi::get();
     for (ncclComm_t c : m->comms)
         if (c) {
@@ -383,7 +422,13 @@ bool multi_wait_group(coreg_multi* m, const char* what, StallFlag* stall = nullp
             else (void)api.CommDestroy(c);
         }
     m->comms.clear();
+    m->phase_s[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_abort).count();
     multi_drop_rccl(m, (std::string(what) + (timed_out ? " did not complete in time" : " failed on a stream")).c_str());
+    // where the time of the recovery went, for whoever reads the status (coreg_multi_rccl_status)
+    char buf[160];
+    std::snprintf(buf, sizeof buf, " [waited %.3f s on the streams (limit %.3g s), ncclCommAbort %.3f s, stream drain %.3f s]",
+                  m->phase_s[0], limit, m->phase_s[1], m->phase_s[2]);
+    m->rccl_error += buf;
     return false;
 }
 
@@ -468,10 +513,11 @@ int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out, bool p
             }));
             StallFlag stall;
             ncclResult_t e = ncclSuccess, e2 = ncclSuccess;
+            RETCHK(multi_mark_pre_group(m));
             if (multi_test_stall() && stall.p) {
                 (void)multi_run(m, [&](int k) {
                     RETCHK(bind_device(m->h[k]));
-                    hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, m->h[k]->stream, (volatile int*)stall.p);
+                    hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, m->h[k]->stream, stall.p);
                     return COREG_OK;
                 });
             } else {
@@ -574,10 +620,11 @@ int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out, bool p
         // sweep was enqueued on
         StallFlag stall;
         ncclResult_t e = ncclSuccess, e2 = ncclSuccess;
+        RETCHK(multi_mark_pre_group(m));
         if (multi_test_stall() && stall.p) {
             (void)multi_run(m, [&](int k) {
                 RETCHK(bind_device(m->h[k]));
-                hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, m->h[k]->stream, (volatile int*)stall.p);
+                hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, m->h[k]->stream, stall.p);
                 return COREG_OK;
             });
         } else {
@@ -656,6 +703,7 @@ int multi_set_small_shares(coreg_multi* m, const void* src, const PixFmt& fmt, c
                                  (hi - lo) * row_bytes));
         return COREG_OK;
     }));
+    RETCHK(multi_mark_pre_group(m));
     RcclApi& api = RcclApi::get();
     ncclResult_t e = api.GroupStart();
     for (int k = 0; k < world && e == ncclSuccess; ++k)
@@ -847,6 +895,7 @@ int coreg_multi_create(coreg_multi** out, int n_devices, const int* device_ids) 
             std::mutex mu;
             std::condition_variable cv;
             bool done = false;
+            bool abandoned = false;  // the creator gave up waiting: whatever the thread still obtains is its own to free
             ncclResult_t rc = ncclSuccess;
         };
         auto st = std::make_shared<InitState>();
@@ -857,10 +906,25 @@ int coreg_multi_create(coreg_multi** out, int n_devices, const int* device_ids) 
             if (stall && std::atof(stall) > 0)
                 std::this_thread::sleep_for(std::chrono::milliseconds((long long)(std::atof(stall) * 1000)));
             const ncclResult_t r = RcclApi::get().CommInitAll(st->comms.data(), (int)st->devs.size(), st->devs.data());
-            std::lock_guard<std::mutex> lk(st->mu);
-            st->rc = r;
-            st->done = true;
-            st->cv.notify_all();
+            bool abandoned;
+            {
+                std::lock_guard<std::mutex> lk(st->mu);
+                st->rc = r;
+                st->done = true;
+                abandoned = st->abandoned;
+                st->cv.notify_all();
+            }
+            if (abandoned && r == ncclSuccess) {
+                // nobody will ever use these communicators -- the late thread gives them back itself
+                // (abort: nothing is queued on them) instead of leaving them to process teardown
+                RcclApi& api = RcclApi::get();
+                for (ncclComm_t c : st->comms)
+                    if (c) {
+                        if (api.CommAbort) (void)api.CommAbort(c);
+                        else (void)api.CommDestroy(c);
+                    }
+                st->comms.clear();
+            }
         });
         const char* env = std::getenv("COREG_RCCL_SELFTEST_SECONDS");
         const double limit = env && std::atof(env) > 0 ? std::atof(env) : 20.0;
@@ -868,9 +932,12 @@ int coreg_multi_create(coreg_multi** out, int n_devices, const int* device_ids) 
         {
             std::unique_lock<std::mutex> lk(st->mu);
             in_time = st->cv.wait_for(lk, std::chrono::milliseconds((long long)(limit * 1000)), [&] { return st->done; });
+            if (!in_time) st->abandoned = true;  // (under the lock: the thread either sees it or has already finished)
         }
         if (!in_time) {
-            init.detach();  // (its communicators, if it ever gets them, are never used)
+            // its communicators, if it ever gets them, are never used: it frees them itself.  Until it has come back the
+            // process should not count on a clean exit from inside RCCL's bootstrap (documented in include/coreg_hip.h)
+            init.detach();
             m->rccl_error = "ncclCommInitAll did not return in time";
         } else {
             init.join();
@@ -898,6 +965,7 @@ void coreg_multi_destroy(coreg_multi* m) {
             m->blk[k].release();
             m->gat[k].release();
             m->img[k].release();
+            if (k < (int)m->pre.size() && m->pre[k]) (void)hipEventDestroy(m->pre[k]);
         });
         m->w[k]->wait();
     }

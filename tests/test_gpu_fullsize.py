@@ -581,6 +581,31 @@ def test_cfg5_five_d_sweep_4096_grid_full_size(gpu_handle, big_scene):
     d = np.abs(full[idx[:, 0], idx[:, 1], 2, 2, idx[:, 2]] - want)
     print("cfg5 map vs", want.size, "lag-points of the reference's own run: max |dcorr|", d.max())
     assert d.max() <= 1e-10
+    # the planes with a CDELT lag (24 of the 25) against the REFERENCE'S OWN CODE -- 38 entries of this
+    # map from the reference's `Alignment` on the 4096^2 grid, run on files whose header went through the reference's
+    # `correct_pointing_header` (Util.py:161-215) first: 32 with the CDELT lags in the header and the CRVAL / CROTA lags
+    # swept by the reference, 6 with all five lags in the header and the reference at its zero lag
+    # (tests/golden/make_golden_cdelt_intended.py cfg5)
+    import os
+    from tests.conftest import GOLDEN
+    from tests.golden.make_golden_headline import fingerprint
+    r = np.load(os.path.join(GOLDEN, "cdelt_intended_cfg5.npz"))
+    assert np.array_equal(fingerprint(small, large), r["fingerprint"])
+    ri = r["index"]
+    assert int(((ri[:, 2] != 2) | (ri[:, 3] != 2)).sum()) >= 16
+    d = np.abs(full[tuple(ri.T)] - r["corr"])
+    print("cfg5 map vs", ri.shape[0], "lag-points of the reference's own code under the intended CDELT semantics "
+          f"({int(((ri[:, 2] != 2) | (ri[:, 3] != 2)).sum())} with a CDELT lag): max |dcorr|", d.max())
+    assert d.max() <= 1e-10, (ri[np.argmax(d)], d.max())
+    # ... and 75 lag-points the oracle evaluated in the build container, three in each of the 25 (d_cdelt1, d_cdelt2)
+    # planes (tests/golden/make_golden_cfg5_sample.py)
+    g = np.load(os.path.join(GOLDEN, "cfg5_sample.npz"))
+    assert np.array_equal(fingerprint(small, large), g["fingerprint"])
+    planes = {tuple(v) for v in np.array(np.unravel_index(g["index"], full.shape))[2:4].T}
+    assert len(planes) == 25
+    d = np.abs(full.ravel()[g["index"]] - g["corr"])
+    print("cfg5 map vs", g["index"].size, "committed oracle lag-points over all 25 CDELT planes: max |dcorr|", d.max())
+    assert d.max() <= 1e-10
     subl = (l1[::8], l2[::10], lc[::2], lc[1::3], lr[::5])
     a = _sweep(gpu_handle, hs, grid, subl)
     gpu_handle.set_option("use_lds", 0)
