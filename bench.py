@@ -69,22 +69,150 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# ---- N > 1 never ends without a line -------------------------------------------------------------
+# The reference joins its workers in a busy-wait with no limit (alignment.py:723-744): a worker that dies leaves zeros,
+# one that hangs leaves the caller waiting for ever.  Here every wait has a limit and every way out prints ONE JSON line:
+#   * the process group is created with a timeout (COREG_BENCH_PG_TIMEOUT_S, default 120 s: rendezvous and, with RCCL,
+#     every collective -- torch's watchdog ends the rank when one stays out that long);
+#   * every rank has a deadline (COREG_BENCH_DEADLINE_S, default 900 s) and a SIGTERM watcher (torchrun ends the
+#     surviving ranks with SIGTERM when one of them dies) on a thread of its own, so that a main thread stuck inside a
+#     collective cannot keep the line from being printed; rank 0 prints {"error": ..., "value": null, ...}, exit != 0;
+#   * `python bench.py --gpus N` (the self-launcher) watches its children: when they end non-zero, or the deadline
+#     passes, it ends THEIR process group (never a pattern), and prints the error line itself if rank 0 did not.
+_LINE_PRINTED = [False]
+_STDOUT_FD = [None]     # the real stdout once fd 1 has been pointed at stderr
+_RUN_INFO = {"n_gpus": None, "n_ranks_seen": 0, "steps": None, "warmup": None}
+
+
+def _mark(what, rank):
+    d = os.environ.get("COREG_BENCH_MARK_DIR")
+    if d:
+        try:
+            open(os.path.join(d, f"{what}_{rank}"), "w").close()
+        except OSError:
+            pass
+
+
+def error_line(msg, **extra):
+    out = {"metric": METRIC, "value": None, "unit": "lag-points/s", "n_gpus": _RUN_INFO["n_gpus"],
+           "n_ranks_seen": _RUN_INFO["n_ranks_seen"], "steps": _RUN_INFO["steps"], "warmup": _RUN_INFO["warmup"],
+           "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic", "error": str(msg)[:600]}
+    out.update(extra)
+    return json.dumps(out)
+
+
+def print_line_once(text):
+    """The ONE line of this run on the real stdout (whatever fd 1 points at by now); False when it was printed before."""
+    if _LINE_PRINTED[0]:
+        return False
+    _LINE_PRINTED[0] = True
+    data = (text + "\n").encode()
+    fd = _STDOUT_FD[0] if _STDOUT_FD[0] is not None else 1
+    try:
+        sys.stdout.flush()
+    except Exception:
+        pass
+    os.write(fd, data)
+    return True
+
+
+def arm_rank_watchdogs(rank):
+    """Deadline + SIGTERM watcher of a rank process, both on daemon threads (see above)."""
+    import signal
+    import threading
+    deadline = float(os.environ.get("COREG_BENCH_DEADLINE_S", "900"))
+
+    def give_up(msg, code):
+        if rank == 0:
+            print_line_once(error_line(msg))
+        log(f"[bench] rank {rank}: {msg}")
+        os._exit(code)
+
+    t = threading.Timer(deadline, give_up, (f"deadline of {deadline:.0f} s passed (COREG_BENCH_DEADLINE_S)", 124))
+    t.daemon = True
+    t.start()
+    try:
+        r, w = os.pipe()
+        os.set_blocking(w, False)
+        signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+        signal.signal(signal.SIGTERM, lambda *_: None)  # (the wake-up fd is what is acted on)
+
+        def watch():
+            while True:
+                b = os.read(r, 1)
+                if b and b[0] == signal.SIGTERM:
+                    give_up("terminated by the launcher (SIGTERM): another rank failed or the launcher's limit passed", 143)
+        th = threading.Thread(target=watch, daemon=True)
+        th.start()
+    except (ValueError, OSError):  # not the main thread / no signals here: the deadline still holds
+        pass
+    return t
+
+
 def self_launch(n, argv):
     """--gpus N > 1 without a torchrun environment: start the N ranks as children and relay their result.  Runs before
-    torch / HIP are imported here (a process that has initialised the GPU must never exec or fork GPU workers)."""
+    torch / HIP are imported here (a process that has initialised the GPU must never exec or fork GPU workers).  The
+    children's stdout comes through a pipe, so that this process knows whether the ONE line was printed."""
+    import shutil
+    import signal
     import socket
     import subprocess
+    import tempfile
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "2")
+    deadline = float(env.get("COREG_BENCH_DEADLINE_S", "900"))
+    env["COREG_BENCH_DEADLINE_S"] = str(deadline)
+    marks = tempfile.mkdtemp(prefix="coreg_bench_marks_")
+    env["COREG_BENCH_MARK_DIR"] = marks
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     log("[bench] launching", n, "ranks:", " ".join(cmd))
-    # the children inherit stdout: rank 0 prints the ONE JSON line
-    return subprocess.run(cmd, env=env).returncode
+    t0 = time.time()
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    seen = []
+
+    def relay():
+        for raw in p.stdout:
+            line = raw.decode(errors="replace")
+            if line.strip():
+                seen.append(line)
+                sys.stdout.write(line)
+                sys.stdout.flush()
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    why = None
+    try:
+        rc = p.wait(timeout=deadline + 30.0)  # (the ranks' own deadline comes first and prints the line itself)
+    except subprocess.TimeoutExpired:
+        why = f"the ranks did not end within {deadline + 30.0:.0f} s"
+        rc = 124
+    if why is not None or rc != 0:
+        # end exactly the process group started above (torchrun and its ranks), first politely
+        for sig, wait in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+            try:
+                os.killpg(p.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                break
+            try:
+                p.wait(timeout=wait)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+    th.join(timeout=5.0)
+    joined = len([f for f in os.listdir(marks) if f.startswith("joined_")])
+    started = len([f for f in os.listdir(marks) if f.startswith("started_")])
+    shutil.rmtree(marks, ignore_errors=True)
+    if rc != 0 and not any('"metric"' in ln for ln in seen):
+        _RUN_INFO.update(n_gpus=n, n_ranks_seen=joined)
+        print(error_line(why or f"the ranks ended with return code {rc} before rank 0 printed its line",
+                         ranks_started=started, launcher_seconds=round(time.time() - t0, 1)), flush=True)
+    return rc if rc != 0 else 0
 
 
 def pmc_summary():
@@ -266,11 +394,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         args.gpus = world
+    _RUN_INFO.update(n_gpus=world, n_ranks_seen=0, steps=args.steps, warmup=args.warmup)
+    _mark("started", rank)
 
     # native libraries (RCCL prints a version banner on first use) write to fd 1: keep stdout for the ONE JSON line
     sys.stdout.flush()
     saved_stdout = os.dup(1)
+    _STDOUT_FD[0] = saved_stdout
     os.dup2(2, 1)
+    if world > 1 or "COREG_BENCH_DEADLINE_S" in os.environ:
+        arm_rank_watchdogs(rank)
+    fail_rank = int(os.environ.get("COREG_BENCH_TEST_FAIL_RANK", "-1"))  # tests of the launcher: a rank that dies
+    fail_at = os.environ.get("COREG_BENCH_TEST_FAIL_AT", "init")
+    if rank == fail_rank and fail_at == "init":
+        os._exit(7)
 
     import numpy as np
     import torch
@@ -299,11 +436,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("COREG_BENCH_PG_TIMEOUT_S", "120")))
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=pg_timeout)
     n_ranks_seen = dist.get_world_size() if use_dist else 1
+    _RUN_INFO["n_ranks_seen"] = n_ranks_seen
+    _mark("joined", rank)
 
     def sync():
         if not dry:
@@ -442,6 +583,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if rank == fail_rank and fail_at == "step":
+        os._exit(7)
+    if rank == fail_rank and fail_at == "hang":  # a rank that stays out of the next collective for ever
+        time.sleep(1e6)
     elapsed = timed(args.steps, n_streams)
     # the same steps for >= 2 s, so that the GPU is visibly busy to an outside observer and a clock that falls under
     # sustained load shows (the K-step region above lasts a second at most)
@@ -699,10 +844,7 @@ def main():
             out["cpu_baseline"] = None
         if not dry:
             out["parity_vs_reference_run"] = reference_run_points(np, small, large, corr)
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        print(json.dumps(out), flush=True)
-        os.dup2(2, 1)
+        print_line_once(json.dumps(out))
     for hk in handles:
         hk.close()
     if use_dist:
@@ -711,4 +853,14 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:  # a rank that fails says so on the ONE line (rank 0) and ends non-zero
+        import traceback
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0:
+            print_line_once(error_line(f"{type(e).__name__}: {e}"))
+        sys.stderr.flush()
+        os._exit(1)  # (not sys.exit: a process group stuck in a collective may never let the interpreter finalise)

@@ -450,18 +450,23 @@ class CoregHandle:
             return
         # (option "async_upload": the library's upload thread reads the pixels after this call has returned -- the object
         # that owns them is kept until the next upload replaces it; the caller must not modify them meanwhile)
+        # (the PREVIOUS buffer stays referenced until the library call has returned -- that call joins the
+        # upload job that may still be reading it -- and only then is it let go)
+        previous = getattr(self, "_small_keepalive", None)
         if _is_raw(img):
             px = _fits_pixels(img)
-            self._small_keepalive = (img, px)
             self._chk(self._lib.coreg_set_small_fits(self._h, C.byref(px), img.shape[0], img.shape[1]))
+            self._small_keepalive = (img, px)
+            del previous
             return
         img = np.asarray(img)
         if img.ndim != 2:
             raise ValueError("small image must be 2-D")
         if img.dtype == np.float32:
             img = np.ascontiguousarray(img)
-            self._small_keepalive = img
             self._chk(self._lib.coreg_set_small_f32(self._h, img.ctypes.data, img.shape[0], img.shape[1]))
+            self._small_keepalive = img
+            del previous
         else:
             img = np.ascontiguousarray(img, dtype=np.float64)
             self._chk(self._lib.coreg_set_small(self._h, img.ctypes.data, img.shape[0], img.shape[1]))

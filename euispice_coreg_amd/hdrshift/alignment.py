@@ -430,7 +430,12 @@ class Alignment:
                 # :765-767 serial): the reference map is resampled once on the grid of the map to align, float32, and
                 # every lag re-samples the map to align on its own grid (round 5: found by the reference-run fixtures;
                 # rounds 1-4 correlated on the reference map's full grid)
-                prepare("helioprojective", self.hdr_large, self.hdr_small, self.order)
+                # the reference casts the reference map to float32 BEFORE the sub-map interpolation in this frame
+                # (alignment.py:371-372); exact and free for BITPIX=-32 pixels, a rounding for a float64 map
+                big = self._large_pixels()
+                if getattr(big, "dtype", None) != np.float32:  # (also a memory-mapped data unit that is not BITPIX=-32)
+                    big = np.asarray(big).astype(np.float32)
+                h.prepare_reference_helioprojective(big, self.hdr_large, self.hdr_small, self.order)
 
                 def run():
                     select_combos()

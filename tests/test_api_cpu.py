@@ -374,6 +374,45 @@ def test_bench_self_launches_its_ranks_gloo_world2():
     assert out["scaling"] == "strong" and out["config"]["resident"] is True
 
 
+def _run_bench_failing(extra_env, *argv, timeout=240):
+    import json
+    import time
+    env = dict(os.environ, COREG_BENCH_BACKEND="gloo", COREG_BENCH_DRY="1", **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, (p.stdout, p.stderr[-2000:])  # still ONE line, nothing else on stdout
+    return p.returncode, json.loads(lines[0]), time.time() - t0
+
+
+@pytest.mark.parametrize("where", ["init", "step"])
+def test_bench_says_so_on_its_one_line_when_a_rank_dies(where):
+    """`python bench.py --gpus 2` with rank 1 made to exit (before the process group exists / after
+    the warm-up, i.e. the others are inside or about to enter a collective): the launcher comes back non-zero within the
+    deadline and stdout holds ONE JSON line with "error", value null and the number of ranks that joined the group.  The
+    reference's counterpart is the unbounded busy-wait join of alignment.py:723-744."""
+    rc, out, dt = _run_bench_failing({"COREG_BENCH_TEST_FAIL_RANK": "1", "COREG_BENCH_TEST_FAIL_AT": where,
+                                      "COREG_BENCH_DEADLINE_S": "120", "COREG_BENCH_PG_TIMEOUT_S": "20"},
+                                     "--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert rc != 0 and dt < 120
+    assert out["value"] is None and out["error"] and out["n_gpus"] == 2
+    assert out["n_ranks_seen"] == (2 if where == "step" else out["n_ranks_seen"]) and 0 <= out["n_ranks_seen"] <= 2
+    assert out["metric"] and out["unit"] == "lag-points/s"
+
+
+def test_bench_deadline_ends_a_run_whose_rank_never_joins_the_collective():
+    """A rank that stays out of a collective for ever: the process-group timeout (here 8 s) or the ranks' own deadline
+    (here 40 s) ends the run; ONE error line, non-zero return code, no process left behind."""
+    rc, out, dt = _run_bench_failing({"COREG_BENCH_TEST_FAIL_RANK": "1", "COREG_BENCH_TEST_FAIL_AT": "hang",
+                                      "COREG_BENCH_DEADLINE_S": "40", "COREG_BENCH_PG_TIMEOUT_S": "8"},
+                                     "--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert rc != 0 and dt < 100
+    assert out["value"] is None and out["error"] and out["n_ranks_seen"] == 2
+
+
 def _several_hdus(tmp_path):
     """A file with an empty primary, a float32 image, an int16 image with BSCALE / BZERO and a float64 image."""
     from euispice_coreg_amd.utils import fits_io

@@ -221,7 +221,7 @@ def test_a_collective_that_never_completes_is_aborted_and_the_map_still_comes_ou
         assert limit == 0.4 and 0.4 <= poll < 0.6, (poll, m.rccl_status)   # bounded by the limit
         assert drain < 0.2, (drain, m.rccl_status)  # the flag released the kernel: the stream was free at once
         assert dt - abort < 1.0, (dt, abort)        # everything that is this library's
-        assert dt < 1.5 + max(0.0, abort - 0.5), (dt, m.rccl_status)  # RCCL's abort is RCCL's (reported above)
+        assert dt < 1.5, (dt, m.rccl_status)        # measured: 0.91 s = 0.40 poll + 0.51 ncclCommAbort (RCCL 2.26.6)
         monkeypatch.delenv("COREG_RCCL_TEST_STALL")
         again = _multi_carr(m, small, hs, large, hl, lags)  # RCCL is gone for this handle: host copies
         assert np.array_equal(again, want, equal_nan=True) and m.collective == "host-copy"
