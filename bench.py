@@ -145,6 +145,13 @@ def arm_rank_watchdogs(rank):
                     give_up("terminated by the launcher (SIGTERM): another rank failed or the launcher's limit passed", 143)
         th = threading.Thread(target=watch, daemon=True)
         th.start()
+
+        # processes forked from this one (the oracle's worker pool of the CPU parity sample) inherit the wake-up pipe: a
+        # SIGTERM sent to one of THEM -- multiprocessing.Pool ends its workers that way -- would be read here as ours
+        def in_child():
+            signal.set_wakeup_fd(-1)
+            signal.signal(signal.SIGTERM, signal.SIG_DFL)
+        os.register_at_fork(after_in_child=in_child)
     except (ValueError, OSError):  # not the main thread / no signals here: the deadline still holds
         pass
     return t
@@ -336,6 +343,219 @@ def main_threads(args):
     os.dup2(2, 1)
 
 
+# ---- the other sweep variants / BASELINE configs, one GPU, same schema -----------------------------
+# Counted float64 operations per (active grid point, lag) of each variant's interior LDS path (kernels.hpp point_lag),
+# with the conventions of the headline's 42: fma = 2 flop elsewhere, the spline-weight instructions 1 each, conversions /
+# class tests / address arithmetic 0.  coordinate: TRANSLATE 2 add; HOMOGRAPHY_SERIES eps (fma + mul) + q (fma) + two
+# numerators (4 fma) + two corrections (2 fma) + 2 window offsets = 19; HOMOGRAPHY w (2 fma) + rcp + Newton (2 fma) +
+# numerators (4 fma) + 2 mul + 2 offsets = 21; CAR rotation (6 fma + 3 mul) + hypot (fma + mul + sqrt) + 2 atan2 counted 1
+# each + linear map (4 fma) + 2 offsets = 31.  2 fract.  weights: order 1: 2, order 2: 10, order 3: 30.  taps, N = order
+# + 1: N rows of (mul + (N - 1) fma) + one column of the same = (N + 1)(2N - 1): 9 / 20 / 35 (+ 1 scale at order 3).
+# float32 rounding of the sample (helioprojective frames): 1 sub of the pivot.  sums: 2 add + 3 fma = 8.
+def _variant_flop(mode, order, rounded):
+    coord = {"TRANSLATE": 2, "HOMOGRAPHY_SERIES": 19, "HOMOGRAPHY": 21, "CAR": 31}[mode]
+    weights = {1: 2, 2: 10, 3: 30}[order]
+    n = order + 1
+    taps = (n + 1) * (2 * n - 1) + (1 if order == 3 else 0)
+    return float(coord + 2 + weights + taps + (1 if rounded else 0) + 8)
+
+
+def _committed(kind, name):
+    """Newest committed profile summary of `bench.py --config name`: kind 'pmc' -> profiles/rNN_pmc_<name>.txt (counter
+    means per launch), 'stats' -> profiles/rNN_kernel_stats_<name>.csv (rocprofv3 --kernel-trace --stats)."""
+    import glob
+    pat = {"pmc": f"r[0-9][0-9]_pmc_{name}.txt", "stats": f"r[0-9][0-9]_kernel_stats_{name}.csv"}[kind]
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+    return paths[-1] if paths else None
+
+
+def main_config(args):
+    """`--config NAME`: one of the other BASELINE configs / sweep variants on ONE GPU, inputs resident, K synchronous
+    sweep calls (map copied to the host every step).  Same line as the headline's, `roofline` from the variant's own
+    counted flop; the headline metric is NOT what `value` is here -- `config.workload` says what it is."""
+    import numpy as np
+    from euispice_coreg_amd import _lib, synthetic
+    name = args.config
+    sys.stdout.flush()
+    _STDOUT_FD[0] = os.dup(1)
+    os.dup2(2, 1)
+    h = _lib.CoregHandle(0)
+    h.set_option("use_lds", args.use_lds)
+    for kv in filter(None, os.environ.get("COREG_BENCH_OPTS", "").split(",")):
+        k, v = kv.split("=")
+        h.set_option(k, int(v))
+    carr = None
+    order, mode, rounded, frame, par = 2, "TRANSLATE", False, "carrington", True
+    if name == "cfg4":
+        small, hs, large, hl, truth = synthetic.make_scene(small_shape=(832, 192), small_cdelt=(4.0, 1.098),
+                                                           small_unit="deg", large_n=3072)
+    elif name == "car":
+        small, hs, large, hl, truth = synthetic.make_car_scene(small_shape=(768, 1024), large_shape=(1200, 1600), n_blobs=60)
+    else:
+        small, hs, large, hl, truth = synthetic.make_scene()
+    if name in ("order1", "order3", "cfg3", "cfg5"):
+        order = {"order1": 1, "order3": 3}.get(name, 2)
+        shape = (4096, 4096) if name == "cfg5" else GRID_SHAPE
+        carr = dict(shape=list(shape), lonlims=list(LONLIMS), latlims=list(LATLIMS))
+        if name == "cfg3":
+            lag_arrays = (np.arange(-60, 61, 1.0), np.arange(-60, 61, 1.0), None, None, None)
+            what = "BASELINE configs[2]: Carrington 'fa' 2048^2 grid, 121x121 CRVAL lags"
+        elif name == "cfg5":
+            lag_arrays = (np.arange(-20, 21, 1.0), np.arange(-20, 21, 1.0), np.round(np.arange(-2, 3) * 0.01, 10),
+                          np.round(np.arange(-2, 3) * 0.01, 10), np.round(np.arange(-5, 6) * 0.1, 10))
+            what = "BASELINE configs[4]: 5-D sweep, Carrington 4096^2 grid, 41x41 CRVAL x 5x5 CDELT x 11 CROTA lags"
+        else:
+            lag_arrays = (np.arange(-30, 30, 1.0), np.arange(-30, 30, 1.0), None, None, None)
+            what = f"the headline sweep at reprojection_order={order}"
+        grid = _lib.Grid(LONLIMS, LATLIMS, shape, numpy_lat_trig=True)
+        h.set_small(small)
+        h.prepare_reference_carrington(large, hl, grid, SOLAR_R, order)
+        lags = _lib.LagSet(*lag_arrays)
+
+        def sweep():
+            return h.sweep_carrington(hs, grid, SOLAR_R, lags, order=order)
+        b_lag = shape[0] * shape[1] * 8 + small.size * 8
+    elif name in ("cfg2", "cfg4"):
+        frame, rounded = "helioprojective", True
+        if name == "cfg2":
+            mode = "HOMOGRAPHY_SERIES"
+            lag_arrays = (np.arange(-30, 31, 1.0), np.arange(-30, 31, 1.0), None, None, None)
+            what = "BASELINE configs[1]: helioprojective, sub-map semantics, 2048^2 vs 3072^2, 61x61 CRVAL lags"
+        else:
+            mode = "HOMOGRAPHY"
+            lag_arrays = (np.arange(-30, 31, 1.0) / 3600, np.arange(-30, 31, 1.0) / 3600, None, None,
+                          np.round(np.arange(-10, 11) * 0.1, 10))
+            what = ("BASELINE configs[3]: SPICE-like raster 192x832 (header in degrees) vs 3072^2, helioprojective, "
+                    "61x61 CRVAL x 21 CROTA lags")
+        h.set_small(small)
+        h.prepare_reference_helioprojective(large, hl, hs, 2)
+        lags = _lib.LagSet(*lag_arrays)
+
+        def sweep():
+            return h.sweep_helioprojective(hs, hs, lags)
+        b_lag = small.size * 4 + small.size * 8  # SURVEY 8d: float32 sub-map on the small grid + the float64 image
+    elif name == "car":
+        frame, mode, rounded, par = "helioprojective", "CAR", True, False
+        lag_arrays = (np.arange(-15, 16) * 0.004, np.arange(-15, 16) * 0.004, None, None, None)
+        what = ("plate-carree maps (align_using_initial_carrington geometry): 768x1024 map against a 1200x1600 reference "
+                "map on the reference's grid, 31x31 CRVAL lags of 0.004 deg")
+        h.set_small(small)
+        h.set_reference_on_grid(np.asarray(large, dtype=np.float32))
+        lags = _lib.LagSet(*lag_arrays)
+
+        def sweep():
+            return h.sweep_helioprojective(hl, hs, lags)
+        b_lag = large.size * 4 + small.size * 8
+    else:
+        raise SystemExit(f"unknown --config {name}")
+    L = lags.size
+    steps = args.steps if args.steps_given else {"cfg5": 3, "cfg2": 20, "cfg4": 20}.get(name, 50)
+    warm = args.warmup if args.warmup_given else {"cfg5": 1}.get(name, 5)
+    _RUN_INFO.update(n_gpus=1, n_ranks_seen=1, steps=steps, warmup=warm)
+    for _ in range(warm):
+        corr = sweep()
+    h.synchronize()
+    t0 = time.perf_counter()
+    kern, pre = [], []
+    for _ in range(steps):
+        corr = sweep()
+        st = h.last_stats()
+        kern.append(st["sweep_kernel_ms"])
+        pre.append(st["precompute_ms"])
+    h.synchronize()
+    elapsed = time.perf_counter() - t0
+    corr = np.asarray(corr).reshape(lags.shape)
+    n_launch = max(1, int(st["n_sweep_launches"]))
+    k_ms = float(np.mean(kern))                    # all launches of one sweep
+    act = int(st["n_active_points"])               # per launch
+    lags_per_launch = L // n_launch
+    flop = _variant_flop(mode, order, rounded)
+    k_s = k_ms * 1e-3
+    achieved_tf = flop * act * L / k_s / 1e12
+    roof = {"bound": "valu_fp64+lds", "achieved": achieved_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+            "frac": achieved_tf / FP64_VALU_PEAK_TF,
+            "kernel": f"k_sweep<{mode},{order},{'f32' if st['small_is_f32'] else 'f64'}>", "launches_per_sweep": n_launch,
+            "kernel_ms": k_ms / n_launch, "kernel_ms_per_sweep": k_ms, "lags_per_launch": lags_per_launch,
+            "active_points": act, "flop_per_point_lag": flop,
+            "ps_per_point_lag": k_ms * 1e9 / max(1, act * L), "traffic": None,
+            "hbm_model": {"algorithmic_bytes_per_lag": b_lag, "algorithmic_bytes_per_launch": b_lag * lags_per_launch,
+                          "achieved_gbs": b_lag * L / k_s / 1e9, "peak_gbs": HBM_PEAK_GBS,
+                          "hbm_model_frac": b_lag * L / k_s / 1e9 / HBM_PEAK_GBS,
+                          "note": "SURVEY 8d one-lag-per-pass byte model; every staged byte is shared between the 256 "
+                                  "lags of a workgroup, so this is not the bound (see traffic)"},
+            "note": "achieved = counted float64 flop of the variant's interior gather path x active points x lags / "
+                    "kernel time (HIP events around every k_sweep launch of the timed steps)"}
+    pmc_path = _committed("pmc", name)
+    if pmc_path:
+        vals = {}
+        for line in open(pmc_path):
+            parts = line.split()
+            if len(parts) >= 4 and parts[1] == "mean/dispatch":
+                vals[parts[0]] = float(parts[3])
+        per_launch_s = k_s / n_launch
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            roof["traffic"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0  # gfx950 half-count of FETCH_SIZE
+            roof["traffic_unit"] = "HBM bytes per launch"
+            roof["hbm_frac_measured"] = roof["traffic"] / per_launch_s / 1e9 / HBM_PEAK_GBS
+        if "SQ_INSTS_VALU" in vals:
+            roof["valu_issue_frac"] = vals["SQ_INSTS_VALU"] / per_launch_s / VALU_ISSUE_PEAK
+            roof["valu_instr_per_wave_sample"] = vals["SQ_INSTS_VALU"] / max(1.0, act * lags_per_launch / 64.0)
+        if "SQ_LDS_IDX_ACTIVE" in vals:
+            roof["lds_busy_frac"] = vals["SQ_LDS_IDX_ACTIVE"] / per_launch_s / LDS_CYCLES_PEAK
+            if "SQ_LDS_BANK_CONFLICT" in vals:
+                roof["lds_conflict_cycle_frac"] = vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"]
+        roof["pmc_source"] = os.path.relpath(pmc_path, ROOT)
+    stats_path = _committed("stats", name)
+    if stats_path:
+        import csv
+        with open(stats_path, newline="") as f:
+            for row in csv.DictReader(f):
+                if "k_sweep" in row.get("Name", ""):
+                    roof["kernel_profile_ms"] = float(row["AverageNs"]) * 1e-6
+                    roof["kernel_profile_source"] = os.path.relpath(stats_path, ROOT)
+                    break
+    am = np.unravel_index(np.nanargmax(corr), corr.shape)
+    out = {"metric": f"lag-points/sec, one GPU, config '{name}' (NOT the headline metric: see config.workload)",
+           "value": L * steps / elapsed, "unit": "lag-points/s", "n_gpus": 1, "n_ranks_seen": 1, "steps": steps,
+           "warmup": warm, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": what, "name": name, "lag_points": L, "lag_shape": list(lags.shape), "resident": True,
+                      "sweeps_in_flight": 1, "order": order, "parallelism": "single GPU, no collective",
+                      "step": "one synchronous sweep call, correlation map copied to the host"},
+           "roofline": roof, "precompute_ms": float(np.mean(pre)), "argmax_index": [int(i) for i in am],
+           "cpu_baseline": None}
+    if not args.no_cpu_baseline:
+        from oracle import coreg_oracle as O
+        from tests import helpers as H
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cores = int(os.environ.get("COREG_CPU_CORES", min(avail, 16)))
+        n_sample = args.cpu_sample or {"cfg4": 64 * cores, "car": 8 * cores, "order1": 32 * cores}.get(name, 2 * cores)
+        n_sample = min(n_sample, L)
+        st_o = H.oracle_state(small, hs, large, hl, lag_arrays, order=order, unit_lag=hs["CUNIT1"],
+                              **({} if carr is None else dict(shape=carr["shape"], lonlims=carr["lonlims"],
+                                                              latlims=carr["latlims"], solar_r=(SOLAR_R,))))
+        O.set_initial_header_values(st_o, use_ang2pipi=(name != "car"))
+        ref = O.prepare_reference(st_o, frame, SOLAR_R, parallelism=par)
+        subset = np.sort(np.random.default_rng(1234).choice(L, size=n_sample, replace=False))
+        log(f"[bench] CPU baseline: {n_sample} lag-points on {cores} cores ...")
+        t0 = time.perf_counter()
+        c_cpu = O.find_best_header_parameters(st_o, frame, parallelism=par, counts=cores, lag_subset=subset,
+                                              prepared_reference=ref, use_ang2pipi=(name != "car"))
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n_sample / dt, "unit": "lag-points/s", "cores": cores, "kind": "port",
+                               "sample": f"{n_sample} seeded random lag-points of this config, {cores} worker processes, "
+                                         f"{dt:.1f} s wall"}
+        d = np.abs(corr.ravel()[subset] - c_cpu.ravel()[subset])
+        out["parity_vs_cpu_sample"] = {"max_abs_dcorr": float(np.nanmax(d)), "n": int(n_sample),
+                                       "tolerance": 1e-10 if frame == "carrington" else 1e-7}
+    h.close()
+    print_line_once(json.dumps(out))
+
+
+
 def reference_run_points(np, small, large, corr):
     """89 entries of the headline map as the REFERENCE ITSELF computed them in the build container (its own
     Alignment.align_using_carrington on a sub-lattice of the lags: tests/golden/make_golden_headline_reference.py ->
@@ -357,8 +577,12 @@ def reference_run_points(np, small, large, corr):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)   # ~3.6 ms each: a timed region above one second
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=None)   # default 300: ~3.6 ms each, a timed region above one second
+    ap.add_argument("--warmup", type=int, default=None)  # default 30
+    ap.add_argument("--config", choices=["headline", "cfg2", "cfg3", "cfg4", "cfg5", "order1", "order3", "car"],
+                    default="headline",
+                    help="headline (default, the driver's line) or one of the other BASELINE configs / sweep variants on "
+                         "one GPU: same schema, roofline of that variant's kernel (profiles/r06_*_<config>.*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="sweeps in flight (one HIP stream + library context each)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement after the timed region")
@@ -383,6 +607,13 @@ def main():
                     help="N > 1: cut the lag plane in blocks (+ one all-gather) or the target grid in point shares "
                          "(+ one all-reduce of the six sums per lag); auto = points below 128 lag-points per GPU")
     args = ap.parse_args()
+    args.steps_given, args.warmup_given = args.steps is not None, args.warmup is not None
+    if args.config != "headline":
+        if args.gpus > 1 or "WORLD_SIZE" in os.environ:
+            raise SystemExit("--config other than headline runs on one GPU")
+        return main_config(args)
+    args.steps = 300 if args.steps is None else args.steps
+    args.warmup = 30 if args.warmup is None else args.warmup
 
     if args.launch == "threads" and "WORLD_SIZE" not in os.environ:
         return main_threads(args)
@@ -749,6 +980,9 @@ def main():
             "kernel": "k_sweep<TRANSLATE,2,%s>" % ("f32" if stats["small_is_f32"] else "f64"), "kernel_ms": k_ms, "lags_per_launch": lags_per_launch,
             "active_points": act, "tile_visits": visits, "flop_per_point_lag": FLOP_PER_POINT_LAG,
             "f64_instr_per_point_lag": F64_INSTR_PER_POINT_LAG,
+            # the workload-independent figure: the throughput above scales with the share of the grid inside the small
+            # FOV (631 710 of 4 194 304 points on the README grid); this does not
+            "ps_per_point_lag": k_ms * 1e9 / max(1, act * lags_per_launch),
             "traffic": None, "hbm_model": {
                 "algorithmic_bytes_per_lag": b_lag, "algorithmic_bytes_per_launch": b_lag * lags_per_launch,
                 "achieved_gbs": b_lag * lags_per_launch / k_s / 1e9, "peak_gbs": HBM_PEAK_GBS,
@@ -810,6 +1044,12 @@ def main():
         if dry:
             out["dry_run"] = True
             out["dry_run_map_ok"] = bool(np.array_equal(corr.ravel(), np.arange(L, dtype=np.float64)))
+            # what the CPU parity sample of a real run does on rank 0: a forked worker pool, ended with SIGTERM by
+            # multiprocessing -- which must not reach this rank's SIGTERM watcher
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(2) as pool:
+                out["dry_run_pool_ok"] = pool.map(abs, [-1, -2]) == [1, 2]
+            time.sleep(0.3)
         if not args.no_cpu_baseline and world > 1 and not dry:
             # N > 1: no CPU timing (that leg belongs to the N = 1 line), but the assembled map is still checked against
             # the oracle on a seeded sample of 128 lag-points

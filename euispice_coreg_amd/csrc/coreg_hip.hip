@@ -12,6 +12,7 @@
 #include <limits>
 #include <condition_variable>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -117,12 +118,25 @@ struct EventPair {
 // The noise-decided samples of ONE launch as kernel arguments: run once about the global pivots into the
 // launch's extra slab and -- when lag-points of the launch are re-evaluated -- a second time about the flagged slots'
 // own pivots (launch_sweep, coreg_finalize_sums).  The device lists the arguments point to live until the next sweep.
+// (a launch's single-sample lists kept past the next launch of the same sweep: grid-shared plate-carree sweeps)
+struct KeptTapLists {
+    DevBuf seg_slot, seg_begin, pixel, xw, yw;
+    ~KeptTapLists() {
+        seg_slot.release();
+        seg_begin.release();
+        pixel.release();
+        xw.release();
+        yw.release();
+    }
+};
 struct FixLaunch {
     std::vector<BorderFixArgs> border;
     std::vector<ParityFixArgs> parity;
     TapFixArgs tap = {};
     bool have_tap = false;
     int tap_segs = 0, tap_mode = 0;
+    long long tap_count = 0;  // entries of the lists
+    std::shared_ptr<KeptTapLists> kept;
     bool small_f32 = true;
     bool empty() const { return border.empty() && parity.empty() && !have_tap; }
 };
@@ -231,7 +245,7 @@ struct coreg_handle {
     // options
     int64_t opt_crop_reference = 1;
     int64_t opt_taper_min = 128, opt_taper_frac = -1, opt_taper_rounds = 6;  // tapered group shares (pick_taper)
-    int64_t opt_use_lds = 1, opt_clean_path = 1, opt_refine = 1, opt_refine_cond_log10 = 5, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_tile_skip = 1, opt_pitch = -1;
+    int64_t opt_use_lds = 1, opt_clean_path = 1, opt_refine = 1, opt_refine_cond_log10 = 5, opt_tile_w = 0, opt_n_groups = 0, opt_lds_bytes = (159 * 1024 * kPointGroups) / 4, opt_patch_w = 0, opt_h_series = 1, opt_h_incr = 1, opt_tile_skip = 1, opt_pitch = -1;
 
     coreg_stats stats;
     bool stats_pending = false;   // a device-output sweep is in flight: timings are collected on demand
@@ -1278,6 +1292,7 @@ struct BorderFix {  // lag-points of a launch whose border pixels are decided by
     // single samples near an integer coordinate (odd spline orders): device arrays ready for k_tap_fix
     int tap_segs = 0;
     int tap_mode = 0;
+    long long tap_count = 0;
     TapFixArgs tap = {};
 };
 
@@ -1411,6 +1426,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
     std::memset(&a.car_inv, 0, sizeof(a.car_inv));
     if (car_inv) a.car_inv = *car_inv;
     a.car_inv.order_rt = order;
+    a.car_inv.h_incr = (int)h->opt_h_incr;
 
     const dim3 grid((unsigned)((long long)g_per * n_batches)), block(kSweepThreads);
     RETCHK(join_small(h));  // the first kernel of the call that reads the image to align
@@ -1574,6 +1590,7 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
             fl.tap = t;
             fl.have_tap = true;
             fl.tap_segs = fix->tap_segs;
+            fl.tap_count = fix->tap_count;
             fl.tap_mode = fix->tap_mode;
         }
     }
@@ -1623,11 +1640,29 @@ int launch_sweep(coreg_handle* h, int mode, int order, int method, const double*
         pf.refine.enabled = refinable ? 1 : 0;
         pf.replay_precompute = h->last_precompute;
         pf.fixes = fl;  // (the slab is inside the reduced sums; the second run of the fix kernels happens on every rank)
-        // a plate-carree sweep has one launch per combination and every launch lists its single samples anew: the lists
-        // of an earlier launch are gone when coreg_finalize_sums runs -- such a launch is not re-evaluated
+        // a plate-carree sweep has one launch per combination and every launch lists its single samples anew in the
+        // handle's buffers: this launch's lists are COPIED (round 6, closes DESIGN 9 open 3 of round 5) so that
+        // coreg_finalize_sums can run the fix kernels a second time about the flagged slots' pivots, as FixLaunch lets it
+        // do for the one-launch helioprojective sweeps.  Rare path (unrotated maps, single-axis lags): blocking copies.
         if (mode == MODE_CAR && fl.have_tap) {
-            pf.refine.enabled = 0;
-            pf.fixes = FixLaunch();
+            auto kept = std::make_shared<KeptTapLists>();
+            const size_t nseg = (size_t)fl.tap_segs, cnt = (size_t)fl.tap_count;
+            HIPCHK(kept->seg_slot.reserve(std::max<size_t>(nseg, 1) * sizeof(int)));
+            HIPCHK(kept->seg_begin.reserve((nseg + 1) * sizeof(int)));
+            HIPCHK(kept->pixel.reserve(std::max<size_t>(cnt, 1) * sizeof(unsigned)));
+            HIPCHK(kept->xw.reserve(std::max<size_t>(cnt, 1) * sizeof(double)));
+            HIPCHK(kept->yw.reserve(std::max<size_t>(cnt, 1) * sizeof(double)));
+            HIPCHK(hipMemcpy(kept->seg_slot.p, fl.tap.seg_slot, nseg * sizeof(int), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(kept->seg_begin.p, fl.tap.seg_begin, (nseg + 1) * sizeof(int), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(kept->pixel.p, fl.tap.pixel, cnt * sizeof(unsigned), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(kept->xw.p, fl.tap.xw, cnt * sizeof(double), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(kept->yw.p, fl.tap.yw, cnt * sizeof(double), hipMemcpyDeviceToDevice));
+            pf.fixes.tap.seg_slot = kept->seg_slot.as<int>();
+            pf.fixes.tap.seg_begin = kept->seg_begin.as<int>();
+            pf.fixes.tap.pixel = kept->pixel.as<unsigned>();
+            pf.fixes.tap.xw = kept->xw.as<double>();
+            pf.fixes.tap.yw = kept->yw.as<double>();
+            pf.fixes.kept = kept;
         }
         h->pending_fin.push_back(pf);
     }
@@ -1980,6 +2015,7 @@ int prepare_tap_fix(coreg_handle* h, int sweep_mode, int order, const coreg_wcs2
     HIPCHK(hipMemcpy(h->tap_xw.p, xw.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->tap_yw.p, yw.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice));
     fix->tap_segs = n_seg;
+    fix->tap_count = (long long)count;
     fix->tap_mode = sweep_mode;
     fix->tap.seg_slot = h->tap_seg_slot.as<int>();
     fix->tap.seg_begin = h->tap_seg_begin.as<int>();
@@ -2323,6 +2359,8 @@ int coreg_set_option(coreg_handle* h, const char* name, int64_t value) {
         h->opt_tile_skip = value ? 1 : 0;  // 0: k_precompute evaluates every grid point (tests compare both)
     } else if (n == "h_series") {
         h->opt_h_series = value ? 1 : 0;
+    } else if (n == "h_incr") {  // homography sweeps, order 2: advance the affine terms along runs of a grid row
+        h->opt_h_incr = value ? 1 : 0;
     } else if (n == "patch_w") {
         if (value < 0 || value > kBlock) return fail(h, COREG_EINVAL, "patch_w must be in [0, 256]");
         h->opt_patch_w = value;

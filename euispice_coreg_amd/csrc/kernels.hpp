@@ -54,7 +54,7 @@ enum { MODE_TRANSLATE = 0, MODE_HOMOGRAPHY = 1, MODE_HOMOGRAPHY_SERIES = 2, MODE
 struct LaunchU {
     double m00, m01, m10, m11, b0, b1;  // MODE_CAR: native (phi, theta) [rad] -> 0-based pixel
     int order_rt;                       // ORDER == ORDER_RT kernels: the spline order (0..5)
-    int pad_;
+    int h_incr;                         // HOMOGRAPHY[_SERIES], order 2, interior LDS visits: advance along runs (tile_points)
     double box_c;     // MODE_CAR: (tile half-diagonal [rad])^2 / 2 x pixels per radian of the shifted map (car_tile_margin)
     double pole_sep;  // MODE_CAR: largest angle [rad] between the native poles of the target and of a shifted map
 };
@@ -765,18 +765,25 @@ __global__ void __launch_bounds__(256) k_precompute(const PrecomputeArgs a) {
         // order: where k_sweep knows that every sample of a visit is finite (interior window without a NaN) the count
         // and these two moments do not depend on the lag, and the lanes add them per chunk instead of per sample.
         // (The stores above are visible: the loop ends with a workgroup barrier.)
-        static_assert(kChunk >= 2, "the two chunk sums live in the pads of the chunk's first two points");
+        // Round 6: the sums live in the pads of the chunk's SECOND and THIRD point; the pad of its FIRST point says
+        // whether the chunk is a RUN -- kChunk neighbouring pixels of one grid row, (x, y), (x + 1, y), ... -- which lets
+        // the homography sweeps advance their affine terms by one addition each instead of re-evaluating them
+        // (tile_points, kIncr).  The first point's pad is what the rolling scalar prefetch holds when the chunk starts.
+        static_assert(kChunk >= 3, "run flag + the two chunk sums live in the pads of the chunk's first three points");
         Pt* tp = a.pts + tbase;
         for (int c = threadIdx.x; c < base_pos / kChunk; c += 256) {
             double sa = tp[c * kChunk].a, saa = sa * sa;
+            bool run = MODE == MODE_HOMOGRAPHY || MODE == MODE_HOMOGRAPHY_SERIES;
 #pragma unroll
             for (int k = 1; k < kChunk; ++k) {
                 const double v = tp[c * kChunk + k].a;
                 sa += v;
                 saa = fma(v, v, saa);
+                run = run && tp[c * kChunk + k].b0 == tp[c * kChunk].b0 + (double)k && tp[c * kChunk + k].b1 == tp[c * kChunk].b1;
             }
-            tp[c * kChunk].pad = sa;
-            tp[c * kChunk + 1].pad = saa;
+            tp[c * kChunk].pad = run ? 1.0 : 0.0;
+            tp[c * kChunk + 1].pad = sa;
+            tp[c * kChunk + 2].pad = saa;
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -1170,8 +1177,10 @@ __device__ __forceinline__ double gather_o2(unsigned win, int pitch, double ux, 
 // CLEAN (interior LDS visits whose window holds no NaN or infinity, Pearson method): every sample is finite, so the mask
 // is not evaluated and only the three lag-dependent sums are accumulated here; the count and the two moments of the
 // reference are added per chunk by tile_points.
+// PREMAPPED (interior LDS visits of the homography modes at order 2, tile_points kIncr): (b0, b1) IS the window-relative
+// mapped coordinate already.
 template <int MODE, int ORDER, typename TS, bool LDS, bool ROUND, bool RESID, bool INTERIOR = false, int PITCH = 0,
-          bool CLEAN = false>
+          bool CLEAN = false, bool PREMAPPED = false>
 __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __restrict__ img, int pitch,
                                           int ox, int oy, int W, int H, double wmax, double hmax, double px0, double py0,
                                           double pxw, double pyw, const H9& hm, const LaunchU& cu, double b0, double b1, double av,
@@ -1183,7 +1192,11 @@ __device__ __forceinline__ void point_lag(Acc& acc, unsigned win, const TS* __re
         // (For TRANSLATE the constant is folded into the lane's origin, which moves the float64 rounding of the sum by
         // at most one ulp of the coordinate, ~2e-13 px.)
         double ux, uy, mx = 0.0, my = 0.0;
-        if (MODE == MODE_TRANSLATE) {
+        if constexpr (PREMAPPED) {
+            static_assert(ORDER == 2, "the cubic gather wants the unshifted coordinate");
+            ux = b0;
+            uy = b1;
+        } else if (MODE == MODE_TRANSLATE) {
             ux = pxw + b0;
             uy = pyw + b1;
         } else {
@@ -1403,6 +1416,87 @@ __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __
     const double wmax = (double)(W - 1), hmax = (double)(H - 1);
     const int n_full = p_end / kChunk;
 #if defined(__HIP_DEVICE_COMPILE__) && COREG_PT_SCALAR == 2
+    // Round 6: homography modes, order 2, interior LDS visits.  The projective map of this lane,
+    // (xn, yn, w)(x, y), is affine in the grid pixel; two things are taken out of the per-sample arithmetic:
+    //  * the window offset (pxw, pyw) is folded into the map ONCE per visit: T(+off) H has rows r0 + pxw r2, r1 + pyw r2,
+    //    so the sample's window-relative coordinate is xn' / w directly (6 fma per visit instead of 2 add per sample);
+    //  * in a RUN (k_precompute: kChunk neighbouring pixels of one grid row) xn', yn' and w (or eps) of the points after
+    //    the first are the previous ones plus the x-column of the map: 3 additions instead of 6 fma.  Every chunk is
+    //    seeded afresh, so at most kChunk - 1 additions accumulate: <= 3 ulp of a window-relative coordinate (<= 160),
+    //    1e-13 px.  The bounds rule is not involved (interior visits keep 1e-9 px clear of it) and an even order has no
+    //    noise-decided tap choice inside the image, so the samples the fix kernels re-evaluate -- all on
+    //    non-interior visits at this order -- still see apply_map's own coordinate.  Odd orders keep the exact path.
+    constexpr bool kIncr = INTERIOR && LDS && ORDER == 2 && !RESID &&
+                           (MODE == MODE_HOMOGRAPHY || MODE == MODE_HOMOGRAPHY_SERIES);
+    if constexpr (kIncr) {
+        if (cu.h_incr) {
+            H9 hv = hm;
+            hv.h[0] = fma(pxw, hm.h[6], hm.h[0]);
+            hv.h[1] = fma(pxw, hm.h[7], hm.h[1]);
+            hv.h[2] = MODE == MODE_HOMOGRAPHY_SERIES ? hm.h[2] + pxw : fma(pxw, hm.h[8], hm.h[2]);
+            hv.h[3] = fma(pyw, hm.h[6], hm.h[3]);
+            hv.h[4] = fma(pyw, hm.h[7], hm.h[4]);
+            hv.h[5] = MODE == MODE_HOMOGRAPHY_SERIES ? hm.h[5] + pyw : fma(pyw, hm.h[8], hm.h[5]);
+            int c = p_begin / kChunk + pg;
+            if (c < n_full) {
+                double& anchor = hv.h[7];
+                SPt cur = spt_load(pts + c * kChunk, anchor);
+                spt_wait(cur);
+                for (; c < n_full; c += kPointGroups) {
+                    const Pt* __restrict__ q = pts + c * kChunk;
+                    const bool run = cur[7] != 0u;  // (pad of the chunk's first point = 1.0 / 0.0: uniform, SGPR test)
+                    double xn = 0.0, yn = 0.0, ww = 0.0;  // ww: eps (series) or w
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) {
+                        SPt nxt = spt_load(k + 1 < kChunk ? q + k + 1 : q + kPointGroups * kChunk, anchor);
+                        const double x = spt_f64(cur, 0), y = spt_f64(cur, 1);
+                        if (k == 0 || !run) {
+                            xn = fma(hv.h[0], x, fma(hv.h[1], y, hv.h[2]));
+                            yn = fma(hv.h[3], x, fma(hv.h[4], y, hv.h[5]));
+                            ww = MODE == MODE_HOMOGRAPHY_SERIES ? fma(hv.h[6], x, hv.h[7] * y)
+                                                                : fma(hv.h[6], x, fma(hv.h[7], y, hv.h[8]));
+                        } else {
+                            xn += hv.h[0];
+                            yn += hv.h[3];
+                            ww += hv.h[6];
+                        }
+                        double ux, uy;
+                        if (MODE == MODE_HOMOGRAPHY_SERIES) {
+                            const double qq = fma(ww, ww, -ww);  // 1 / (1 + eps) - 1 up to eps^3
+                            ux = fma(xn, qq, xn);
+                            uy = fma(yn, qq, yn);
+                        } else {
+                            double r = __builtin_amdgcn_rcp(ww);
+                            r = fma(r, fma(-ww, r, 1.0), r);
+                            ux = xn * r;
+                            uy = yn * r;
+                        }
+                        point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR, PITCH, CLEAN, true>(
+                            acc, win, img, pitch, ox, oy, W, H, wmax, hmax, px0, py0, pxw, pyw, hv, cu, ux, uy,
+                            spt_f64(cur, 2), spt_f64(cur, 3), pivot_b);
+                        if constexpr (CLEAN) {
+                            if (k == 1) acc.a += spt_f64(cur, 3);
+                            if (k == 2) acc.aa += spt_f64(cur, 3);
+                            if (k == kChunk - 1) acc.n += kChunk;
+                        }
+                        spt_wait(nxt);
+                        cur = nxt;
+                    }
+                }
+            }
+            // ragged tail (< kChunk points): the exact path below
+            if (pg == n_full % kPointGroups) {
+                for (int p = n_full * kChunk; p < p_end; ++p) {
+                    Pt pt;
+                    load_pt_uniform(pts + p, pt);
+                    point_lag<MODE, ORDER, TS, LDS, ROUND, RESID, INTERIOR, PITCH>(acc, win, img, pitch, ox, oy, W, H, wmax,
+                                                                                   hmax, px0, py0, pxw, pyw, hm, cu, pt.b0,
+                                                                                   pt.b1, pt.a, pt.pad, pivot_b);
+                }
+            }
+            return;
+        }
+    }
     {
         // rolling scalar prefetch: the s_load of point m + 1 is issued before point m's address arithmetic and is
         // drained by the s_waitcnt lgkmcnt(0) that ends point m's LDS gather (SMEM and LDS share that counter; a
@@ -1426,8 +1520,8 @@ __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __
                         spt_f64(cur, 1), spt_f64(cur, 2), spt_f64(cur, 3), pivot_b);
                     if constexpr (CLEAN) {
                         // the chunk's lag-independent sums (k_precompute left them in the pads of its first two points)
-                        if (k == 0) acc.a += spt_f64(cur, 3);
-                        if (k == 1) acc.aa += spt_f64(cur, 3);
+                        if (k == 1) acc.a += spt_f64(cur, 3);
+                        if (k == 2) acc.aa += spt_f64(cur, 3);
                         if (k == kChunk - 1) acc.n += kChunk;
                     }
                     spt_wait(nxt);  // (already drained by the gather's wait unless no lane sampled)
@@ -1449,8 +1543,8 @@ __device__ __forceinline__ void tile_points(Acc& acc, unsigned win, const TS* __
                                                                                   pt[k].b1, pt[k].a, pt[k].pad, pivot_b);
         if constexpr (CLEAN) {
             acc.n += kChunk;
-            acc.a += pt[0].pad;
-            acc.aa += pt[1].pad;
+            acc.a += pt[1].pad;
+            acc.aa += pt[2].pad;
         }
     }
 #endif
@@ -2187,6 +2281,47 @@ __global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
                 hit = (cxlo <= 0.0 && cxhi >= 0.0) || (cxlo <= a.wmax && cxhi >= a.wmax) || (cylo <= 0.0 && cyhi >= 0.0) ||
                       (cylo <= a.hmax && cyhi >= a.hmax);
             }
+            if (hit && sane && a.bounds_only) {
+                // Round 6.  Every row has a segment in which the coordinate crosses a bound of the image (the lag moves the
+                // image's edge across the grid), for every lag: on a narrow raster with tens of thousands of lag-points
+                // (BASELINE configs[3]: 78 141 x 832 rows) that is more segments than the queue holds, and the rest used
+                // to be tested pixel by pixel here -- 17.6 ms of a 40 ms sweep.  Along the chord the coordinate is
+                // c0 + s (i - i0), true value within `bulge` of it (the bound used above): a pixel can only be within
+                // tol of the bound b when |c0 + s (i - i0) - b| <= bulge, i.e. in an interval of 2 bulge / |s| pixels
+                // about the crossing.  Those few pixels (one or two per crossing) are tested at once; an axis the lag
+                // leaves invariant (|s| ~ 0: the whole segment may sit on the bound) still goes to the queue.
+                const int iend_c = (i0 + L > a.i_hi) ? a.i_hi + 1 : i1;
+                const double n = (double)(i1 - i0);
+                int clo[4], chi[4], n_cand = 0;
+                bool narrow = n >= 1.0;
+#pragma unroll
+                for (int b = 0; b < 4 && narrow; ++b) {
+                    const double c0 = b < 2 ? x0 : y0, c1 = b < 2 ? x1 : y1, bulge = b < 2 ? bulge_x : bulge_y;
+                    const double bound = (b & 1) ? (b < 2 ? a.wmax : a.hmax) : 0.0;
+                    clo[b] = 0;
+                    chi[b] = -1;
+                    if (fmin(c0, c1) - bulge > bound || fmax(c0, c1) + bulge < bound) continue;  // never near this bound
+                    const double sl = (c1 - c0) / n;
+                    if (!(fabs(sl) > 1e-3)) {
+                        narrow = false;
+                        break;
+                    }
+                    const double t = (bound - c0) / sl, w = bulge / fabs(sl) + 1e-6;
+                    const int lo = max(i0, i0 + (int)floor(t - w)), hi = min(iend_c - 1, i0 + (int)ceil(t + w));
+                    clo[b] = lo;
+                    chi[b] = hi;
+                    n_cand += max(hi - lo + 1, 0);
+                }
+                if (narrow && n_cand <= 8) {
+                    for (int b = 0; b < 4; ++b)
+                        for (int i = clo[b]; i <= chi[b]; ++i) {
+                            bool seen = false;  // (a pixel in the interval of two bounds is listed once)
+                            for (int b2 = 0; b2 < b; ++b2) seen = seen || (i >= clo[b2] && i <= chi[b2]);
+                            if (!seen) tap_scan_pixel<MODE>(a, hm, slot, i, j);
+                        }
+                    hit = false;
+                }
+            }
             if (hit) {
                 const int iend = (i0 + L > a.i_hi) ? a.i_hi + 1 : i1;  // (the shared end point belongs to the next segment)
                 const unsigned q = a.seg_list ? atomicAdd(a.seg_count, 1u) : a.seg_cap;
@@ -2401,7 +2536,7 @@ __device__ void refine_list_block(const RefineArgs& r, long long n_slots, long l
         int chunks = n > 0 ? kRefineItems / n : 1;
         chunks = chunks < 1 ? 1 : (chunks > kRefineMaxChunks ? kRefineMaxChunks : chunks);
         r.head[1] = chunks;
-        r.head[2] = 0;  // the ticket, for the next launch
+        // (head[2] is unused; k_refine's ticket is head[3], which k_refine itself leaves at zero -- ADVICE r05)
         if (refine_count && n > 0) atomicAdd((unsigned long long*)refine_count, (unsigned long long)n);
     }
 }

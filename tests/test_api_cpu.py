@@ -370,6 +370,7 @@ def test_bench_self_launches_its_ranks_gloo_world2():
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["steps"] == 3 and out["warmup"] == 1
     assert out["dry_run"] is True and out["value"] is None
     assert out["dry_run_map_ok"] is True  # gathered blocks + permutation == C-order raveled lag map
+    assert out["dry_run_pool_ok"] is True and "error" not in out  # a forked pool's SIGTERM is not this rank's
     assert [r["rank"] for r in out["per_rank"]] == [0, 1] and sum(r["lags"] for r in out["per_rank"]) == 3600
     assert out["scaling"] == "strong" and out["config"]["resident"] is True
 

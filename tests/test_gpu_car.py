@@ -290,3 +290,64 @@ def test_a_pure_crota_lag_returns_the_reference_pixel_to_itself(gpu_handle):
     finally:
         gpu_handle.set_option("tap_fix", 1)
     assert 1e-7 < np.nanmax(np.abs(raw - want)) < 1e-4
+
+
+@pytest.mark.parametrize("order", [1, 3])
+def test_grid_shared_plate_carree_launches_keep_their_single_sample_lists(gpu_handle, order):
+    """Round 6 (closes DESIGN 9 open 3 of round 5).  A plate-carree sweep is one launch per (CDELT,
+    CROTA) combination and every launch lists its noise-decided single samples anew in the handle's buffers; when the
+    GRID is shared between GPUs the ill-conditioned lag-points can only be flagged from the REDUCED sums, i.e. after the
+    last launch -- and the lists of the earlier launches were gone by then, so such launches were not re-evaluated
+    (N > 1 could differ from N = 1).  Each launch's lists are now copied and `coreg_finalize_sums` runs the fix kernels a
+    second time about the flagged slots' own pivots, as it does for the one-launch helioprojective sweeps.
+
+    Two UNROTATED Carrington maps, an odd spline order, lags in CRVAL2 alone (columns map to columns: wcslib's noise
+    picks the taps) x two CROTA lags = two launches, over data the one-pass moments cannot carry (a nearly flat reference
+    with a far-away block that moves the pivot): every lag-point is flagged.  Two and three emulated ranks give the
+    one-GPU map to 1e-10 and the two-pass oracle to 1e-7; with the single-sample pass off they do not."""
+    from euispice_coreg_amd import _lib, synthetic
+    from oracle import coreg_oracle as O
+    rng = np.random.default_rng(17)
+    small, hs, _, hl, _ = synthetic.make_car_scene(small_shape=(56, 64), large_shape=(84, 100), seed=1143, crota=0.0,
+                                                   nan_frac=0.02)
+    small = np.array(small, dtype=np.float64)
+    small[:8, :8] = np.nan
+    ref = (1000.0 + 1.0e-3 * rng.standard_normal(small.shape)).astype(np.float64)
+    ref[:6, :6] = -1.0e7
+    lags = ([0.0], [0.0, 0.0113, 0.0207], None, None, [0.0, 0.3])
+    ls = _lib.LagSet(*lags)
+    st = H.oracle_state(small, hs, ref, hs, lags, order=order, unit_lag="deg")
+    want = O.find_best_header_parameters(st, "initial_carrington", prepared_reference=ref, use_ang2pipi=False)[..., 0]
+    want = want.reshape(ls.shape)
+    assert np.isfinite(want).all() and np.abs(want).max() < 0.3
+    gpu_handle.set_small(small)
+    gpu_handle.set_reference_on_grid(ref)
+    got = gpu_handle.sweep_helioprojective(hs, hs, ls, order=order).reshape(ls.shape)
+    counts = gpu_handle.last_visit_counts()
+    assert counts["refined_lag_points"] == ls.size and counts["flagged_not_refined"] == 0, counts
+    assert np.abs(got - want).max() <= 1e-7, np.abs(got - want)
+
+    def shared(world):
+        total = None
+        try:
+            for r in range(world):
+                gpu_handle.set_point_shard(r, world)
+                gpu_handle.sweep_helioprojective(hs, hs, ls, order=order)
+                part = gpu_handle.copy_sums()
+                total = part if total is None else total + part
+            return gpu_handle.finalize_sums(total, ls.size).reshape(ls.shape)
+        finally:
+            gpu_handle.set_point_shard(0, 1)
+
+    for world in (2, 3):
+        m = shared(world)
+        assert gpu_handle.last_visit_counts()["refined_lag_points"] == ls.size
+        assert np.abs(m - want).max() <= 1e-7 and np.abs(m - got).max() <= 1e-10, (world, np.abs(m - got))
+    # the single samples matter at this level: without the pass the pure-latitude lag-points of the first launch are off
+    gpu_handle.set_option("tap_fix", 0)
+    try:
+        nofix = shared(2)
+    finally:
+        gpu_handle.set_option("tap_fix", 1)
+    d = np.abs(nofix - want)
+    assert d[0, 1:, 0, 0, 0].max() > 1e-7, d

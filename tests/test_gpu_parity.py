@@ -212,6 +212,33 @@ def test_homography_exact_division_path_equals_series_path(gpu_handle):
     assert np.nanmax(np.abs(exact - series)) <= 1e-9
 
 
+@pytest.mark.parametrize("series", [1, 0])
+@pytest.mark.parametrize("nan_frac", [0.0, 0.01])
+def test_homography_sweeps_advanced_along_runs_equal_the_per_sample_map(gpu_handle, series, nan_frac):
+    """Round 6 (`h_incr`, kernels.hpp tile_points kIncr): on interior LDS visits of an order-2 homography sweep the affine
+    terms of a lane's map are advanced by additions along runs of a grid row, with the window offset folded into the map.
+    Same map as the per-sample evaluation to 1e-11, with NaN pixels in the reference image (runs broken by culled points)
+    and without (the unmasked CLEAN path), series and exact-division variants; both against the oracle."""
+    small, hs, large, hl, _ = H.scene(small_n=160, large_n=200, nan_frac=nan_frac)
+    large = large.copy()
+    large[60:64, 70:90] = np.nan  # culled grid points: chunks that are not runs
+    lags = _lags(5, 4, crota=[0.0, -0.4])
+    want = H.oracle_helio(small, hs, large, hl, lags)
+    gpu_handle.set_option("h_series", series)
+    try:
+        maps = []
+        for incr in (1, 0):
+            gpu_handle.set_option("h_incr", incr)
+            maps.append(H.gpu_helio(gpu_handle, small, hs, large, hl, lags))
+            assert gpu_handle.last_visit_counts()["interior"] > 0
+    finally:
+        gpu_handle.set_option("h_series", 1)
+        gpu_handle.set_option("h_incr", 1)
+    H.assert_corr_close(maps[0], want, 1e-7, "helio, advanced along runs")
+    H.assert_corr_close(maps[1], want, 1e-7, "helio, per-sample map")
+    assert np.nanmax(np.abs(maps[0] - maps[1])) <= 1e-11
+
+
 def test_sweep_helioprojective_serial_semantics(gpu_handle):
     """parallelism=False path of the reference (quirk Q1): target = FULL large-FOV grid, float64 reference."""
     small, hs, large, hl, _ = H.scene(small_n=64, large_n=96)
