@@ -72,7 +72,7 @@ def kernel_metadata(lib):
              int(k.get("vgpr_spill_count", 0)) + int(k.get("private_segment_fixed_size", 0))) for k in out if "name" in k]
 
 
-# dynamic LDS the host asks for at most (coreg_hip.hip: opt_lds_bytes) and what a gfx950 workgroup can have
+# dynamic LDS the host asks for at most (host_state.hpp: opt_lds_bytes) and what a gfx950 workgroup can have
 MAX_DYNAMIC_LDS = 159 * 1024
 LDS_PER_WORKGROUP = 160 * 1024
 

@@ -95,7 +95,7 @@ LAUNCH_OVERHEAD_BATCHES = 0.75
 
 def lag_batches(b1: int, b2: int) -> int:
     """Lag batches (workgroup patches of sw x sh <= 256 lags) the library needs for a b1 x b2 block of the CRVAL plane:
-    the minimum over patch shapes, as csrc/coreg_hip.hip:choose_plan searches it."""
+    the minimum over patch shapes, as csrc/host_plan.hpp:choose_plan searches it."""
     if b1 < 1 or b2 < 1:
         return 0
     best = None

@@ -327,17 +327,31 @@ int coreg_last_visit_counts(coreg_handle* h, int64_t* counts6);
  * concerned, counts3[2] = 1 when the list exceeded "tap_cap" and nothing was applied. */
 int coreg_last_tap_fix(coreg_handle* h, int64_t* counts3);
 
-/* Tuning / test knobs (name -> integer value). Known names:
- *   "use_lds"      1 (default) stage the gather window in LDS, 0 gather from global memory
- *   "clean_path"   1 (default) interior visits whose LDS window holds only finite values skip the per-sample mask and
- *                  take the count and the reference moments from per-chunk sums; 0: always the masked arithmetic
+/* Options (name -> integer value), in three groups.  A caller of the drop-in API needs NONE of them: every default is
+ * the behaviour that reproduces the reference; euispice_coreg_amd/hdrshift sets only "async_upload" (when a reference
+ * preparation follows the upload) and the sharding options of group B.
+ *
+ * A. USER-FACING -- change what is computed or how inputs are handed over:
  *   "refine"       1 (default) lag-points whose sums are ill-conditioned (sum xx / (n var) > 1e5: a handful of samples, an
  *                  overlap inside a flat region) are re-evaluated with sums centred on the lag-point's own means and the
  *                  corrected two-pass formula -- the accuracy of c_correlate.py:39-72's means-first evaluation -- by
  *                  kernels of their own, EVERY flagged lag-point, also in grid-sharded multi-GPU sweeps
  *                  (coreg_finalize_sums flags from the reduced sums); 0: the one-pass formula everywhere
- *   "refine_cond_log10"  5 (default): log10 of that threshold; -1 re-evaluates every lag-point (tests)
- *   "refine_max"   accepted and ignored (round 4 capped the re-evaluations per block of lag slots; no cap any more)
+ *   "border_fix"   1 (default) lag-points whose map leaves an image axis invariant (the zero lag, CDELT-only lags) have
+ *                  their border pixels -- and, for odd spline orders, every pixel's tap set -- decided as the reference's
+ *                  wcslib round trip decides them; 0: the exact map decides
+ *   "tap_fix"      1 (default): helioprojective / plate-carree sweeps re-evaluate, with wcslib's own arithmetic on the
+ *                  host, the single samples whose fate hangs on the sign of the rounding noise of the reference's round
+ *                  trip (alignment.py:1038-1069).  Odd spline orders: every sample whose mapped coordinate comes back
+ *                  within 1e-8 px of an integer -- the sign picks the taps, hence which neighbour's NaN poisons the
+ *                  sample.  Even orders: only those within 1e-8 px of a BOUND of the image -- the sign decides the bounds
+ *                  rule c < 0 or c > n - 1.  One scan kernel before the sweep (0.07 ms on a 2048^2 grid x 3721 lags,
+ *                  1.3 ms on a 192 x 832 raster x 78 141 lags), one correction kernel after it when anything was listed;
+ *                  0: the exact map's coordinate decides
+ *   "tap_cap"      2^24 (default): most samples listed per sweep; beyond it nothing is applied (coreg_last_tap_fix)
+ *   "crop_reference" 1 (default) coreg_prepare_reference_* upload only the rectangle of the reference image the target
+ *                  grid can touch (bounding box of the sample coordinates, computed on the GPU; identical results),
+ *                  0 the whole image
  *   "overlap_upload"  1 (default) coreg_set_small_f32 / coreg_set_small_fits (BITPIX -32) put the image to align on an
  *                  upload stream of the handle's own: a coreg_prepare_reference_* called next does not queue behind the
  *                  image's DMA; the first call that reads the image joins the streams.  0: everything on one stream
@@ -345,36 +359,44 @@ int coreg_last_tap_fix(coreg_handle* h, int64_t* counts3);
  *                  (staging copies + DMA run there while the caller prepares the reference and plans the sweep).  The
  *                  caller's pixel buffer must then stay valid and unchanged until the next call on this handle that reads
  *                  the image (a sweep, coreg_threshold_small, coreg_synchronize, ...) has returned
- *   "tap_nan_filter"  2 (default) the odd-order pass ("tap_fix") lists only the near-integer samples that can change the
- *                  result: on the bounds rule, or -- one axis near an integer -- with the taps the two footprints share
- *                  all finite and exactly one of the two end lines not, or -- both axes -- with a non-finite pixel in the
- *                  union of the footprints; 1: the union test everywhere; 0: all near-integer samples
- *   "tap_fix"      1 (default): helioprojective sweeps re-evaluate, with wcslib's own arithmetic on the host, the samples
- *                  whose fate hangs on the sign of the rounding noise of the reference's round trip
- *                  (alignment.py:1038-1069).  Odd spline orders: every sample whose mapped coordinate comes back within
- *                  1e-8 px of an integer -- the sign picks the taps, hence which neighbour's NaN poisons the sample.
- *                  Even orders: only those within 1e-8 px of a BOUND of the image -- the sign decides the bounds rule
- *                  c < 0 or c > n - 1 (a pure CRVAL1 / CRVAL2 lag under an unrotated header keeps whole border rows /
- *                  columns of the grid there).  One scan kernel before the sweep (0.1-0.2 ms on a 2048^2 grid x 3721
- *                  lags), one correction kernel after it when anything was listed; 0: the homography's coordinate decides
- *   "tap_cap"      2^24 (default): most samples listed per sweep; beyond it nothing is applied (coreg_last_tap_fix)
- *   "tile_w"       0 (default, auto) or a power of two in [4, 256]: grid-tile width in points (tile = 1024 pts)
- *   "n_groups"     0 (default, auto): tile groups (partial-sum slabs) per lag batch
- *   "lds_bytes"    dynamic LDS per workgroup for the float64 gather window (default and max 159 KiB)
- *   "h_series"     1 (default) helioprojective maps with |projective term| < 4e-6 invert 1 + eps as 1 - eps + eps^2
- *                  (exact to float64 there) instead of dividing; 0 always divide
- *   "patch_w"      0 (default, auto) or the maximum width, in CRVAL1 lags, of a workgroup's lag patch
- *   "taper_frac"   -1 (default, automatic) / 0 equal shares of the grid points per tile group / n: the last n/1024 of the
- *                  groups get linearly smaller shares (down to "taper_min"/1024, default 128) and the others more;
- *                  automatic = 512 for launches of at least "taper_rounds" (default 6) rounds of workgroups and at least 128 tile groups
- *   "crop_reference" 1 (default) coreg_prepare_reference_* upload only the rectangle of the reference image the target
- *                  grid can touch (bounding box of the sample coordinates, computed on the GPU; identical results),
- *                  0 the whole image
- *   "combo_begin", "combo_end"  multi-GPU sharding by (cdelt1, cdelt2, crota) combination: the NEXT sweep call covers
+ *
+ * B. MULTI-GPU PLUMBING -- set by the host side that shards a sweep (parallel.py, csrc/multi.hpp), not by users:
+ *   "shard_world", "shard_rank"  grid shares: above (coreg_copy_sums / coreg_finalize_sums)
+ *   "combo_begin", "combo_end"  sharding by (cdelt1, cdelt2, crota) combination: the NEXT sweep call covers
  *                  only the combinations [begin, end) of the inner C-order index (i_cdelt1 * n_cdelt2 + i_cdelt2) * n_crota
  *                  + i_crota; its output (and lag_begin / lag_end) is the C-order array [n_crval1][n_crval2][end - begin].
  *                  One-shot: taken off the handle at the very top of that call, before any validation -- it leaves
  *                  "all combinations" behind whether it succeeds, fails late or fails at once.
+ *
+ * C. TEST / TUNING KNOBS -- identical results (to summation rounding) at any setting; they exist so that the tests can
+ *    hold one code path against another and the profiles can sweep a parameter.  Not part of the drop-in surface:
+ *   "use_lds"      1 (default) stage the gather window in LDS, 0 gather from global memory
+ *   "clean_path"   1 (default) interior visits whose LDS window holds only finite values skip the per-sample mask and
+ *                  take the count and the reference moments from per-chunk sums; 0: always the masked arithmetic
+ *   "h_series"     1 (default) helioprojective maps with |projective term| < 4e-6 invert 1 + eps as 1 - eps + eps^2
+ *                  (exact to float64 there) instead of dividing; 0 always divide
+ *   "h_incr"       1 (default) order-2 homography sweeps fold the LDS window offset into each lane's map once per tile
+ *                  visit and advance the map's affine terms by additions along runs of a grid row (round 6; maps equal
+ *                  to 1e-11); 0: every sample evaluates the map from the pixel
+ *   "refine_cond_log10"  5 (default): log10 of the "refine" threshold; -1 re-evaluates every lag-point
+ *   "refine_max"   accepted and ignored (round 4 capped the re-evaluations per block of lag slots; no cap any more)
+ *   "tap_nan_filter"  2 (default) the odd-order pass ("tap_fix") lists only the near-integer samples that can change the
+ *                  result: on the bounds rule, or -- one axis near an integer -- with the taps the two footprints share
+ *                  all finite and exactly one of the two end lines not, or -- both axes -- with a non-finite pixel in the
+ *                  union of the footprints; 1: the union test everywhere; 0: all near-integer samples
+ *   "tile_skip"    1 (default) Carrington precompute drops whole tiles that provably miss the cull box; 0 evaluates them
+ *   "tile_w"       0 (default, auto) or a power of two in [4, 256]: grid-tile width in points (tile = 1024 pts)
+ *   "n_groups"     0 (default, auto): tile groups (partial-sum slabs) per lag batch
+ *   "lds_bytes"    dynamic LDS per workgroup for the float64 gather window (default and max 159 KiB)
+ *   "pitch"        -1 (default, auto): compile-time LDS row pitch of the order-2 / order-3 Carrington kernels; 0 per-visit
+ *   "skew"         accepted and ignored (a row skew against bank conflicts, measured slower in round 2)
+ *   "patch_w"      0 (default, auto) or the maximum width, in CRVAL1 lags, of a workgroup's lag patch
+ *   "taper_frac"   -1 (default, automatic) / 0 equal shares of the grid points per tile group / n: the last n/1024 of the
+ *                  groups get linearly smaller shares (down to "taper_min"/1024, default 128) and the others more;
+ *                  automatic = 512 for launches of at least "taper_rounds" (default 6) rounds of workgroups and at least
+ *                  128 tile groups
+ * coreg_multi_set_option: "image_shares" (A: 1 = row shares + one all-gather of the image to align when RCCL is in use,
+ * 0 = every device copies the whole image), "force_mode" (C: one partition on any lag set).
  * Returns COREG_EINVAL for unknown names. */
 int coreg_set_option(coreg_handle* h, const char* name, int64_t value);
 

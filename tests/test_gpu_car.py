@@ -132,11 +132,9 @@ def test_fuzz_car(gpu_handle, seed):
     H.assert_corr_close(got, want, 1e-7, f"fuzz CAR seed={seed}")
 
 
-def _sub_map_case(gpu_handle, seed, force_order=None):
-    """One random pair of Carrington maps through the sub-map semantics, lag axes through exactly zero: (GPU map, oracle
-    map, lags, order, header of the map to align)."""
-    from euispice_coreg_amd import _lib, synthetic
-    from oracle import coreg_oracle as O
+def _sub_map_scene(seed, force_order=None):
+    """One random pair of Carrington maps, lag axes through exactly zero: (small, hs, large, hl, lags, order)."""
+    from euispice_coreg_amd import synthetic
     rng = np.random.default_rng(seed)
     ny, nx = int(rng.integers(40, 90)), int(rng.integers(40, 90))
     cd = (0.0101 * rng.uniform(0.8, 1.3) * rng.choice([1.0, -1.0]), 0.0099 * rng.uniform(0.8, 1.3))
@@ -161,6 +159,14 @@ def _sub_map_case(gpu_handle, seed, force_order=None):
     order = int(rng.choice([1, 2]))
     if force_order is not None:
         order = int(force_order)
+    return small, hs, large, hl, lags, order
+
+
+def _sub_map_case(gpu_handle, seed, force_order=None):
+    """The pair through the sub-map semantics: (GPU map, oracle map, lags, order, header of the map to align)."""
+    from euispice_coreg_amd import _lib
+    from oracle import coreg_oracle as O
+    small, hs, large, hl, lags, order = _sub_map_scene(seed, force_order)
     ls = _lib.LagSet(*lags)
     gpu_handle.set_small(small)
     gpu_handle.prepare_reference_helioprojective(large, hl, hs, order)
@@ -305,16 +311,19 @@ def test_grid_shared_plate_carree_launches_keep_their_single_sample_lists(gpu_ha
     picks the taps) x two CROTA lags = two launches, over data the one-pass moments cannot carry (a nearly flat reference
     with a far-away block that moves the pivot): every lag-point is flagged.  Two and three emulated ranks give the
     one-GPU map to 1e-10 and the two-pass oracle to 1e-7; with the single-sample pass off they do not."""
-    from euispice_coreg_amd import _lib, synthetic
+    from euispice_coreg_amd import _lib
     from oracle import coreg_oracle as O
     rng = np.random.default_rng(17)
-    small, hs, _, hl, _ = synthetic.make_car_scene(small_shape=(56, 64), large_shape=(84, 100), seed=1143, crota=0.0,
-                                                   nan_frac=0.02)
+    # the pair of tests/deep_fuzz_car.py's seed 1143 (unrotated, 1 % NaN pixels; 3e-6 .. 1.7e-3 on its pure-latitude
+    # lag-points without the single-sample pass), its reference swapped for the ill-conditioned one
+    small, hs, _, _, lags0, _ = _sub_map_scene(1143)
+    assert hs["CROTA"] == 0.0 and np.isnan(small).any()
     small = np.array(small, dtype=np.float64)
     small[:8, :8] = np.nan
     ref = (1000.0 + 1.0e-3 * rng.standard_normal(small.shape)).astype(np.float64)
     ref[:6, :6] = -1.0e7
-    lags = ([0.0], [0.0, 0.0113, 0.0207], None, None, [0.0, 0.3])
+    l2 = np.unique(np.concatenate([np.asarray(lags0[1]), [0.0113]]))
+    lags = ([0.0], l2, None, None, [0.0, 0.3])
     ls = _lib.LagSet(*lags)
     st = H.oracle_state(small, hs, ref, hs, lags, order=order, unit_lag="deg")
     want = O.find_best_header_parameters(st, "initial_carrington", prepared_reference=ref, use_ang2pipi=False)[..., 0]
@@ -350,4 +359,4 @@ def test_grid_shared_plate_carree_launches_keep_their_single_sample_lists(gpu_ha
     finally:
         gpu_handle.set_option("tap_fix", 1)
     d = np.abs(nofix - want)
-    assert d[0, 1:, 0, 0, 0].max() > 1e-7, d
+    assert d[0, 1:, 0, 0, 0].max() > 1e-7, d   # (l2[0] = 0 is the identity lag: k_parity_fix's)
