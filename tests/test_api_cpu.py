@@ -643,3 +643,26 @@ def test_gzip_compressed_fits_files_are_opened_transparently(tmp_path):
     assert gzip.open(out_gz, "rb").read() == open(out_plain, "rb").read()
     assert fits_io.read_header(out_gz, -1)["CRVAL1"] == pytest.approx(10.0 + R.shift_arcsec[0])
     assert np.array_equal(fits_io.read_image(out_gz, -1)[0], img)
+
+
+def test_bench_counted_flop_of_every_variant_and_config_arguments():
+    """`bench.py --config`: the counted float64 flop per (point, lag) of each sweep variant follows the headline's
+    convention (42 for TRANSLATE order 2), and a variant other than the headline refuses N > 1."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("coreg_bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b._variant_flop("TRANSLATE", 2, False) == b.FLOP_PER_POINT_LAG == 42.0
+    assert b._variant_flop("TRANSLATE", 1, False) == 23.0 and b._variant_flop("TRANSLATE", 3, False) == 78.0
+    assert b._variant_flop("HOMOGRAPHY_SERIES", 2, True) == 60.0 and b._variant_flop("HOMOGRAPHY", 2, True) == 62.0
+    assert b._variant_flop("CAR", 2, True) == 72.0
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg2", "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "one GPU" in (p.stderr + p.stdout)
+    line = json_line = b.error_line("x")
+    import json
+    d = json.loads(line)
+    assert d["value"] is None and d["error"] == "x" and d["unit"] == "lag-points/s" and json_line
