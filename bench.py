@@ -72,7 +72,7 @@ def log(*a):
 # ---- N > 1 never ends without a line -------------------------------------------------------------
 # The reference joins its workers in a busy-wait with no limit (alignment.py:723-744): a worker that dies leaves zeros,
 # one that hangs leaves the caller waiting for ever.  Here every wait has a limit and every way out prints ONE JSON line:
-#   * the process group is created with a timeout (COREG_BENCH_PG_TIMEOUT_S, default 120 s: rendezvous and, with RCCL,
+#   * the process group is created with a timeout (COREG_BENCH_PG_TIMEOUT_S, default 300 s: rendezvous and, with RCCL,
 #     every collective -- torch's watchdog ends the rank when one stays out that long);
 #   * every rank has a deadline (COREG_BENCH_DEADLINE_S, default 900 s) and a SIGTERM watcher (torchrun ends the
 #     surviving ranks with SIGTERM when one of them dies) on a thread of its own, so that a main thread stuck inside a
@@ -668,7 +668,7 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         import datetime
-        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("COREG_BENCH_PG_TIMEOUT_S", "120")))
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("COREG_BENCH_PG_TIMEOUT_S", "300")))
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
         else:
