@@ -129,3 +129,22 @@ def test_cfg5_at_4096_the_oracle_equals_the_references_own_code_on_the_cdelt_pla
         assert rc == 0
         for k, w in zip(K.CARDS, want):
             assert abs(getattr(got, k.lower()) - w) <= 4e-16 * max(abs(w), 1e-3), (k, idx, getattr(got, k.lower()), w)
+
+
+@pytest.mark.parametrize("name", K.scene_names())
+def test_products_correct_pointing_header_gives_the_references_cards(name):
+    """`euispice_coreg_amd.utils.header.correct_pointing_header` (what `AlignmentResults.write_corrected_fits`
+    / `return_corrected_header` apply) against the cards the REFERENCE's function produced from the same header and lags
+    (Util.py:161-215), CDELT lags included -- 30 headers over three scenes, in memory (before astropy rounds to 16 digits)."""
+    from euispice_coreg_amd.utils import header as hdrutil
+    _, hs, _, _, _, _ = K.scene(name)
+    n = 0
+    for c in K.corrected(name):
+        h = dict(hs)
+        a = [None if v == 0.0 else float(v) for v in c["lag"]]   # as the generator handed them to the reference
+        hdrutil.correct_pointing_header(h, lag_cdelt1=a[2], lag_cdelt2=a[3], lag_crota=a[4], lag_crval1=a[0], lag_crval2=a[1])
+        for k in K.CARDS:
+            w = c["memory"][k]
+            assert abs(h[k] - w) <= 4e-16 * max(abs(w), 1e-3 if k.startswith("PC") else 0.0), (k, c["index"], h[k], w)
+        n += 1
+    assert n >= 8
