@@ -339,16 +339,26 @@ inline double multi_rccl_wait_limit() {
 // cannot hold the device -- far enough above every wait limit the tests use (0.4 s) that a recovery released by this
 // self-limit cannot pass for one released by the abort path.  The flag is COHERENT (fine-grained)
 // page-locked memory, re-read with a system-scope atomic load on every turn: a host store reaches the spinning wave.
-__global__ void k_test_stall(int* release) {
+__global__ void k_test_stall(int* release, int legacy) {
     const long long t0 = wall_clock64();
+    if (legacy) {  // (round 5's form, kept for the A/B of DESIGN 6: a plain volatile load of plain page-locked memory)
+        volatile int* r = release;
+        while (*r == 0 && wall_clock64() - t0 < 1200000000LL) __builtin_amdgcn_s_sleep(64);
+        return;
+    }
     while (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 &&
            wall_clock64() - t0 < 1200000000LL)  // 100 MHz counter: 12 s
         __builtin_amdgcn_s_sleep(64);
 }
+inline int multi_test_stall_legacy() {
+    const char* env = std::getenv("COREG_RCCL_TEST_STALL_LEGACY");
+    return env && std::atoi(env) == 1 ? 1 : 0;
+}
 struct StallFlag {
     int* p = nullptr;
     StallFlag() {
-        if (hipHostMalloc((void**)&p, sizeof(int), hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) p = nullptr;
+        const unsigned flags = multi_test_stall_legacy() ? hipHostMallocPortable : (hipHostMallocPortable | hipHostMallocCoherent);
+        if (hipHostMalloc((void**)&p, sizeof(int), flags) != hipSuccess) p = nullptr;
         if (p) __atomic_store_n(p, 0, __ATOMIC_SEQ_CST);
     }
     ~StallFlag() {
@@ -517,7 +527,7 @@ int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out, bool p
             if (multi_test_stall() && stall.p) {
                 (void)multi_run(m, [&](int k) {
                     RETCHK(bind_device(m->h[k]));
-                    hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, m->h[k]->stream, stall.p);
+                    hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, m->h[k]->stream, stall.p, multi_test_stall_legacy());
                     return COREG_OK;
                 });
             } else {
@@ -624,7 +634,7 @@ int multi_sweep(coreg_multi* m, const coreg_lags* lags, double* corr_out, bool p
         if (multi_test_stall() && stall.p) {
             (void)multi_run(m, [&](int k) {
                 RETCHK(bind_device(m->h[k]));
-                hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, m->h[k]->stream, stall.p);
+                hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, m->h[k]->stream, stall.p, multi_test_stall_legacy());
                 return COREG_OK;
             });
         } else {
