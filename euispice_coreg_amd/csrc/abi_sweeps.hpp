@@ -369,8 +369,10 @@ static int sweep_car(coreg_handle* h, const coreg_wcs2d* hdr_target, const coreg
         RETCHK(fill_nan(h, out_dev, n_out));
         return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
     }
+    trace("sweep_helioprojective: lane parameters laid out");
     RETCHK(upload_plan(h, params, outidx, out_dev, n_out));
     RETCHK(prepare_sharded(h, outidx.size(), n_out, lag_begin));
+    trace("sweep_helioprojective: plan in page-locked memory");
 
     PrecomputeArgs pa;
     std::memset(&pa, 0, sizeof(pa));
@@ -467,6 +469,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
         return sweep_car(h, hdr_target, hdr_small, lags, d, order, method, cdelt_semantics, lag_begin, lag_end, corr_out,
                          out_on_device, out_dev);
 
+    trace("sweep_helioprojective: enter (checks done)");
     // ---- plan: local geometry from the maps of the central lag and of its two neighbours
     Geometry geo;
     {
@@ -585,6 +588,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                 }
             }
     };
+    trace("sweep_helioprojective: geometry + lag family ready");
     const unsigned plan_threads = (d.nc >= 2 && (long long)d.nc * d.n1 * d.n2 >= 16384)
                                       ? std::min<unsigned>({8u, (unsigned)d.nc, std::max(1u, std::thread::hardware_concurrency())})
                                       : 1u;
@@ -656,6 +660,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
         RETCHK(fill_nan(h, out_dev, n_out));
         return end_sweep(h, n_out, corr_out, out_on_device, out_dev);
     }
+    trace("sweep_helioprojective: combinations planned");
     const size_t ns = outidx.size();
     std::vector<double> params(9 * ns);
     double eps_max = 0.0;  // largest |h6 x + h7 y| over the target grid and all lags
@@ -728,6 +733,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
     }
     h->tap_last[0] = h->tap_last[1] = h->tap_last[2] = 0;
     const double tap_box[4] = {pa.f0lo, pa.f0hi, pa.f1lo, pa.f1hi};
+    trace("sweep_helioprojective: precompute launched");
     if (tap_fixing)
         RETCHK(prepare_tap_fix(
             h, sweep_mode, order, *hdr_target, (long long)ns, tap_skip, tap_box,
@@ -738,6 +744,7 @@ int coreg_sweep_helioprojective(coreg_handle* h, const coreg_wcs2d* hdr_target, 
                 return hl;
             },
             &fix));
+    trace("sweep_helioprojective: single-sample scan done");
     RETCHK(launch_sweep(h, sweep_mode, order, method, h->lane_params.as<double>(), h->out_index.as<long long>(), n_batches,
                         n_tiles, lag_begin, out_dev, nullptr, &fix, 0,
                         pick_pitch(h, plan, h->opt_use_lds ? lds_window_elems(h) : 0, order)));
