@@ -279,3 +279,21 @@ def test_readme_spice_example_runs_to_its_last_line(tmp_path):
         m = np.isfinite(a) & np.isfinite(b)
         return np.corrcoef(a[m], b[m])[0, 1]
     assert pearson(c["reference"], c["after"]) > pearson(c["reference"], c["before"])
+
+
+@pytest.mark.parametrize("name", ["order1", "cfg4"])
+def test_bench_config_lines_carry_the_variant_s_roofline(name):
+    """`python bench.py --config NAME`: one JSON line with the headline's schema for another sweep variant --
+    the variant's own counted flop, ps per (point x lag), kernel time from the library's HIP events, and a CPU sample of
+    that config checked against the map."""
+    from tests.test_api_cpu import _run_bench
+    out = _run_bench({"COREG_CPU_CORES": "8"}, "--config", name, "--steps", "2", "--warmup", "1", "--cpu-sample", "8",
+                     timeout=600)
+    r = out["roofline"]
+    assert out["config"]["name"] == name and out["n_gpus"] == 1 and out["value"] > 0 and out["unit"] == "lag-points/s"
+    assert r["flop_per_point_lag"] == {"order1": 23.0, "cfg4": 62.0}[name] and 0.0 < r["frac"] < 1.0
+    assert r["kernel"].startswith({"order1": "k_sweep<TRANSLATE,1", "cfg4": "k_sweep<HOMOGRAPHY,2"}[name])
+    assert 0.5 < r["ps_per_point_lag"] < 5.0 and r["kernel_ms"] > 0 and r["lags_per_launch"] * r["launches_per_sweep"] == out["config"]["lag_points"]
+    p = out["parity_vs_cpu_sample"]
+    assert p["n"] == 8 and p["max_abs_dcorr"] <= p["tolerance"]
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
