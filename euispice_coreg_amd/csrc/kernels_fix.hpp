@@ -415,8 +415,8 @@ __global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
                 // to be tested pixel by pixel here -- 17.6 ms of a 40 ms sweep.  Along the chord the coordinate is
                 // c0 + s (i - i0), true value within `bulge` of it (the bound used above): a pixel can only be within
                 // tol of the bound b when |c0 + s (i - i0) - b| <= bulge, i.e. in an interval of 2 bulge / |s| pixels
-                // about the crossing.  Those few pixels (one or two per crossing) are tested at once; an axis the lag
-                // leaves invariant (|s| ~ 0: the whole segment may sit on the bound) still goes to the queue.
+                // about the crossing.  The integers of that interval -- usually none -- are tested at once; an axis the
+                // lag leaves invariant (|s| ~ 0: the whole segment may sit on the bound) still goes to the queue.
                 const int iend_c = (i0 + L > a.i_hi) ? a.i_hi + 1 : i1;
                 const double n = (double)(i1 - i0);
                 int clo[4], chi[4], n_cand = 0;
@@ -433,8 +433,11 @@ __global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
                         narrow = false;
                         break;
                     }
+                    // pixel i0 + j can be within tol of the bound only if |c0 + sl j - bound| <= bulge, i.e. |j - t| <= w: the
+                    // INTEGERS of [t - w, t + w] (w ~ 1e-6 px for these maps: almost always none -- the crossing falls
+                    // between two pixels -- so that nothing at all is read or mapped for this row)
                     const double t = (bound - c0) / sl, w = bulge / fabs(sl) + 1e-6;
-                    const int lo = max(i0, i0 + (int)floor(t - w)), hi = min(iend_c - 1, i0 + (int)ceil(t + w));
+                    const int lo = max(i0, i0 + (int)ceil(t - w)), hi = min(iend_c - 1, i0 + (int)floor(t + w));
                     clo[b] = lo;
                     chi[b] = hi;
                     n_cand += max(hi - lo + 1, 0);
