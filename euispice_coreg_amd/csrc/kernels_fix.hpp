@@ -389,6 +389,27 @@ __global__ void __launch_bounds__(256) k_tap_scan(const TapScanArgs a) {
                 const double rxlo = fmin(gx0, gx1) - row_bx, rxhi = fmax(gx0, gx1) + row_bx;
                 const double rylo = fmin(gy0, gy1) - row_by, ryhi = fmax(gy0, gy1) + row_by;
                 if (ceil(rxlo) > rxhi && ceil(rylo) > ryhi) continue;  // no integer offset anywhere along this row
+                if (a.bounds_only && lr >= 1.0) {
+                    // even orders (round 6): the same crossing argument as in the segment loop below, over the whole row --
+                    // pixel a.i_lo + j can be within tol of a bound b only if |c0 + s j - b| <= row bound, i.e. j within
+                    // w of the chord's crossing t; no integer there for any of the four bounds, and no axis along which
+                    // the row is (nearly) invariant: nothing on this row can be on the bounds rule
+                    bool none = true;
+#pragma unroll
+                    for (int b = 0; b < 4 && none; ++b) {
+                        const double c0 = b < 2 ? x0 : y0, c1 = b < 2 ? xe : ye, rb = b < 2 ? row_bx : row_by;
+                        const double bound = (b & 1) ? (b < 2 ? a.wmax : a.hmax) : 0.0;
+                        if (fmin(c0, c1) - rb > bound || fmax(c0, c1) + rb < bound) continue;  // never near this bound
+                        const double sl = (c1 - c0) / lr;
+                        if (!(fabs(sl) > 1e-3)) {
+                            none = false;
+                            break;
+                        }
+                        const double t = (bound - c0) / sl, w = rb / fabs(sl) + 1e-6;
+                        none = ceil(t - w) > floor(t + w);
+                    }
+                    if (none) continue;
+                }
             }
         }
         for (int i0 = a.i_lo; i0 <= a.i_hi; i0 += L) {
