@@ -346,7 +346,7 @@ int coreg_last_tap_fix(coreg_handle* h, int64_t* counts3);
  *                  within 1e-8 px of an integer -- the sign picks the taps, hence which neighbour's NaN poisons the
  *                  sample.  Even orders: only those within 1e-8 px of a BOUND of the image -- the sign decides the bounds
  *                  rule c < 0 or c > n - 1.  One scan kernel before the sweep (0.07 ms on a 2048^2 grid x 3721 lags,
- *                  1.3 ms on a 192 x 832 raster x 78 141 lags), one correction kernel after it when anything was listed;
+ *                  0.4 ms on a 192 x 832 raster x 78 141 lags), one correction kernel after it when anything was listed;
  *                  0: the exact map's coordinate decides
  *   "tap_cap"      2^24 (default): most samples listed per sweep; beyond it nothing is applied (coreg_last_tap_fix)
  *   "crop_reference" 1 (default) coreg_prepare_reference_* upload only the rectangle of the reference image the target
