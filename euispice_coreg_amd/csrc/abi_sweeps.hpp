@@ -793,7 +793,42 @@ int coreg_finalize_sums(coreg_handle* h, const double* sums, int sums_on_device,
     }
     const size_t n_pending = h->pending_fin.size();
     size_t points_of = n_pending - 1;  // the launch whose compacted points the handle holds: the sweep's last one
-    for (size_t ip = 0; ip < n_pending; ++ip) {
+    // a plate-carree sweep has one pending launch per combination, and asking each one "anything flagged?"
+    // used to cost a host round trip apiece.  With several launches pending, all of them are finalized and their flags
+    // COUNTED first (k_refine_list adds into a counter of its own, counters[2]): ONE read-back -- and when the total is
+    // zero, the normal case, that was all.  Otherwise the per-launch pass below runs as before (k_finalize is idempotent).
+    bool probe_says_nothing_flagged = false;
+    if (n_pending > 1) {
+        long long* probe = h->counters.as<long long>() + 2;
+        HIPCHK(hipMemsetAsync(probe, 0, sizeof(long long), h->stream));
+        for (size_t ip = 0; ip < n_pending; ++ip) {
+            const coreg_handle::PendingFinalize& pf = h->pending_fin[ip];
+            FinalizeArgs f = {};
+            RETCHK(fill_refine(h, &f.refine, pf.refine.mode, pf.refine.order, pf.refine.lane_params, pf.refine.car_inv,
+                               pf.n_slots));
+            f.refine.enabled = pf.refine.enabled;
+            f.refine_count = nullptr;  // (the counters of the sweep are written by the pass that re-evaluates)
+            f.partials = h->sums.as<double>() + pf.slot_off;
+            f.n_groups = 1;
+            f.n_slots = pf.n_slots;
+            f.part_stride = h->sums_slots;
+            f.out_index = h->fin_outidx.as<long long>() + pf.slot_off;
+            f.lag_begin = pf.lag_begin;
+            f.out = out_dev;
+            f.residus = pf.residus;
+            f.n_required = (long long)h->gW * h->gH;
+            hipLaunchKernelGGL(k_finalize, dim3((unsigned)((pf.n_slots + kFinSlots - 1) / kFinSlots)),
+                               dim3(kFinSlots * kFinLanes), 0, h->stream, f);
+            if (f.refine.enabled)
+                hipLaunchKernelGGL(k_refine_list, dim3(1), dim3(kListThreads), 0, h->stream, f.refine, pf.n_slots, probe);
+        }
+        HIPCHK(hipGetLastError());
+        long long flagged = 0;
+        HIPCHK(hipMemcpyAsync(&flagged, probe, sizeof(flagged), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        probe_says_nothing_flagged = flagged == 0;
+    }
+    for (size_t ip = 0; ip < n_pending && !probe_says_nothing_flagged; ++ip) {
         const coreg_handle::PendingFinalize& pf = h->pending_fin[ip];
         FinalizeArgs f = {};
         // flags from the REDUCED sums: the same on every rank.  (work-space pointers taken afresh: a later launch of the
